@@ -1,0 +1,174 @@
+/*
+ * lav_amd.h - C ABI of liblav_amd.so: the MI355X (gfx950) kernels of the LAV per-frame
+ * perception -> prediction -> planning forward path.
+ *
+ * The reference (dotchen/LAV) has no native code and no FFI: its "operator boundary" for this
+ * path is a set of third-party/torch ops called from Python (level B3).
+ * Each entry point below replaces one such call site; the reference file:line it replaces is
+ * cited on the declaration.  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add, and lav_amd/_lib.py is that stub as shipped here.
+ *
+ * Conventions
+ *   - plain C: device pointers are raw `void*`/`float*` into HBM, sizes are ints, `stream` is a
+ *     hipStream_t passed as void* (NULL = the legacy default stream).  No torch types.
+ *   - every call only ENQUEUES work on `stream`; nothing synchronises the host.
+ *   - return value: 0 on success, a negative LAV_E* code otherwise; lav_last_error() returns a
+ *     thread-local message.  Inputs are never written.
+ *   - tensors are dense row-major float32 unless stated; index outputs are int32.
+ *   - there is no CPU fallback: on a box without a gfx950 device every entry point fails.
+ */
+#ifndef LAV_AMD_H
+#define LAV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAV_ABI_VERSION 1
+
+#define LAV_OK 0
+#define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
+#define LAV_EHIP (-2)      /* a HIP runtime call failed */
+#define LAV_EWORKSPACE (-3)/* workspace too small */
+
+int lav_abi_version(void);
+const char *lav_last_error(void);
+/* number of HIP devices visible, or a negative error.  Used by the loader to fail loudly. */
+int lav_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. PointPillars: dynamic voxelisation + decoration + PointNet + scatter-max + dense canvas.
+ *    Replaces PointPillarNet.forward, lav/models/point_pillar.py:92-116, i.e. grid_locations
+ *    (:70-79), coords.unique(dim=0) (:82), decorate incl. torch_scatter.scatter_mean (:55-68),
+ *    DynamicPointNet incl. torch_scatter.scatter_max (:28-35) and scatter_points (:87-90).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lav_grid {
+    float min_x, max_x, min_y, max_y; /* metres; keep x in [min_x,max_x), y in [min_y,max_y) */
+    float ppm;                        /* pixels per metre */
+    int nx, ny;                       /* (max_x-min_x)*ppm, (max_y-min_y)*ppm : number of xi / yi cells */
+} lav_grid;
+
+/* PointNet weights with eval-mode BatchNorm1d folded in (host does the folding once):
+ *   h1 = relu(f @ w1 + b1),  h2 = relu(h1 @ w2 + b2);  w1 [D+5][C], w2 [C][C], row-major. */
+typedef struct lav_pointnet {
+    const float *w1, *b1, *w2, *b2;
+    int num_input; /* D+5 (16 for the v2 agent) */
+    int channels;  /* C (64) */
+} lav_pointnet;
+
+/* Bytes of scratch lav_pillar_scatter needs for `batch` clouds of at most `max_points` points. */
+size_t lav_pillar_workspace_bytes(int batch, int max_points, const lav_grid *grid);
+
+/*
+ * points      [batch][max_points][D]   (a single cloud: batch=1, max_points=N)
+ * h_num_points host array [batch]: only the first h_num_points[b] rows of cloud b are used (:98)
+ * canvas      out [batch][C][ny][nx]; every element is written (empty cells = 0)
+ * Optional index outputs (NULL to skip; they cost extra passes and exist for parity/training):
+ *   unique_coords out [<= total kept][3] rows (b, xi, yi) sorted lexicographically  (:82)
+ *   inverse       out [total kept]  pillar row of each kept point, in input order   (:82)
+ *   counts        out [2] = { number of pillars P, number of kept points }
+ */
+int lav_pillar_scatter(const float *points, const int *h_num_points, int batch, int max_points, int D,
+                       const lav_grid *grid, const lav_pointnet *net, float *canvas,
+                       int *unique_coords, int *inverse, int *counts,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Point painting: LiDAR->camera projection + semantic gather for up to 4 cameras.
+ *    Replaces InferModel.forward_paint / point_painting / CoordConverter.forward,
+ *    team_code_v2/model_inference.py:44-50, 75-93, 280-297.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lav_camera {
+    float K[9];    /* row-major 3x3 intrinsics                       (model_inference.py:259-262) */
+    float l2w[16]; /* row-major 4x4 lidar_to_world                    (:264-266) */
+    float w2c[16]; /* row-major 4x4 world_to_cam                      (:268-271) */
+} lav_camera;
+
+/*
+ * lidar    [n][lidar_dim]  (xyz in columns 0..2; lidar_dim >= 3)
+ * sem      [ncam][sem_c+1][h][w] softmax probabilities; channel 0 is the "other" class
+ * fused    out [n][lidar_dim + sem_c] = cat(lidar, painted) where, per camera in order (later
+ *          cameras overwrite), painted = sem[cam][1+c][v][u] * (1 - sem[cam][0][v][u]) for points
+ *          whose truncated (u, v, depth) satisfy depth>=0, 0<=u<w, 0<=v<h; else 0.
+ * uvz      optional out [ncam][n][3] int32 truncated projections (INT32_MIN where the reference's
+ *          .long() is out of range); NULL to skip.
+ */
+int lav_paint(const float *lidar, int n, int lidar_dim, const float *sem, int ncam, int sem_c, int h, int w,
+              const lav_camera *h_cams, float *fused, int *uvz, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. GRU waypoint decoders.  Replaces UniPlanner.cast (team_code_v2/models/uniplanner.py:288-308),
+ *    UniPlanner.plan/_plan (:255-286) and the cuDNN GRU calls inside them.
+ *    PyTorch GRU parameter layout: w_ih [3H][I], w_hh [3H][H], b_ih [3H], b_hh [3H], gates r,z,n.
+ * ------------------------------------------------------------------------------------------ */
+/*
+ * cast: for each of num_cmds GRUs (I=embd_dim, H=hidden): constant input embd[b] at every step,
+ *       h0 = 0, T steps; locs = cumsum_t( mlp_w @ h_t + mlp_b ).
+ * embd [B][embd_dim]; w_ih [num_cmds][3H][embd_dim]; w_hh [num_cmds][3H][H]; b_ih,b_hh [num_cmds][3H];
+ * mlp_w [num_cmds][2][H]; mlp_b [num_cmds][2];  out [B][num_cmds][T][2]
+ */
+int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int num_cmds, int T,
+                 const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                 const float *mlp_w, const float *mlp_b, float *out,
+                 void *workspace, size_t workspace_bytes, void *stream);
+size_t lav_gru_cast_workspace_bytes(int B, int embd_dim, int H, int num_cmds, int T);
+
+/*
+ * plan: GRU(I=4 -> H), h0 = embd[b]; iteration it, command c:
+ *         u_t = [ nxp[b]*ppm/crop_size*2-1 , loc_{it-1}[b][c][t] ],  loc_{-1} = cast_locs
+ *         loc_it[b][c] = cumsum_t(mlp(h_t)) + loc_{it-1}[b][c]
+ * cmd >= 0: only that command branch is evaluated (branches never interact) and `out` is
+ *           [B][iters][1][T][2];  cmd = -1: all branches, out [B][iters][num_cmds][T][2].
+ * embd [B][H]; nxp [B][2]; cast_locs [B][num_cmds][T][2]; w_ih [3H][4]; w_hh [3H][H]; mlp_w [2][H].
+ */
+int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds, int T,
+                 int iters, int cmd, float pixels_per_meter, float crop_size,
+                 const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                 const float *mlp_w, const float *mlp_b, float *out,
+                 void *workspace, size_t workspace_bytes, void *stream);
+size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. 2-D convolutions on the matrix cores (fp32-in / fp32-accumulate MFMA: exact fp32 products,
+ *    fp32 running sums).  Replaces the cuDNN calls behind ConvBackbone / Head
+ *    (team_code_v2/models/lidar.py:48-161) and, with the same kernel, the ResNet-18 embedder
+ *    (lav/models/resnet.py:39-82,235-247).  NCHW activations.
+ *
+ *    y = epilogue( conv(x, w) ),  epilogue in this order (each optional):
+ *        + bias[co] -> ReLU (relu_pre) -> * scale[co] + shift[co] -> + residual -> ReLU (relu_post)
+ *        -> sigmoid
+ *    (the reference's BEV blocks are Conv -> ReLU -> BatchNorm, lidar.py:57-60, i.e. relu_pre +
+ *    scale/shift; its ResNet blocks are Conv -> BatchNorm (-> +identity) -> ReLU, i.e. scale/shift
+ *    (+residual) + relu_post.)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lav_conv {
+    int batch;
+    int in_c_total, in_c_offset, cin; /* x is [batch][in_c_total][h][w]; channels [in_c_offset, +cin) are read */
+    int h, w;
+    int cout, kh, kw;
+    int stride, pad_h, pad_w, dil_h, dil_w;
+    int transposed, out_pad;             /* 1: ConvTranspose2d(stride, padding=pad_h/pad_w, output_padding) */
+    int out_c_total, out_c_offset;       /* y is [batch][out_c_total][oh][ow]; channels [out_c_offset, +cout)
+                                            are written (fused torch.cat, lidar.py:143) */
+    int relu_pre, relu_post, sigmoid;
+} lav_conv;
+
+/* output spatial size of the convolution */
+int lav_conv_out_hw(const lav_conv *c, int *oh, int *ow);
+/* number of floats of the packed weight buffer */
+size_t lav_conv_packed_weight_floats(const lav_conv *c);
+/* host-side repack of a PyTorch-layout weight (Conv2d: [cout][cin][kh][kw]; ConvTranspose2d:
+ * [cin][cout][kh][kw]) into the kernel's [class][tap][cin][cout] layout.  Pure host code. */
+int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed);
+/* x, y, w_packed: device.  bias / scale / shift: [cout] device or NULL.  residual: same shape and
+ * channel window as y, or NULL. */
+int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
+               const float *shift, const float *residual, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAV_AMD_H */

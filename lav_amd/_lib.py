@@ -1,0 +1,94 @@
+"""ctypes binding of liblav_amd.so - the FFI stub INTEGRATION.md describes.
+
+The library is the product; this file only declares its C ABI (include/lav_amd.h).
+There is no fallback: if the shared object is missing, cannot be loaded, or sees no
+HIP device when an op is called, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblav_amd.so")
+
+ABI_VERSION = 1
+MAX_CAM = 4
+
+
+class Grid(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("ppm", C.c_float), ("nx", C.c_int), ("ny", C.c_int)]
+
+
+class PointNet(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("num_input", C.c_int), ("channels", C.c_int)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("K", C.c_float * 9), ("l2w", C.c_float * 16), ("w2c", C.c_float * 16)]
+
+
+class Conv(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "batch", "in_c_total", "in_c_offset", "cin", "h", "w", "cout", "kh", "kw", "stride", "pad_h", "pad_w",
+        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid")]
+
+
+# name -> (restype, argtypes); every symbol declared in include/lav_amd.h
+_P, _I, _Z, _F = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+SIGNATURES = {
+    "lav_abi_version": (_I, []),
+    "lav_last_error": (C.c_char_p, []),
+    "lav_device_count": (_I, []),
+    "lav_pillar_workspace_bytes": (_Z, [_I, _I, C.POINTER(Grid)]),
+    "lav_pillar_scatter": (_I, [_P, C.POINTER(_I), _I, _I, _I, C.POINTER(Grid), C.POINTER(PointNet), _P, _P, _P, _P,
+                                _P, _Z, _P]),
+    "lav_paint": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, C.POINTER(Camera), _P, _P, _P]),
+    "lav_gru_cast": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_gru_cast_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "lav_gru_plan": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_gru_plan_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "lav_conv_out_hw": (_I, [C.POINTER(Conv), C.POINTER(_I), C.POINTER(_I)]),
+    "lav_conv_packed_weight_floats": (_Z, [C.POINTER(Conv)]),
+    "lav_conv_pack_weights": (_I, [C.POINTER(Conv), _P, _P]),
+    "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m lav_amd.build` (hipcc, gfx950). "
+            "lav_amd has no CPU or pure-torch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.lav_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"liblav_amd ABI {got} != binding ABI {ABI_VERSION}: rebuild (python -m lav_amd.build --force)")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().lav_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def require_device() -> None:
+    n = load().lav_device_count()
+    if n <= 0:
+        msg = load().lav_last_error()
+        raise RuntimeError(f"liblav_amd: no HIP device visible ({msg.decode() if msg else n}); "
+                           "the LAV hot path has no CPU fallback")

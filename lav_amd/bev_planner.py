@@ -1,0 +1,54 @@
+"""BEVPlanner (privileged teacher) with the reference's constructor and state_dict keys
+(lav/models/bev_planner_v2.py:7-71).  It rides inside UniPlanner checkpoints (`bev_planner.*`), so it must
+exist for drop-in loading; its cast/plan decoders run on the same HIP GRU kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .lidar import _Engine
+from .planner_common import DecoderMixin, crop_feature
+from .resnet import resnet18
+
+
+class BEVPlanner(DecoderMixin, _Engine):
+    def __init__(self, pixels_per_meter=2, crop_size=64, x_offset=0, y_offset=0.75, feature_x_jitter=1,
+                 feature_angle_jitter=10, num_plan=10, k=16, num_out_feature=64, num_cmds=6, max_num_cars=5,
+                 num_plan_iter=1, num_frame_stack=0):
+        super().__init__()
+        self.num_cmds, self.num_plan, self.num_plan_iter = num_cmds, num_plan, num_plan_iter
+        self.max_num_cars, self.num_out_feature = max_num_cars, num_out_feature
+        self.pixels_per_meter, self.crop_size = pixels_per_meter, crop_size
+        self.feature_x_jitter = feature_x_jitter
+        self.feature_angle_jitter = np.deg2rad(feature_angle_jitter)
+        self.offset_x = nn.Parameter(torch.tensor(x_offset).float(), requires_grad=False)
+        self.offset_y = nn.Parameter(torch.tensor(y_offset).float(), requires_grad=False)
+        self.bev_conv_emb = nn.Sequential(resnet18(num_channels=3 + 2 * (num_frame_stack + 1)),
+                                          nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
+        self.plan_gru = nn.GRU(4, 512, batch_first=True)
+        self.plan_mlp = nn.Linear(512, 2)
+        self.cast_grus = nn.ModuleList([nn.GRU(512, 64, batch_first=True) for _ in range(num_cmds)])
+        self.cast_mlps = nn.ModuleList([nn.Linear(64, 2) for _ in range(num_cmds)])
+        self.cast_cmd_pred = nn.Sequential(nn.Linear(512, num_cmds), nn.Sigmoid())
+        self._drop()
+
+    def _drop(self):
+        super()._drop()
+        self._drop_dec()
+
+    def _cast_modules(self):
+        return self.cast_grus, self.cast_mlps
+
+    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
+        return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, float(self.offset_x), float(self.offset_y))
+
+    @torch.no_grad()
+    def infer(self, bev, nxps):
+        """bev_planner_v2.py:46-70."""
+        crop = self.crop_feature(bev, bev.new_zeros((1, 2)), bev.new_zeros((1,)), self.pixels_per_meter, self.crop_size * 2)
+        embd = self.bev_conv_emb(crop)
+        cast = self.cast(embd)
+        plan = self.plan(embd, nxps, cast_locs=cast, pixels_per_meter=self.pixels_per_meter, crop_size=self.crop_size * 2)
+        return plan, cast, self.cast_cmd_pred(embd)

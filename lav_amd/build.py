@@ -1,0 +1,67 @@
+"""Build liblav_amd.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m lav_amd.build            # (re)build if sources are newer than the library
+    python -m lav_amd.build --force
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liblav_amd.so")
+SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "conv.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(REPO, "include"), "-I", CSRC]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "lav_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    t0 = time.time()
+    for s in SOURCES:
+        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    if verbose:
+        print(f"built {LIB} in {time.time() - t0:.1f}s")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,59 @@
+// Shared host/device helpers for liblav_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "lav_amd.h"
+
+namespace lav {
+
+inline char *error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LAV_HIP(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t lav_e_ = (expr);                                                                        \
+        if (lav_e_ != hipSuccess)                                                                          \
+            return lav::fail(LAV_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(lav_e_)); \
+    } while (0)
+
+#define LAV_REQUIRE(cond, ...)                                     \
+    do {                                                           \
+        if (!(cond)) return lav::fail(LAV_EINVAL, __VA_ARGS__);    \
+    } while (0)
+
+// launch errors are sticky until queried; call after every kernel launch
+#define LAV_LAUNCH_CHECK() LAV_HIP(hipGetLastError())
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Arena {
+    char *base;
+    size_t cap, used;
+    Arena(void *p, size_t bytes) : base(static_cast<char *>(p)), cap(bytes), used(0) {}
+    template <typename T>
+    T *take(size_t count) {
+        used = align_up(used, 256);
+        T *p = reinterpret_cast<T *>(base + used);
+        used += count * sizeof(T);
+        return p;
+    }
+    bool ok() const { return used <= cap; }
+};
+
+constexpr int WAVE = 64;
+
+}  // namespace lav

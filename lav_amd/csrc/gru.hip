@@ -1,0 +1,267 @@
+// GRU waypoint decoders of the uniplanner (cast: 6 x GRU(512->64); plan: GRU(4->512) iterated 5x).
+//
+// Replaces UniPlanner.cast / plan / _plan of the reference (team_code_v2/models/uniplanner.py:255-308),
+// which issues 6 (cast) + 30 (plan) cuDNN GRU calls of 20 steps each per frame.
+//
+// cast  - one workgroup per (sample, command).  The GRU input is the same embedding at every step, so
+//         W_ih.embd + b_ih is computed once (wave-cooperative coalesced row dot products); W_hh (192x64) lives
+//         in registers (one row per thread) and the 20-step recurrence, the Linear(64->2) and the cumulative
+//         sum all run inside the workgroup.
+// plan  - W_hh is 1536x512 fp32 = 3.1 MB: it does not fit one CU, so a step is spread over H/8 workgroups
+//         (each owns 8 hidden units = 24 rows of W_hh, read coalesced from L2) and the time steps are
+//         separate launches on the stream (first version; see DESIGN.md for the persistent variant).
+//         Inputs are not autoregressive inside an iteration (uniplanner.py:264-270), so W_ih.u_t is formed on
+//         the fly (4 FMAs).  Command branches never interact: with cmd >= 0 only that branch is evaluated.
+//
+// Gate order r, z, n as in torch.nn.GRU;  h' = (1-z)*n + z*h;  precise expf/tanhf (no fast-math).
+#include "common.hpp"
+
+namespace {
+using namespace lav;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------- cast
+// H = 64 fixed by the register layout (one W_hh row of 64 floats per thread, 3H = 192 threads)
+constexpr int CAST_H = 64;
+
+__global__ __launch_bounds__(192) void k_gru_cast(const float *__restrict__ embd, int embd_dim, int num_cmds, int T,
+                                                  const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                                  const float *__restrict__ b_ih, const float *__restrict__ b_hh,
+                                                  const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
+                                                  float *__restrict__ out) {
+    constexpr int H = CAST_H, G = 3 * H;
+    __shared__ float gi[G];
+    __shared__ float gh[G];
+    __shared__ float h[H];
+    const int cmd = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float *e = embd + (long)b * embd_dim;
+    const float *wih = w_ih + (long)cmd * G * embd_dim;
+    // input projection, once: wave `wid` owns rows wid*64 .. wid*64+63, lanes stride the 512-long row
+    for (int rr = 0; rr < 64; ++rr) {
+        const int row = wid * 64 + rr;
+        const float *wr = wih + (long)row * embd_dim;
+        float acc = 0.f;
+        for (int k = lane; k < embd_dim; k += 64) acc = fmaf(wr[k], e[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) gi[row] = acc + b_ih[cmd * G + row];
+    }
+    float w[H];
+    {
+        const float *wr = w_hh + ((long)cmd * G + tid) * H;
+#pragma unroll
+        for (int k = 0; k < H; ++k) w[k] = wr[k];
+    }
+    const float bh = b_hh[cmd * G + tid];
+    if (tid < H) h[tid] = 0.f;
+    const float m0 = tid < H ? mlp_w[(cmd * 2 + 0) * H + tid] : 0.f;
+    const float m1 = tid < H ? mlp_w[(cmd * 2 + 1) * H + tid] : 0.f;
+    float run0 = 0.f, run1 = 0.f;
+    __syncthreads();
+    float *o = out + (((long)b * num_cmds + cmd) * T) * 2;
+    for (int t = 0; t < T; ++t) {
+        float acc = bh;
+#pragma unroll
+        for (int k = 0; k < H; ++k) acc = fmaf(w[k], h[k], acc);
+        gh[tid] = acc;
+        __syncthreads();
+        if (tid < H) {
+            const float r = sigmoidf_(gi[tid] + gh[tid]);
+            const float z = sigmoidf_(gi[H + tid] + gh[H + tid]);
+            const float n = tanhf(gi[2 * H + tid] + r * gh[2 * H + tid]);
+            const float hn = (1.f - z) * n + z * h[tid];
+            h[tid] = hn;  // only this thread reads h[tid] in this phase; others read it after the barrier
+            const float s0 = wave_sum(m0 * hn), s1 = wave_sum(m1 * hn);
+            if (tid == 0) {
+                run0 += s0 + mlp_b[cmd * 2 + 0];
+                run1 += s1 + mlp_b[cmd * 2 + 1];
+                o[t * 2 + 0] = run0;
+                o[t * 2 + 1] = run1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- plan
+constexpr int PLAN_UNITS = 8;  // hidden units per workgroup  -> 24 W_hh rows, 6 per wave
+constexpr int PLAN_RC = 6;     // state rows (sample x command) processed per register pass
+constexpr int PLAN_MAXK = 8;   // H <= 64*PLAN_MAXK = 512
+
+struct PlanArgs {
+    const float *embd, *nxp, *cast_locs;
+    const float *w_ih, *w_hh, *b_ih, *b_hh, *mlp_w, *mlp_b;
+    float *out;   // [B][iters][NC][T][2]
+    float *hseq;  // [T][R][H]
+    int B, H, num_cmds, T, iters, cmd, NC, R;
+    float ppm, crop;
+};
+
+// row r of the state = (sample b, evaluated command ci); ci maps to command c
+__device__ __forceinline__ void row_decode(const PlanArgs &a, int r, int &b, int &ci, int &c) {
+    b = r / a.NC;
+    ci = r - b * a.NC;
+    c = a.cmd >= 0 ? a.cmd : ci;
+}
+
+__global__ __launch_bounds__(256) void k_plan_step(PlanArgs a, int it, int t) {
+    const int H = a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nk = H / 64;
+    __shared__ float gh_s[3 * PLAN_UNITS][PLAN_RC];
+    const int j0 = blockIdx.x * PLAN_UNITS;
+    // this wave's 6 rows of W_hh: local row lr = wid*6 + q  ->  gate g = lr / 8, unit j0 + lr % 8
+    float w[6][PLAN_MAXK];
+    float bh[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int lr = wid * 6 + q;
+        const int row = (lr / PLAN_UNITS) * H + j0 + (lr % PLAN_UNITS);
+        const float *wr = a.w_hh + (long)row * H;
+#pragma unroll
+        for (int i = 0; i < PLAN_MAXK; ++i) w[q][i] = i < nk ? wr[lane + 64 * i] : 0.f;
+        bh[q] = a.b_hh[row];
+    }
+    const float *h_prev_base = t == 0 ? nullptr : a.hseq + (long)(t - 1) * a.R * H;
+    float *h_out = a.hseq + (long)t * a.R * H;
+    for (int r0 = 0; r0 < a.R; r0 += PLAN_RC) {
+        const int nr = min(PLAN_RC, a.R - r0);
+        float hv[PLAN_RC][PLAN_MAXK];
+#pragma unroll
+        for (int rr = 0; rr < PLAN_RC; ++rr) {
+            int b, ci, c;
+            row_decode(a, min(r0 + rr, a.R - 1), b, ci, c);
+            const float *hp = t == 0 ? a.embd + (long)b * H : h_prev_base + (long)min(r0 + rr, a.R - 1) * H;
+#pragma unroll
+            for (int i = 0; i < PLAN_MAXK; ++i) hv[rr][i] = i < nk ? hp[lane + 64 * i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int rr = 0; rr < PLAN_RC; ++rr) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < PLAN_MAXK; ++i) acc = fmaf(w[q][i], hv[rr][i], acc);
+                acc = wave_sum(acc);
+                if (lane == 0) gh_s[wid * 6 + q][rr] = acc + bh[q];
+            }
+        }
+        __syncthreads();
+        if (tid < PLAN_UNITS * PLAN_RC) {
+            const int u = tid % PLAN_UNITS, rr = tid / PLAN_UNITS;
+            if (rr < nr) {
+                const int r = r0 + rr, j = j0 + u;
+                int b, ci, c;
+                row_decode(a, r, b, ci, c);
+                // u_t = [nxp*ppm/crop*2-1, previous iteration's waypoint]
+                const float *prev = it == 0 ? a.cast_locs + (((long)b * a.num_cmds + c) * a.T + t) * 2
+                                            : a.out + ((((long)b * a.iters + (it - 1)) * a.NC + ci) * a.T + t) * 2;
+                float uu[4];
+                uu[0] = a.nxp[b * 2 + 0] * a.ppm / a.crop * 2.f - 1.f;
+                uu[1] = a.nxp[b * 2 + 1] * a.ppm / a.crop * 2.f - 1.f;
+                uu[2] = prev[0];
+                uu[3] = prev[1];
+                float gi[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int row = g * H + j;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = fmaf(a.w_ih[row * 4 + k], uu[k], acc);
+                    gi[g] = acc + a.b_ih[row];
+                }
+                const float hp = t == 0 ? a.embd[(long)b * H + j] : h_prev_base[(long)r * H + j];
+                const float rg = sigmoidf_(gi[0] + gh_s[0 * PLAN_UNITS + u][rr]);
+                const float zg = sigmoidf_(gi[1] + gh_s[1 * PLAN_UNITS + u][rr]);
+                const float ng = tanhf(gi[2] + rg * gh_s[2 * PLAN_UNITS + u][rr]);
+                h_out[(long)r * H + j] = (1.f - zg) * ng + zg * hp;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// After the T steps of iteration `it`: loc[r][t] = cumsum_t(mlp(h_t)) + prev[r][t].  One wave per state row.
+__global__ __launch_bounds__(64) void k_plan_out(PlanArgs a, int it) {
+    const int r = blockIdx.x, lane = threadIdx.x, H = a.H;
+    int b, ci, c;
+    row_decode(a, r, b, ci, c);
+    float run0 = 0.f, run1 = 0.f;
+    float *o = a.out + ((((long)b * a.iters + it) * a.NC + ci) * a.T) * 2;
+    for (int t = 0; t < a.T; ++t) {
+        const float *h = a.hseq + ((long)t * a.R + r) * H;
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = lane; k < H; k += 64) {
+            s0 = fmaf(a.mlp_w[k], h[k], s0);
+            s1 = fmaf(a.mlp_w[H + k], h[k], s1);
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        run0 += s0 + a.mlp_b[0];
+        run1 += s1 + a.mlp_b[1];
+        if (lane == 0) {
+            const float *prev = it == 0 ? a.cast_locs + (((long)b * a.num_cmds + c) * a.T + t) * 2
+                                        : a.out + ((((long)b * a.iters + (it - 1)) * a.NC + ci) * a.T + t) * 2;
+            o[t * 2 + 0] = run0 + prev[0];
+            o[t * 2 + 1] = run1 + prev[1];
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t lav_gru_cast_workspace_bytes(int, int, int, int, int) { return 0; }
+
+extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int num_cmds, int T, const float *w_ih,
+                            const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
+                            const float *mlp_b, float *out, void *, size_t, void *stream) {
+    LAV_REQUIRE(B >= 0 && embd_dim > 0 && num_cmds > 0 && T > 0, "lav_gru_cast: bad sizes");
+    LAV_REQUIRE(H == CAST_H, "lav_gru_cast: hidden size %d not instantiated (%d)", H, CAST_H);
+    LAV_REQUIRE(B <= 65535, "lav_gru_cast: B too large");
+    if (B == 0) return LAV_OK;
+    LAV_REQUIRE(embd && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_gru_cast: null argument");
+    hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(192), 0, static_cast<hipStream_t>(stream), embd, embd_dim,
+                       num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T) {
+    return lav::align_up((size_t)T * B * num_cmds * H * sizeof(float), 256);
+}
+
+extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds,
+                            int T, int iters, int cmd, float pixels_per_meter, float crop_size, const float *w_ih,
+                            const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
+                            const float *mlp_b, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    LAV_REQUIRE(B >= 0 && num_cmds > 0 && T > 0 && iters > 0, "lav_gru_plan: bad sizes");
+    LAV_REQUIRE(H % 64 == 0 && H <= 64 * PLAN_MAXK && H % PLAN_UNITS == 0, "lav_gru_plan: hidden size %d unsupported", H);
+    LAV_REQUIRE(cmd >= -1 && cmd < num_cmds, "lav_gru_plan: cmd %d out of range", cmd);
+    if (B == 0) return LAV_OK;
+    LAV_REQUIRE(embd && nxp && cast_locs && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_gru_plan: null argument");
+    PlanArgs a;
+    a.embd = embd; a.nxp = nxp; a.cast_locs = cast_locs;
+    a.w_ih = w_ih; a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.mlp_w = mlp_w; a.mlp_b = mlp_b;
+    a.out = out; a.hseq = static_cast<float *>(workspace);
+    a.B = B; a.H = H; a.num_cmds = num_cmds; a.T = T; a.iters = iters; a.cmd = cmd;
+    a.NC = cmd >= 0 ? 1 : num_cmds;
+    a.R = B * a.NC;
+    a.ppm = pixels_per_meter; a.crop = crop_size;
+    const size_t need = (size_t)T * a.R * H * sizeof(float);
+    if (!workspace || workspace_bytes < need) return lav::fail(LAV_EWORKSPACE, "lav_gru_plan: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int it = 0; it < iters; ++it) {
+        for (int t = 0; t < T; ++t) {
+            hipLaunchKernelGGL(k_plan_step, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, it, t);
+        }
+        hipLaunchKernelGGL(k_plan_out, dim3(a.R), dim3(64), 0, st, a, it);
+    }
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}

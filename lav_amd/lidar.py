@@ -1,0 +1,182 @@
+"""LiDARModel / ConvBackbone / Head with the reference's constructors and state_dict keys
+(team_code_v2/models/lidar.py:8-161), evaluated with liblav_amd's MFMA convolution.
+
+Each Conv -> ReLU -> BatchNorm triple of the reference becomes ONE lav_conv2d launch with the ReLU and the
+eval-mode BatchNorm affine in its epilogue; the three up-convolutions write straight into their channel
+window of the (B,384,160,160) feature map (no torch.cat); the four heads' first convolutions run as a single
+384->256 convolution (the 39 MB feature map is read once instead of four times).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .ops import ConvLayer
+from .point_pillar import PointPillarNet
+
+_NORM = dict(eps=1e-3, momentum=0.01)
+
+
+class _Engine(nn.Module):
+    """Mixin: cache of packed ConvLayers, dropped whenever parameters may have changed."""
+
+    def _drop(self):
+        object.__setattr__(self, "_eng", None)
+
+    def _apply(self, fn, *a, **k):
+        self._drop()
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):
+        self._drop()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._drop()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _need_eval(self):
+        if self.training:
+            raise NotImplementedError(f"{type(self).__name__}: the HIP path is inference-only in this round (eval() first)")
+
+
+def _bn_tuple(bn: nn.BatchNorm2d):
+    return (bn.running_mean, bn.running_var, bn.weight, bn.bias)
+
+
+def _stage(cin, cout, n):
+    """n x [Conv3x3(no bias) , ReLU, BatchNorm(eps 1e-3)], first conv stride 2 (lidar.py:57-108)."""
+    mods = []
+    for j in range(n):
+        mods += [nn.Conv2d(cin if j == 0 else cout, cout, 3, 2 if j == 0 else 1, 1, bias=False),
+                 nn.ReLU(inplace=True), nn.BatchNorm2d(cout, **_NORM)]
+    return nn.Sequential(*mods)
+
+
+def _up(cin, cout, k, s, p=0, op=0):
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, k, s, p, op, bias=False), nn.ReLU(inplace=True),
+                         nn.BatchNorm2d(cout, **_NORM))
+
+
+class ConvBackbone(_Engine):
+    def __init__(self, num_feature=64, norm_cfg=None):
+        super().__init__()
+        f = num_feature
+        self.conv1 = _stage(f, f, 4)
+        self.conv2 = _stage(f, 2 * f, 6)
+        self.conv3 = _stage(2 * f, 2 * f, 6)
+        self.upconv1 = _up(f, 2 * f, 1, 1)
+        self.upconv2 = _up(2 * f, 2 * f, 4, 2, 1)
+        self.upconv3 = _up(2 * f, 2 * f, 4, 4, 1, 2)
+        self.out_channels = 6 * f
+        self._drop()
+
+    def _engine(self, device):
+        if self._eng is not None and self._eng["device"] == device:
+            return self._eng
+        def stage(seq):
+            out = []
+            for j in range(0, len(seq), 3):
+                conv, bn = seq[j], seq[j + 2]
+                out.append(ConvLayer(conv.weight, stride=conv.stride[0], padding=conv.padding, bn=_bn_tuple(bn),
+                                     bn_eps=bn.eps, relu_pre=True, device=device))
+            return out
+        ups = []
+        off = 0
+        for seq in (self.upconv1, self.upconv2, self.upconv3):
+            ct, bn = seq[0], seq[2]
+            ups.append(ConvLayer(ct.weight, stride=ct.stride[0], padding=ct.padding, transposed=True,
+                                 output_padding=ct.output_padding[0], bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True,
+                                 out_c_total=self.out_channels, out_c_offset=off, device=device))
+            off += ct.weight.shape[1]
+        eng = dict(device=device, s1=stage(self.conv1), s2=stage(self.conv2), s3=stage(self.conv3), ups=ups)
+        object.__setattr__(self, "_eng", eng)
+        return eng
+
+    def forward(self, x):
+        self._need_eval()
+        e = self._engine(x.device)
+        feats = []
+        for st in (e["s1"], e["s2"], e["s3"]):
+            for layer in st:
+                x = layer(x)
+            feats.append(x)
+        oh, ow = e["ups"][0].out_hw(feats[0].shape[2], feats[0].shape[3])
+        out = torch.empty((x.shape[0], self.out_channels, oh, ow), dtype=torch.float32, device=x.device)
+        for up, f in zip(e["ups"], feats):
+            up(f, out=out)
+        return out
+
+
+class Head(_Engine):
+    def __init__(self, num_input, num_output, num_hidden=64, norm_cfg=None, output_activation=nn.Identity()):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.Conv2d(num_input, num_hidden, 3, 1, 1, bias=False),
+            nn.ReLU(inplace=True),
+            nn.BatchNorm2d(num_hidden, **_NORM),
+            nn.ConvTranspose2d(num_hidden, num_output, 3, 2, 1, 1),
+        )
+        self.output_activation = output_activation
+        self._drop()
+
+    @property
+    def _sigmoid(self):
+        return self.output_activation is torch.sigmoid or isinstance(self.output_activation, nn.Sigmoid)
+
+    def deconv_layer(self, device, in_c_total=None, in_c_offset=0):
+        ct = self.net[3]
+        if not (self._sigmoid or isinstance(self.output_activation, nn.Identity)):
+            raise RuntimeError("Head.output_activation must be identity or sigmoid for the fused epilogue")
+        return ConvLayer(ct.weight, stride=2, padding=1, transposed=True, output_padding=1, bias=ct.bias,
+                         sigmoid=self._sigmoid, in_c_total=in_c_total, in_c_offset=in_c_offset, device=device)
+
+    def forward(self, x):
+        self._need_eval()
+        if self._eng is None or self._eng["device"] != x.device:
+            conv, bn = self.net[0], self.net[2]
+            eng = dict(device=x.device,
+                       conv=ConvLayer(conv.weight, padding=1, bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True, device=x.device),
+                       deconv=self.deconv_layer(x.device))
+            object.__setattr__(self, "_eng", eng)
+        return self._eng["deconv"](self._eng["conv"](x))
+
+
+class LiDARModel(_Engine):
+    def __init__(self, num_input=9, num_features=(32, 32), backbone="swin", min_x=-10, max_x=70, min_y=-40, max_y=40,
+                 pixels_per_meter=4):
+        super().__init__()
+        self.point_pillar_net = PointPillarNet(num_input, list(num_features), min_x=min_x, max_x=max_x, min_y=min_y,
+                                               max_y=max_y, pixels_per_meter=pixels_per_meter)
+        nf = num_features[-1]
+        if backbone != "cnn":
+            raise NotImplementedError(backbone)
+        self.backbone = ConvBackbone(num_feature=nf)
+        self.center_head = Head(6 * nf, 2)
+        self.box_head = Head(6 * nf, 2)
+        self.ori_head = Head(6 * nf, 2)
+        self.seg_head = Head(6 * nf, 3, output_activation=torch.sigmoid)
+        self._drop()
+
+    def heads(self, features):
+        """(center, box, ori, seg) from the shared feature map: one fused 384->256 convolution, then four
+        ConvTranspose2d(64->n) over their channel windows of the hidden tensor (lidar.py:30-33,159-161)."""
+        self._need_eval()
+        hs = (self.center_head, self.box_head, self.ori_head, self.seg_head)
+        if self._eng is None or self._eng["device"] != features.device:
+            dev = features.device
+            w = torch.cat([h.net[0].weight.detach() for h in hs], dim=0)
+            bn = tuple(torch.cat([getattr(h.net[2], n).detach() for h in hs]) for n in
+                       ("running_mean", "running_var", "weight", "bias"))
+            hid = w.shape[0]
+            per = hs[0].net[0].weight.shape[0]
+            eng = dict(device=dev,
+                       conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=dev),
+                       deconvs=[h.deconv_layer(dev, in_c_total=hid, in_c_offset=i * per) for i, h in enumerate(hs)])
+            object.__setattr__(self, "_eng", eng)
+        hidden = self._eng["conv"](features)
+        return tuple(d(hidden) for d in self._eng["deconvs"])
+
+    def forward(self, lidars, num_points):
+        features = self.backbone(self.point_pillar_net(lidars, num_points))
+        return (features, *self.heads(features))

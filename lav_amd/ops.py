@@ -1,0 +1,214 @@
+"""Tensor-level wrappers over the C ABI (include/lav_amd.h).
+
+torch is used here only as the owner of HBM buffers and of the HIP stream; every
+function hands raw device pointers to liblav_amd.so and enqueues on torch's
+current stream.  No function here has a torch/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Camera, Conv, Grid, PointNet, check
+
+_workspaces: dict = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor in HBM (cuda/hip device), got {t.device}; lav_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _workspace(key, nbytes: int, device) -> torch.Tensor:
+    ws = _workspaces.get((key, device))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _workspaces[(key, device)] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------ pillar
+def make_grid(min_x, max_x, min_y, max_y, ppm) -> Grid:
+    nx = int((max_x - min_x) * ppm)
+    ny = int((max_y - min_y) * ppm)
+    return Grid(float(min_x), float(max_x), float(min_y), float(max_y), float(ppm), nx, ny)
+
+
+def pillar_scatter(points: torch.Tensor, num_points: Sequence[int], grid: Grid, w1, b1, w2, b2,
+                   want_indices: bool = False):
+    """points (B, Nmax, D) or (N, D) f32 in HBM -> canvas (B, C, ny, nx)
+    [+ unique_coords (P,3) int32, inverse (N_kept,) int32 when want_indices]."""
+    lib = _lib.load()
+    if points.dim() == 2:
+        points = points[None]
+    points = _f32c(points, "points")
+    B, nmax, D = points.shape
+    if len(num_points) != B:
+        raise RuntimeError("num_points must have one entry per cloud")
+    Cc = w2.shape[1]
+    net = PointNet(_ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), D + 5, Cc)
+    dev = points.device
+    canvas = torch.empty((B, Cc, grid.ny, grid.nx), dtype=torch.float32, device=dev)
+    nbytes = lib.lav_pillar_workspace_bytes(B, nmax, C.byref(grid))
+    ws = _workspace("pillar", nbytes, dev)
+    h_num = (C.c_int * B)(*[int(n) for n in num_points])
+    uc = inv = cnt = None
+    if want_indices:
+        total = B * nmax
+        uc = torch.empty((max(total, 1), 3), dtype=torch.int32, device=dev)
+        inv = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+        cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+    check(lib.lav_pillar_scatter(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), C.byref(net),
+                                 _ptr(canvas), _ptr(uc), _ptr(inv), _ptr(cnt), _ptr(ws), ws.numel(), _stream()),
+          "lav_pillar_scatter")
+    if want_indices:
+        p, k = [int(v) for v in cnt.tolist()]
+        return canvas, uc[:p], inv[:k]
+    return canvas
+
+
+# ------------------------------------------------------------------------------------------ paint
+def make_cameras(mats) -> C.Array:
+    """mats: sequence of (K 3x3, lidar_to_world 4x4, world_to_cam 4x4) float32 arrays."""
+    arr = (Camera * len(mats))()
+    for cam, (K, l2w, w2c) in zip(arr, mats):
+        cam.K[:] = [float(v) for v in np.asarray(K, np.float32).reshape(-1)]
+        cam.l2w[:] = [float(v) for v in np.asarray(l2w, np.float32).reshape(-1)]
+        cam.w2c[:] = [float(v) for v in np.asarray(w2c, np.float32).reshape(-1)]
+    return arr
+
+
+def paint(lidar: torch.Tensor, sem: torch.Tensor, cams, want_uvz: bool = False):
+    """lidar (N, Dl) f32, sem (ncam, 1+Cs, H, W) softmax maps -> fused (N, Dl+Cs) [+ uvz (ncam, N, 3) int32]."""
+    lib = _lib.load()
+    lidar = _f32c(lidar, "lidar")
+    sem = _f32c(sem, "sem")
+    n, dl = lidar.shape
+    ncam, cs1, h, w = sem.shape
+    fused = torch.empty((n, dl + cs1 - 1), dtype=torch.float32, device=lidar.device)
+    uvz = torch.empty((ncam, n, 3), dtype=torch.int32, device=lidar.device) if want_uvz else None
+    check(lib.lav_paint(_ptr(lidar), n, dl, _ptr(sem), ncam, cs1 - 1, h, w, cams, _ptr(fused), _ptr(uvz), _stream()),
+          "lav_paint")
+    return (fused, uvz) if want_uvz else fused
+
+
+# ------------------------------------------------------------------------------------------ GRU decoders
+def gru_cast(embd, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, T: int):
+    """embd (B, E); stacked per-command GRU/MLP weights -> (B, num_cmds, T, 2)."""
+    lib = _lib.load()
+    embd = _f32c(embd, "embd")
+    B, E = embd.shape
+    ncmd, g3, _ = w_ih.shape
+    H = g3 // 3
+    out = torch.empty((B, ncmd, T, 2), dtype=torch.float32, device=embd.device)
+    check(lib.lav_gru_cast(_ptr(embd), B, E, H, ncmd, T, _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(mlp_w),
+                           _ptr(mlp_b), _ptr(out), None, 0, _stream()), "lav_gru_cast")
+    return out
+
+
+def gru_plan(embd, nxp, cast_locs, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, iters: int, cmd: int, ppm: float,
+             crop_size: float):
+    """embd (B,H), nxp (B,2), cast_locs (B,num_cmds,T,2) -> (B, iters, num_cmds or 1, T, 2)."""
+    lib = _lib.load()
+    embd = _f32c(embd, "embd")
+    nxp = _f32c(nxp, "nxp")
+    cast_locs = _f32c(cast_locs, "cast_locs")
+    B, H = embd.shape
+    _, ncmd, T, _ = cast_locs.shape
+    nc = 1 if cmd >= 0 else ncmd
+    out = torch.empty((B, iters, nc, T, 2), dtype=torch.float32, device=embd.device)
+    nbytes = lib.lav_gru_plan_workspace_bytes(B, H, ncmd, T)
+    ws = _workspace("plan", nbytes, embd.device)
+    check(lib.lav_gru_plan(_ptr(embd), _ptr(nxp), _ptr(cast_locs), B, H, ncmd, T, iters, cmd, float(ppm),
+                           float(crop_size), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(mlp_w), _ptr(mlp_b),
+                           _ptr(out), _ptr(ws), ws.numel(), _stream()), "lav_gru_plan")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ conv
+class ConvLayer:
+    """One fused convolution of the C ABI: packed weights + epilogue vectors resident in HBM.
+
+    Built once from PyTorch-layout parameters (host-side repack in the library), then
+    `__call__(x, out=None, residual=None)` enqueues lav_conv2d.
+    """
+
+    def __init__(self, weight: torch.Tensor, *, stride=1, padding=(0, 0), dilation=(1, 1), transposed=False,
+                 output_padding=0, bias: Optional[torch.Tensor] = None, bn=None, bn_eps: float = 1e-5,
+                 relu_pre=False, relu_post=False, sigmoid=False, in_c_total=None, in_c_offset=0, out_c_total=None,
+                 out_c_offset=0, device=None):
+        lib = _lib.load()
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        if transposed:
+            cin, cout, kh, kw = w.shape
+        else:
+            cout, cin, kh, kw = w.shape
+        if isinstance(padding, int):
+            padding = (padding, padding)
+        if isinstance(dilation, int):
+            dilation = (dilation, dilation)
+        self.cin, self.cout = cin, cout
+        self.in_c_total = in_c_total if in_c_total is not None else cin
+        self.out_c_total = out_c_total if out_c_total is not None else cout
+        self.desc = Conv(1, self.in_c_total, in_c_offset, cin, 0, 0, cout, kh, kw, int(stride), int(padding[0]),
+                         int(padding[1]), int(dilation[0]), int(dilation[1]), int(bool(transposed)),
+                         int(output_padding), self.out_c_total, out_c_offset, int(relu_pre), int(relu_post),
+                         int(sigmoid))
+        probe = Conv.from_buffer_copy(self.desc)
+        probe.h, probe.w = 64, 64
+        nfl = lib.lav_conv_packed_weight_floats(C.byref(probe))
+        if nfl == 0:
+            raise RuntimeError("lav_conv_packed_weight_floats: " + lib.lav_last_error().decode())
+        packed = torch.empty(nfl, dtype=torch.float32)
+        check(lib.lav_conv_pack_weights(C.byref(probe), w.data_ptr(), packed.data_ptr()), "lav_conv_pack_weights")
+        dev = device if device is not None else weight.device
+        self.w = packed.to(dev)
+        self.bias = None if bias is None else bias.detach().to(dev, torch.float32).contiguous()
+        self.scale = self.shift = None
+        if bn is not None:  # eval-mode BatchNorm as y = x*scale + shift, folded in float64
+            mean, var, gamma, beta = [t.detach().to("cpu", torch.float64) for t in bn]
+            scale = gamma / torch.sqrt(var + bn_eps)
+            self.scale = scale.to(torch.float32).to(dev)
+            self.shift = (beta - mean * scale).to(torch.float32).to(dev)
+
+    def out_hw(self, h: int, w: int):
+        d = Conv.from_buffer_copy(self.desc)
+        d.h, d.w = h, w
+        oh, ow = C.c_int(), C.c_int()
+        check(_lib.load().lav_conv_out_hw(C.byref(d), C.byref(oh), C.byref(ow)), "lav_conv_out_hw")
+        return oh.value, ow.value
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
+        x = _f32c(x, "x")
+        B, ct, h, w = x.shape
+        if ct != self.in_c_total:
+            raise RuntimeError(f"conv input has {ct} channels, layer expects {self.in_c_total}")
+        d = Conv.from_buffer_copy(self.desc)
+        d.batch, d.h, d.w = B, h, w
+        oh, ow = self.out_hw(h, w)
+        if out is None:
+            out = torch.empty((B, self.out_c_total, oh, ow), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (B, self.out_c_total, oh, ow) or not out.is_contiguous():
+            raise RuntimeError(f"conv output buffer {tuple(out.shape)} != {(B, self.out_c_total, oh, ow)}")
+        if residual is not None:
+            residual = _f32c(residual, "residual")
+            if residual.shape != out.shape:
+                raise RuntimeError("residual shape mismatch")
+        check(_lib.load().lav_conv2d(C.byref(d), _ptr(x), _ptr(self.w), _ptr(self.bias), _ptr(self.scale),
+                                     _ptr(self.shift), _ptr(residual), _ptr(out), _stream()), "lav_conv2d")
+        return out

@@ -1,0 +1,97 @@
+"""UniPlanner with the reference's constructor, state_dict keys and inference methods
+(team_code_v2/models/uniplanner.py:8-53, 180-352): ResNet-18 embedding of rotated 96x96 feature crops on the
+MFMA convolution, multi-modal cast GRUs and the iterative plan GRU on liblav_amd's GRU kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .lidar import _Engine
+from .planner_common import DecoderMixin, crop_feature, transform_points
+from .resnet import resnet18
+
+
+class UniPlanner(DecoderMixin, _Engine):
+    def __init__(self, bev_planner, pixels_per_meter=2, crop_size=64, x_offset=0, y_offset=0.75, feature_x_jitter=1,
+                 feature_angle_jitter=10, num_plan=10, k=16, num_input_feature=96, num_out_feature=64, num_cmds=6,
+                 max_num_cars=4, num_plan_iter=1):
+        super().__init__()
+        self.num_cmds, self.num_plan, self.num_plan_iter = num_cmds, num_plan, num_plan_iter
+        self.max_num_cars = max_num_cars
+        self.bev_planner = bev_planner
+        self.num_out_feature = num_out_feature
+        self.pixels_per_meter, self.crop_size = pixels_per_meter, crop_size
+        self.feature_x_jitter = feature_x_jitter
+        self.feature_angle_jitter = np.deg2rad(feature_angle_jitter)
+        self.offset_x = nn.Parameter(torch.tensor(x_offset).float(), requires_grad=False)
+        self.offset_y = nn.Parameter(torch.tensor(y_offset).float(), requires_grad=False)
+        self.lidar_conv_emb = nn.Sequential(resnet18(num_channels=num_input_feature), nn.AdaptiveAvgPool2d((1, 1)),
+                                            nn.Flatten())
+        self.plan_gru = nn.GRU(4, 512, batch_first=True)
+        self.plan_mlp = nn.Linear(512, 2)
+        self.cast_grus_ego = nn.ModuleList([nn.GRU(512, 64, batch_first=True) for _ in range(num_cmds)])
+        self.cast_mlps_ego = nn.ModuleList([nn.Linear(64, 2) for _ in range(num_cmds)])
+        # present in the reference's checkpoints but never used by any forward (uniplanner.py:296-300)
+        self.cast_grus_other = nn.ModuleList([nn.GRU(512, 64, batch_first=True) for _ in range(num_cmds)])
+        self.cast_mlps_other = nn.ModuleList([nn.Linear(64, 2) for _ in range(num_cmds)])
+        self.cast_cmd_pred = nn.Sequential(nn.Linear(512, num_cmds), nn.Sigmoid())
+        self._drop()
+
+    def _drop(self):
+        super()._drop()
+        self._drop_dec()
+
+    def _cast_modules(self):
+        return self.cast_grus_ego, self.cast_mlps_ego
+
+    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
+        return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, float(self.offset_x), float(self.offset_y))
+
+    def others_from_detections(self, det, H, W):
+        """Pixel detections -> ego-frame metres and headings, skipping the ego's own box
+        (uniplanner.py:194-212 / model_inference.py:125-144)."""
+        cx = float(W / 2 + float(self.offset_x) * W / 2)
+        cy = float(H / 2 + float(self.offset_y) * H / 2)
+        locs, oris = [], []
+        for X, Y, h, w, cos, sin in det:
+            if np.linalg.norm([X - cx, Y - cy]) <= 4:
+                continue
+            locs.append([(X - cx) / self.pixels_per_meter, (Y - cy) / self.pixels_per_meter])
+            oris.append(float(np.arctan2(sin, cos)))
+        return locs, oris
+
+    @torch.no_grad()
+    def infer(self, features, det, cmd, nxp):
+        """features (384,160,160), det list of (X,Y,h,w,cos,sin), cmd int, nxp (2,)
+        -> ego_plan_locs (T,2), ego_cast_locs (T,2), other_cast_locs (N,6,T,2), other_cast_cmds (N,6)."""
+        ego_embd, plan, cast, oc, om = self.infer_all(features, det, cmd, nxp)
+        return plan, cast, oc, om
+
+    @torch.no_grad()
+    def infer_all(self, features, det, cmd, nxp):
+        dev = features.device
+        H, W = features.size(1) * 2, features.size(2) * 2
+        locs, oris = self.others_from_detections(det, H, W)
+        N = len(locs)
+        ppm_f = self.pixels_per_meter / 2
+        if N > 0:
+            locs_t = torch.tensor(locs, dtype=torch.float32, device=dev)
+            oris_t = torch.tensor(oris, dtype=torch.float32, device=dev)
+            crops = self.crop_feature(features.expand(N, *features.size()), locs_t, oris_t, ppm_f, self.crop_size)
+            other_embd = self.lidar_conv_emb(crops)
+            other_cast = self.cast(other_embd, mode="other")
+            other_cmds = self.cast_cmd_pred(other_embd)
+            other_cast = transform_points(other_cast, oris_t[:, None].repeat(1, self.num_cmds))
+            other_cast = other_cast + locs_t.view(N, 1, 1, 2)
+        else:  # the reference returns CPU zeros here (model_inference.py:167-168) - keep
+            other_cast = torch.zeros((0, self.num_cmds, self.num_plan, 2))
+            other_cmds = torch.zeros((0, self.num_cmds))
+        ego_crop = self.crop_feature(features[None], features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, self.crop_size)
+        ego_embd = self.lidar_conv_emb(ego_crop)
+        ego_cast = self.cast(ego_embd, mode="ego")
+        # only the commanded branch of the plan GRU is needed: branches never interact (uniplanner.py:264-275)
+        ego_plan = self.plan(ego_embd, nxp[None], cast_locs=ego_cast, pixels_per_meter=self.pixels_per_meter,
+                             crop_size=self.crop_size * 2, cmd=int(cmd))[0, -1, 0]
+        return ego_embd, ego_plan, ego_cast[0, int(cmd)], other_cast, other_cmds

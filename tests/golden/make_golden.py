@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own
+Python modules on CPU.
+
+Runs only in the build container (needs /root/reference, read-only).  The reference
+cannot travel to the GPU box, so the outputs are committed as small .npz fixtures and
+this script is committed with them.  Inputs and weights are NOT stored: they are
+regenerated from lav_amd.synth (numpy PCG64 keyed by (seed, name)); each fixture
+carries CRC32s of its inputs so a drifted generator is detected, not silently compared.
+
+Stand-ins for the two packages the reference imports but this image lacks live in
+tests/golden/_shims (torch_scatter, carla) - see their docstrings.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("LAV_REFERENCE", "/root/reference")
+sys.path[:0] = [os.path.join(HERE, "_shims"), os.path.join(REF, "team_code_v2"), REPO]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from models.lidar import LiDARModel  # noqa: E402  (reference)
+from models.uniplanner import UniPlanner  # noqa: E402  (reference)
+from models.bev_planner import BEVPlanner  # noqa: E402  (reference)
+from models.rgb import RGBSegmentationModel, RGBBrakePredictionModel  # noqa: E402  (reference)
+import model_inference as ref_mi  # noqa: E402  (reference)
+
+from lav_amd import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+CFG = dict(min_x=-10, max_x=70, min_y=-40, max_y=40, pixels_per_meter=4)
+
+
+def crc(a) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def build_reference():
+    lm = LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **CFG)
+    y_off = 1 + CFG["min_x"] / ((CFG["max_x"] - CFG["min_x"]) / 2)
+    bp = BEVPlanner(pixels_per_meter=4, crop_size=96, feature_x_jitter=1.5, feature_angle_jitter=20,
+                    x_offset=0, y_offset=y_off, num_cmds=6, num_plan=20, num_plan_iter=5, num_frame_stack=2)
+    up = UniPlanner(bp, pixels_per_meter=4, crop_size=96, feature_x_jitter=1.5, feature_angle_jitter=20,
+                    x_offset=0, y_offset=y_off, num_cmds=6, num_plan=20, num_input_feature=384, num_plan_iter=5)
+    lm.load_state_dict(synth.seeded_state_dict(lm, prefix="lidar."))
+    up.load_state_dict(synth.seeded_state_dict(up, prefix="uni."))
+    return lm.eval(), up.eval()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+def edge_points():
+    """Hand-made cloud hitting every boundary rule of grid_locations (point_pillar.py:70-79)."""
+    e = np.nextafter
+    f = np.float32
+    rows = [
+        [-10.0, -40.0, 0.0], [e(f(-10), f(-11)), 0.0, 0.0], [e(f(70), f(0)), e(f(40), f(0)), 1.0],
+        [70.0, 0.0, 0.0], [0.0, 40.0, 0.0], [-0.0, -0.0, -1.2], [0.0, 0.0, -1.3], [0.24999, 0.25, 0.5],
+        [0.25, 0.24999, 0.5], [69.99999, 39.99999, 0.1], [12.125, -7.875, 0.3], [12.125, -7.875, 0.9],
+        [np.nan, 1.0, 0.0], [1.0, np.nan, 0.0], [np.inf, 0.0, 0.0], [-np.inf, 0.0, 0.0], [5.0, 5.0, 0.7],
+        [-9.999999, -39.999996, 2.0], [3.3333333, -3.3333333, 0.0], [3.3333335, -3.3333335, 0.0],
+    ]
+    pts = np.zeros((len(rows), 11), np.float32)
+    pts[:, :3] = np.asarray(rows, np.float32)
+    r = np.random.Generator(np.random.PCG64(7))
+    pts[:, 3:8] = r.uniform(0, 1, (len(rows), 5)).astype(np.float32)
+    pts[:, 8 + (np.arange(len(rows)) % 3)] = 1
+    return pts
+
+
+def gold_pillar(lm):
+    ppn = lm.point_pillar_net
+    out = {}
+    cases = {
+        "lidar": [synth.stacked_lidar(512, kind="lidar")],
+        "uniform": [synth.stacked_lidar(512, kind="uniform")],
+        "edge": [edge_points()],
+        "one_cell": [np.tile(np.array([[3.1, 4.1, -0.5, .2, 0, 0, 0, 0, 1, 0, 0]], np.float32), (70, 1))
+                     + np.linspace(0, 0.1, 70, dtype=np.float32)[:, None] * np.eye(11, dtype=np.float32)[2]],
+        "all_outside": [np.concatenate([synth.stacked_lidar(64)[:, :11] * 0 + 100.0])],
+    }
+    # training-style padded batch of 2 with num_points truncation (point_pillar.py:98)
+    a = synth.stacked_lidar(300, seed=11, kind="uniform")
+    b = synth.stacked_lidar(300, seed=12, kind="lidar")
+    cases["batch2"] = [a, b]
+    nump = {"batch2": [700, 450]}
+    for name, lst in cases.items():
+        n = nump.get(name, [len(p) for p in lst])
+        tl = [torch.from_numpy(p) for p in lst]
+        # replicate forward() stage by stage to expose the intermediate indices
+        coords, pts = [], []
+        for bi, p in enumerate(tl):
+            p = p[: n[bi]]
+            p, g = ppn.grid_locations(p)
+            coords.append(torch.nn.functional.pad(g, (1, 0), value=bi))
+            pts.append(p)
+        coords, pts = torch.cat(coords), torch.cat(pts)
+        if len(pts) > 0:
+            dec, uniq, inv = ppn.pillar_generation(pts, coords)
+            feat = ppn.point_net(dec, inv)
+            canvas = ppn.scatter_points(feat, uniq, len(tl))
+            full = ppn(tl, n)
+            assert torch.equal(full, canvas)
+        else:  # reference raises on an empty cloud (unique of empty / scatter of empty): record that
+            uniq = torch.zeros((0, 3), dtype=torch.long); inv = torch.zeros((0,), dtype=torch.long)
+            feat = torch.zeros((0, 64)); dec = torch.zeros((0, 16))
+        out[f"{name}/in_crc"] = np.array([crc(p) for p in lst], np.int64)
+        out[f"{name}/num_points"] = np.array(n, np.int64)
+        out[f"{name}/unique_coords"] = t2n(uniq).astype(np.int32)
+        out[f"{name}/inverse"] = t2n(inv).astype(np.int32)
+        out[f"{name}/feat"] = t2n(feat)
+        out[f"{name}/decorated"] = t2n(dec)
+    out["edge/points"] = edge_points()
+    save("pillar", **out)
+
+
+def gold_paint(lm, up):
+    im = ref_mi.InferModel(lm, up, 1.5, 2.4, device=torch.device("cpu"))
+    lidar = np.concatenate([synth.lidar_sweep(2048, name="paintA"), synth.lidar_sweep(2048, name="paintB")])
+    # a few hand-made points: behind every camera, on the optical axes, at the image borders, ego box
+    extra = np.array([[1.5, 0, 2.4 - 2.4, .5], [1.5 + 1e-5, 0, 0, .5], [10, 0, 0, .5], [-10, 0, 0, .5],
+                      [5, 8.66, 0, .1], [5, -8.66, 0, .1], [1.49999, 0, 0, .3], [30, 18.7, -2.4, .3],
+                      [-1.0, 0.0, -1.2, .9], [20, 12.4967, 3, .2], [20, -12.4967, 3, .2]], np.float32)
+    lidar = np.concatenate([lidar, extra]).astype(np.float32)
+    sem = synth.semantic_probs()
+    fused = im.forward_paint(torch.from_numpy(lidar), torch.from_numpy(sem))
+    uvz = [t2n(cc(torch.from_numpy(lidar))).astype(np.int64) for cc in im.coord_converters]
+    mats = {}
+    for i, cc in enumerate(im.coord_converters):
+        mats[f"K{i}"] = t2n(cc.K); mats[f"l2w{i}"] = t2n(cc.lidar_to_world); mats[f"w2c{i}"] = t2n(cc.world_to_cam)
+    save("paint", lidar=lidar, sem_crc=np.array([crc(sem)], np.int64), fused=t2n(fused),
+         uvz=np.stack(uvz).clip(-2 ** 31, 2 ** 31 - 1).astype(np.int32), **mats)
+
+
+def gold_bev(lm, up):
+    pts = synth.stacked_lidar(8192)
+    canvas = lm.point_pillar_net([torch.from_numpy(pts)], [len(pts)])
+    bb = lm.backbone
+    x1 = bb.conv1(canvas); x2 = bb.conv2(x1); x3 = bb.conv3(x2)
+    feat = bb(canvas)
+    heads = [lm.center_head(feat), lm.box_head(feat), lm.ori_head(feat), lm.seg_head(feat)]
+    save("bev", in_crc=np.array([crc(pts)], np.int64),
+         canvas_sum=t2n(canvas.double().sum((2, 3))[0]),
+         x1_s=t2n(x1[0, :, ::8, ::8]), x2_s=t2n(x2[0, :, ::4, ::4]), x3_s=t2n(x3[0, :, ::2, ::2]),
+         feat_s=t2n(feat[0, :, ::8, ::8]), feat_win=t2n(feat[0, :, 120:128, 152:168]),
+         feat_sum=t2n(feat.double().sum((2, 3))[0]),
+         heat_s=t2n(heads[0][0, :, ::4, ::4]), size_s=t2n(heads[1][0, :, ::4, ::4]),
+         ori_s=t2n(heads[2][0, :, ::4, ::4]), seg_s=t2n(heads[3][0, :, ::4, ::4]),
+         head_sum=np.stack([t2n(h.double().sum()) for h in heads]))
+    return feat
+
+
+def gold_planner(lm, up, feat):
+    im = ref_mi.InferModel(lm, up, 1.5, 2.4, device=torch.device("cpu"))
+    # fixed "others": (X, Y, h, w, cos, sin) in 320x320 pixel space
+    det = [(140, 200, 2.0, 4.0, 0.9, 0.1), (190, 150, 2.0, 4.0, -0.3, 0.8), (100, 260, 1.5, 3.0, 0.0, -1.0),
+           (160, 279, 2, 4, 1.0, 0.0),  # within 4 px of the ego centre -> skipped (model_inference.py:133)
+           (222, 90, 2.0, 4.5, 0.5, 0.5)]
+    nxp = torch.tensor([1.5, -12.0])
+    outs = {}
+    for cmd in (0, 3, 5):
+        e, p, c, oc, om = im.uniplanner_infer(feat[0], det, cmd, nxp)
+        outs[f"ego_plan_{cmd}"] = t2n(p); outs[f"ego_cast_{cmd}"] = t2n(c)
+    outs.update(ego_embd=t2n(e), other_cast=t2n(oc), other_cmds=t2n(om))
+    # stages
+    crop = ref_mi.crop_feature(feat, torch.zeros(1, 2), torch.zeros(1), 2.0, 96, 0.0, 0.75)
+    locs = torch.tensor([[-5.0, -20.0], [7.5, -32.5]]); oris = torch.tensor([0.3, -1.2])
+    crop2 = ref_mi.crop_feature(feat.expand(2, -1, -1, -1), locs, oris, 2.0, 96, 0.0, 0.75)
+    embd2 = up.lidar_conv_emb(crop2)
+    cast_all = up.cast(embd2)
+    plan_all = up.plan(embd2, torch.tensor([[1.5, -12.0], [-3.0, -8.0]]), cast_locs=cast_all,
+                       pixels_per_meter=4, crop_size=192)
+    outs.update(crop_ego_s=t2n(crop[0, ::4, ::3, ::3]), crop2_s=t2n(crop2[:, ::4, ::3, ::3]), embd2=t2n(embd2),
+                cast_all=t2n(cast_all), plan_all=t2n(plan_all), cmd_pred2=t2n(up.cast_cmd_pred(embd2)),
+                det=np.array(det, np.float64), nxp=t2n(nxp))
+    # stand-alone GRU golden from a synthetic embedding (no dependence on the conv stack)
+    r = np.random.Generator(np.random.PCG64(5))
+    embd = torch.from_numpy(np.abs(r.normal(0.2, 0.3, (3, 512))).astype(np.float32))
+    nx = torch.from_numpy(r.uniform(-15, 15, (3, 2)).astype(np.float32))
+    c = up.cast(embd)
+    outs.update(gru_embd=t2n(embd), gru_nxp=t2n(nx), gru_cast=t2n(c),
+                gru_plan=t2n(up.plan(embd, nx, cast_locs=c, pixels_per_meter=4, crop_size=192)),
+                gru_cmd=t2n(up.cast_cmd_pred(embd)))
+    save("planner", **outs)
+
+
+def gold_e2e(lm, up):
+    im = ref_mi.InferModel(lm, up, 1.5, 2.4, device=torch.device("cpu"))
+    out = {}
+    for name, n, kind in (("a", 32768, "lidar"), ("b", 16384, "uniform")):
+        pts = synth.stacked_lidar(n, kind=kind)
+        nxp = torch.tensor([0.0, -10.0]) if name == "a" else torch.tensor([2.5, -14.0])
+        cmd = 3 if name == "a" else 1
+        e, p, c, oc, om, bev, det = im(torch.from_numpy(pts), nxp, cmd)
+        out.update({f"{name}/in_crc": np.array([crc(pts)], np.int64), f"{name}/nxp": t2n(nxp),
+                    f"{name}/cmd": np.array([cmd]), f"{name}/ego_embd": t2n(e), f"{name}/ego_plan": t2n(p),
+                    f"{name}/ego_cast": t2n(c), f"{name}/other_cast": t2n(oc), f"{name}/other_cmds": t2n(om),
+                    f"{name}/bev_s": t2n(bev[0, :, ::4, ::4]),
+                    f"{name}/det0": np.array(det[0], np.float64).reshape(-1, 6),
+                    f"{name}/det1": np.array(det[1], np.float64).reshape(-1, 6)})
+    save("e2e", **out)
+
+
+def gold_rgb():
+    seg = RGBSegmentationModel([4, 6, 7, 10]).eval()
+    seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg."))
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]).eval()
+    bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra."))
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]                    # lav_agent_fast.py:252-254
+    all_rgb = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float()
+    logits = seg(all_rgb)
+    sem = torch.softmax(logits, dim=1)
+    rgb = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float()
+    tel_rgb = tel[..., :3][..., ::-1][:-96].copy()
+    pred_bra = bra(rgb, torch.tensor(tel_rgb[None]).permute(0, 3, 1, 2).float())
+    save("rgb", logits_s=t2n(logits[:, :, ::4, ::4]), sem_s=t2n(sem[:, :, ::4, ::4]),
+         logits_sum=t2n(logits.double().sum((2, 3))), pred_bra=t2n(pred_bra))
+
+
+if __name__ == "__main__":
+    lm, up = build_reference()
+    gold_pillar(lm)
+    gold_paint(lm, up)
+    feat = gold_bev(lm, up)
+    gold_planner(lm, up, feat)
+    gold_e2e(lm, up)
+    gold_rgb()

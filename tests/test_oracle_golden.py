@@ -1,0 +1,138 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors produced by the REFERENCE's own modules
+(tests/golden/make_golden.py).  CPU only.  Integer outputs must match bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from lav_amd import synth
+from oracle import bev as obev
+from oracle import paint as opaint
+from oracle import pillar as opillar
+from tests.util import CFG, assert_close, crc, pointnet_sd_numpy, state_dicts, sub_sd
+
+GRID = (CFG["min_x"], CFG["max_x"], CFG["min_y"], CFG["max_y"], CFG["pixels_per_meter"])
+
+
+def pillar_cases(g):
+    cases = {
+        "lidar": ([synth.stacked_lidar(512, kind="lidar")], None),
+        "uniform": ([synth.stacked_lidar(512, kind="uniform")], None),
+        "edge": ([g["edge/points"]], None),
+        "one_cell": ([np.tile(np.array([[3.1, 4.1, -0.5, .2, 0, 0, 0, 0, 1, 0, 0]], np.float32), (70, 1))
+                      + np.linspace(0, 0.1, 70, dtype=np.float32)[:, None] * np.eye(11, dtype=np.float32)[2]], None),
+        "batch2": ([synth.stacked_lidar(300, seed=11, kind="uniform"), synth.stacked_lidar(300, seed=12, kind="lidar")], [700, 450]),
+    }
+    return cases
+
+
+@pytest.mark.parametrize("name", ["lidar", "uniform", "edge", "one_cell", "batch2"])
+def test_pillar_oracle_matches_reference(golden, name):
+    g = golden["pillar"]
+    clouds, n = pillar_cases(g)[name]
+    assert [crc(c) for c in clouds] == list(g[f"{name}/in_crc"]), "synthetic input drifted from the golden run"
+    n = n or [len(c) for c in clouds]
+    out = opillar.pillar_forward(clouds, n, pointnet_sd_numpy(), *GRID)
+    np.testing.assert_array_equal(out["unique_coords"], g[f"{name}/unique_coords"])   # bit-exact pillar list
+    np.testing.assert_array_equal(out["inverse"], g[f"{name}/inverse"])               # bit-exact inverse map
+    assert_close(out["decorated"], g[f"{name}/decorated"], atol=1e-6, what="decorated")
+    assert_close(out["feat"], g[f"{name}/feat"], atol=2e-6, rtol=1e-5, what="pillar features")
+
+
+def test_pillar_edge_semantics(golden):
+    """The boundary rules the kernels must reproduce are really present in the reference output."""
+    g = golden["pillar"]
+    uc = g["edge/unique_coords"]
+    assert uc[:, 2].max() == 320, "y = nextafter(40,0) must round up to cell 320 (one past the grid)"
+    assert uc[:, 1].max() <= 319
+    assert len(g["edge/inverse"]) == 13  # 20 points, 7 dropped: x<min_x, x==max_x, y==max_y, NaN x, NaN y, +inf, -inf
+    pts = g["edge/points"]
+    kept = opillar.grid_locations(pts, *GRID)[2]
+    assert len(kept) == len(g["edge/inverse"])
+
+
+def test_paint_oracle_matches_reference(golden):
+    g = golden["paint"]
+    sem = synth.semantic_probs()
+    assert crc(sem) == int(g["sem_crc"][0])
+    lidar = g["lidar"]
+    for i, yaw in enumerate(opaint.CAMERA_YAWS):
+        K, l2w, w2c = opaint.camera_matrices(yaw, (0, 0, 2.4), (1.5, 0, 2.4))
+        np.testing.assert_array_equal(K, g[f"K{i}"])
+        np.testing.assert_array_equal(l2w, g[f"l2w{i}"])
+        np.testing.assert_array_equal(w2c, g[f"w2c{i}"])
+        uvz, raw = opaint.project(lidar[:, :3], K, l2w, w2c)
+        ref = g["uvz"][i].astype(np.int64)
+
+        def valid(t):
+            return (t[:, 2] >= 0) & (t[:, 0] >= 0) & (t[:, 0] < 256) & (t[:, 1] >= 0) & (t[:, 1] < 288)
+        vo, vr = valid(uvz), valid(ref)
+        # Off-image projections (|u| up to 1e7 when depth ~ 0) have ulp >> 1 px and only their validity
+        # matters.  The reference's sgemm association is unspecified, so a coordinate within 1e-3 px of an
+        # integer may truncate differently: those are the only disagreements allowed.
+        near = (np.abs(raw[:, :2] - np.round(raw[:, :2])) < 1e-3).any(axis=1) | (np.abs(raw[:, 2]) < 1e-3)
+        assert not ((vo != vr) & ~near).any(), f"camera {i}: validity differs away from pixel boundaries"
+        both = vo & vr
+        bad = both & (uvz[:, :2] != ref[:, :2]).any(axis=1)
+        assert not (bad & ~near).any(), f"camera {i}: in-image pixel differs away from pixel boundaries"
+        assert (bad | (vo != vr)).mean() < 2e-3
+        assert both.sum() > 300, "the fixture must exercise in-image points"
+    fused = opaint.forward_paint(lidar, sem)
+    ref = g["fused"]
+    np.testing.assert_array_equal(fused[:, :4], ref[:, :4])
+    same = (fused[:, 4:] == ref[:, 4:]).all(axis=1)
+    assert (~same).mean() < 2e-3, f"{(~same).sum()} painted rows differ"
+
+
+def test_bev_oracle_matches_reference(golden):
+    g = golden["bev"]
+    lsd, _ = state_dicts()
+    pts = synth.stacked_lidar(8192)
+    assert crc(pts) == int(g["in_crc"][0])
+    canvas = opillar.pillar_forward([pts], [len(pts)], pointnet_sd_numpy(), *GRID)["canvas"]
+    assert_close(canvas.astype(np.float64).sum((2, 3))[0], g["canvas_sum"], atol=1e-2, rtol=1e-5, what="canvas channel sums")
+    with torch.no_grad():
+        feat = obev.conv_backbone(torch.from_numpy(canvas), lsd)
+        heads = obev.lidar_heads(feat, lsd)
+    assert_close(feat[0, :, ::8, ::8].numpy(), g["feat_s"], atol=2e-5, rtol=1e-4, what="features")
+    assert_close(feat[0, :, 120:128, 152:168].numpy(), g["feat_win"], atol=2e-5, rtol=1e-4, what="feature window")
+    for h, key in zip(heads, ("heat_s", "size_s", "ori_s", "seg_s")):
+        assert_close(h[0, :, ::4, ::4].numpy(), g[key], atol=2e-5, rtol=1e-4, what=key)
+
+
+def test_planner_oracle_matches_reference(golden):
+    g = golden["planner"]
+    _, usd = state_dicts()
+    with torch.no_grad():
+        embd = torch.from_numpy(g["gru_embd"])
+        nxp = torch.from_numpy(g["gru_nxp"])
+        cast = obev.cast(embd, usd)
+        assert_close(cast.numpy(), g["gru_cast"], atol=2e-5, what="cast")
+        plan = obev.plan(embd, nxp, cast, usd)
+        assert_close(plan.numpy(), g["gru_plan"], atol=1e-4, what="plan")
+        assert_close(obev.cast_cmd_pred(embd, usd).numpy(), g["gru_cmd"], atol=1e-6, what="cmd")
+
+
+def test_e2e_oracle_matches_reference(golden):
+    """Whole InferModel.forward restated by the oracle vs the reference run (config #1 of BASELINE.json)."""
+    g = golden["e2e"]
+    lsd, usd = state_dicts()
+    name, n, kind = "b", 16384, "uniform"
+    pts = synth.stacked_lidar(n, kind=kind)
+    assert crc(pts) == int(g[f"{name}/in_crc"][0])
+    with torch.no_grad():
+        canvas = torch.from_numpy(opillar.pillar_forward([pts], [len(pts)], pointnet_sd_numpy(), *GRID)["canvas"])
+        feat = obev.conv_backbone(canvas, lsd)
+        heat, size, ori, seg = obev.lidar_heads(feat, lsd)
+        det = obev.det_inference(torch.sigmoid(heat[0]), size[0], ori[0])
+        for i in (0, 1):
+            ref = g[f"{name}/det{i}"]
+            assert len(det[i]) == len(ref)
+            if len(ref):
+                np.testing.assert_array_equal(np.array(det[i])[:, :2], ref[:, :2])
+                assert_close(np.array(det[i])[:, 2:], ref[:, 2:], atol=1e-4, what="det attributes")
+        e, p, c, oc, om = obev.uniplanner_infer(feat[0], det[1], int(g[f"{name}/cmd"][0]), torch.from_numpy(g[f"{name}/nxp"]), usd)
+    assert_close(p.numpy(), g[f"{name}/ego_plan"], atol=1e-4, what="ego plan waypoints")   # BASELINE tolerance
+    assert_close(c.numpy(), g[f"{name}/ego_cast"], atol=1e-4, what="ego cast waypoints")
+    assert_close(oc.numpy(), g[f"{name}/other_cast"], atol=1e-4, what="other cast")
+    assert_close(om.numpy(), g[f"{name}/other_cmds"], atol=1e-5, what="other cmds")
+    assert_close(seg[0, :, ::4, ::4].numpy(), g[f"{name}/bev_s"], atol=1e-5, what="pred_bev")
