@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the LAV full-agent forward on MI355X (BASELINE.json metric: frames/s, 32k-point LiDAR + 3 cams).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1: one replica per GPU)
+
+One step = one pass of lav_amd.frame.FramePipeline.step - everything LAVAgent.run_step does on the GPU for
+one 20 Hz tick (half-sweep concat, ego-box removal, ERFNet + softmax on 3 cameras, point painting, 3-sweep
+temporal stacking, pillar scatter, BEV backbone + heads, detection decode, ResNet-18 embedding of the ego crop
+(+ one crop per detected vehicle), cast + plan GRUs, brake net) - on synthetic inputs already resident in HBM.
+Inference is a closed loop with per-vehicle state: it does not shard, so N > 1 runs N independent replicas
+("replicas only") and reports the aggregate frames/s.
+
+Prints ONE JSON line (rank 0) with `roofline` for the pillar point-net/scatter kernel (HIP events recorded by
+the library on its launch stream) and `cpu_baseline` (the oracle's full frame on the host cores, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def build_pipeline(device):
+    import lav_amd
+    from lav_amd import synth
+    from lav_amd.frame import FramePipeline
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    cfg = dict(min_x=-10, max_x=70, min_y=-40, max_y=40, pixels_per_meter=4)
+    y_off = 1 + cfg["min_x"] / ((cfg["max_x"] - cfg["min_x"]) / 2)
+    lm = lav_amd.LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **cfg)
+    bp = lav_amd.BEVPlanner(pixels_per_meter=4, crop_size=96, feature_x_jitter=1.5, feature_angle_jitter=20, x_offset=0,
+                            y_offset=y_off, num_cmds=6, num_plan=20, num_plan_iter=5, num_frame_stack=2)
+    up = lav_amd.UniPlanner(bp, pixels_per_meter=4, crop_size=96, feature_x_jitter=1.5, feature_angle_jitter=20,
+                            x_offset=0, y_offset=y_off, num_cmds=6, num_plan=20, num_input_feature=384, num_plan_iter=5)
+    seg = RGBSegmentationModel([4, 6, 7, 10])
+    bra = RGBBrakePredictionModel([4, 6, 7, 10])
+    sds = dict(lidar=synth.seeded_state_dict(lm, prefix="lidar."), uni=synth.seeded_state_dict(up, prefix="uni."),
+               seg=synth.seeded_state_dict(seg, prefix="seg."), bra=synth.seeded_state_dict(bra, prefix="bra."))
+    lm.load_state_dict(sds["lidar"]); up.load_state_dict(sds["uni"]); seg.load_state_dict(sds["seg"]); bra.load_state_dict(sds["bra"])
+    for m in (lm, up, seg, bra):
+        m.eval().to(device)
+    return FramePipeline(lm, up, seg, bra, 1.5, 2.4, num_frame_stack=2, device=device), sds, (lm, up, seg, bra)
+
+
+def synthetic_inputs(device, n_ticks=4, n_points=32768):
+    from lav_amd import synth
+    ticks = [synth.lidar_sweep(n_points, name=f"tick{i}") for i in range(n_ticks)]
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]                                 # BGRA -> RGB (lav_agent_fast.py:252-254)
+    all_rgb = np.stack(rgbs, 0).transpose(0, 3, 1, 2).astype(np.float32)          # (3,3,288,256)
+    wide = np.concatenate(rgbs, axis=1)[None].transpose(0, 3, 1, 2).astype(np.float32)   # (1,3,288,768)
+    tel_rgb = tel[..., :3][..., ::-1][:-96][None].transpose(0, 3, 1, 2).astype(np.float32)  # (1,3,192,480)
+    host = dict(ticks=ticks, all_rgbs=all_rgb, rgbs=wide, tel_rgbs=tel_rgb, nxp=np.array([0.0, -10.0], np.float32))
+    dev = dict(ticks=[torch.from_numpy(t).to(device) for t in ticks], all_rgbs=torch.from_numpy(all_rgb).to(device),
+               rgbs=torch.from_numpy(wide).to(device), tel_rgbs=torch.from_numpy(tel_rgb).to(device),
+               nxp=torch.from_numpy(host["nxp"]).to(device))
+    return host, dev
+
+
+def pose(i):
+    """EKF pose stream: gentle forward motion, 0.05 rad / 5 frames of yaw."""
+    return np.array([0.2 * i, 0.02 * i]), 0.01 * i
+
+
+def cpu_baseline(sds, host, budget_s=20.0):
+    """The oracle's full frame on the host cores (kind "port"), bounded to ~budget_s of CPU work."""
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    from oracle import frame as oframe
+    torch.set_num_threads(os.cpu_count() or 1)
+    seg = RGBSegmentationModel([4, 6, 7, 10]).eval(); seg.load_state_dict(sds["seg"])
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]).eval(); bra.load_state_dict(sds["bra"])
+    lsd = {k: v for k, v in sds["lidar"].items()}
+    usd = {k: v for k, v in sds["uni"].items()}
+    pn = {k[len("point_pillar_net."):]: v.numpy() for k, v in lsd.items() if k.startswith("point_pillar_net.")}
+    hist = dict(lidars=[], locs=[], oris=[])
+    t_args = dict(all_rgbs=torch.from_numpy(host["all_rgbs"]), rgbs=torch.from_numpy(host["rgbs"]),
+                  tel_rgbs=torch.from_numpy(host["tel_rgbs"]))
+    # fill the 15-frame history cheaply with painted sweeps (not timed)
+    from oracle import paint as opaint
+    for i in range(14):
+        loc, ori = pose(i)
+        cur = opaint.preprocess(np.concatenate([host["ticks"][i % len(host["ticks"])], host["ticks"][(i + 1) % len(host["ticks"])]]))
+        hist["lidars"].append(np.concatenate([cur, np.zeros((len(cur), 4), np.float32)], axis=1))
+        hist["locs"].append(loc); hist["oris"].append(ori)
+    times = []
+    i = 14
+    t_start = time.time()
+    while True:
+        loc, ori = pose(i)
+        t0 = time.time()
+        oframe.frame(host["ticks"][i % len(host["ticks"])], host["ticks"][(i - 1) % len(host["ticks"])], hist,
+                     t_args["all_rgbs"], t_args["rgbs"], t_args["tel_rgbs"], seg, bra, lsd, usd, pn,
+                     torch.from_numpy(host["nxp"]), 3, loc, ori)
+        times.append(time.time() - t0)
+        i += 1
+        if time.time() - t_start > budget_s or len(times) >= 12:
+            break
+    med = float(np.median(times[1:] if len(times) > 1 else times))
+    return dict(value=1.0 / med, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(times)} full frames of the oracle (numpy pillar/paint + torch-CPU conv/GRU), median of all but the first; 32k-pt ticks, 3 cams")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the LAV hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from lav_amd import _lib
+    lib = _lib.load()
+    pipe, sds, _ = build_pipeline(device)
+    host, dev = synthetic_inputs(device)
+    nt = len(dev["ticks"])
+
+    def step(i):
+        loc, ori = pose(i)
+        return pipe.step(dev["ticks"][i % nt], dev["all_rgbs"], dev["rgbs"], dev["tel_rgbs"], loc, ori, dev["nxp"], 3)
+
+    # fill the 15-frame history + warm up (untimed)
+    i = 0
+    for _ in range(max(args.warmup, 16)):
+        step(i); i += 1
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    lib.lav_profile_enable(args.steps + 4)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(i); i += 1
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def read(name):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        lib.lav_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n))
+        return ms.value, n.value
+    prof = {k: read(k) for k in ("pointnet_scatter", "pillar_prep", "conv2d", "paint", "gru_cast", "gru_plan")}
+    lib.lav_profile_enable(0)
+
+    n_pts = int(out["lidar_points"].shape[0])
+    ms_pn, n_pn = prof["pointnet_scatter"]
+    avg_s = ms_pn / max(n_pn, 1) * 1e-3
+    algo_bytes = 4 * (n_pts * 11 + 64 * 320 * 320)          # read each point once, write the canvas once
+    achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    roofline = dict(bound="hbm", kernel="k_pointnet_scatter", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, points=n_pts, algorithmic_bytes=algo_bytes,
+                    avg_kernel_us=round(avg_s * 1e6, 2), launches=n_pn)
+    per_frame_us = {k: round(v[0] / args.steps * 1e3, 1) for k, v in prof.items()}
+
+    if rank == 0:
+        res = dict(metric="frames/s full agent fwd (32k-pt LiDAR + 3 cams)", value=round(world * args.steps / dt, 2),
+                   unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32", data="synthetic",
+                   config=dict(workload="full lav_agent_fast forward, batch 1: 2x32768-pt half sweeps -> 3-sweep stack "
+                                        f"({n_pts} pts x 11) + 3x288x256 RGB + 288x480 tele; ERFNet seg, paint, pillar 320x320x64, "
+                                        "BEV backbone+heads, uniplanner (cast+plan GRUs), brake net",
+                               parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1])),
+                   roofline=roofline, hip_kernel_us_per_frame=per_frame_us)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sds, host)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

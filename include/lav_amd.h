@@ -39,6 +39,14 @@ const char *lav_last_error(void);
 /* number of HIP devices visible, or a negative error.  Used by the loader to fail loudly. */
 int lav_device_count(void);
 
+/* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for
+ * the live roofline figure).  lav_profile_enable(slots>0) arms it: the first `slots` launches of each
+ * tracked kernel ("pointnet_scatter", "pillar_prep", "conv2d", "paint", "gru_cast", "gru_plan") get an
+ * event pair; lav_profile_enable(0) disarms.  lav_profile_read synchronises those events and returns
+ * the summed duration and the launch count.  Not part of the reference's surface. */
+int lav_profile_enable(int slots);
+int lav_profile_read(const char *kernel, double *total_ms, int *launches);
+
 /* ------------------------------------------------------------------------------------------
  * 1. PointPillars: dynamic voxelisation + decoration + PointNet + scatter-max + dense canvas.
  *    Replaces PointPillarNet.forward, lav/models/point_pillar.py:92-116, i.e. grid_locations

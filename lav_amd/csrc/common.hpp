@@ -56,4 +56,9 @@ struct Arena {
 
 constexpr int WAVE = 64;
 
+// Optional per-kernel HIP-event timers (lav_profile_enable / lav_profile_read in include/lav_amd.h).
+// timer_begin returns a slot token (< 0 when profiling is off); both calls only record events on `st`.
+int timer_begin(const char *name, hipStream_t st);
+void timer_end(int token, hipStream_t st);
+
 }  // namespace lav

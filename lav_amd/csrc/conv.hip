@@ -218,7 +218,9 @@ int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t 
     }
     const int Q = p.QH * p.QW;
     dim3 grid((Q + 128 * MP - 1) / (128 * MP), (a.cout + 32 * MC - 1) / (32 * MC), batch * p.nclasses);
+    const int tok = timer_begin("conv2d", st);
     hipLaunchKernelGGL((k_conv<MP, MC>), grid, dim3(256), lds, st, a);
+    timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }

@@ -226,8 +226,10 @@ extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int n
     LAV_REQUIRE(B <= 65535, "lav_gru_cast: B too large");
     if (B == 0) return LAV_OK;
     LAV_REQUIRE(embd && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_gru_cast: null argument");
+    const int tok = timer_begin("gru_cast", static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(192), 0, static_cast<hipStream_t>(stream), embd, embd_dim,
                        num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out);
+    timer_end(tok, static_cast<hipStream_t>(stream));
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }
@@ -256,12 +258,14 @@ extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *ca
     const size_t need = (size_t)T * a.R * H * sizeof(float);
     if (!workspace || workspace_bytes < need) return lav::fail(LAV_EWORKSPACE, "lav_gru_plan: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tok = timer_begin("gru_plan", st);
     for (int it = 0; it < iters; ++it) {
         for (int t = 0; t < T; ++t) {
             hipLaunchKernelGGL(k_plan_step, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, it, t);
         }
         hipLaunchKernelGGL(k_plan_out, dim3(a.R), dim3(64), 0, st, a, it);
     }
+    timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }

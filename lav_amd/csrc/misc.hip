@@ -14,3 +14,84 @@ extern "C" int lav_device_count(void) {
     }
     return n;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// HIP-event timers around selected kernels, for bench.py's live roofline figure.
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+struct Timer {
+    std::string name;
+    std::vector<hipEvent_t> start, stop;
+    long launches = 0;
+};
+std::mutex g_mu;
+std::vector<Timer> g_timers;
+int g_slots = 0;
+}  // namespace
+
+namespace lav {
+int timer_begin(const char *name, hipStream_t st) {
+    if (g_slots <= 0) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int ti = -1;
+    for (size_t i = 0; i < g_timers.size(); ++i)
+        if (g_timers[i].name == name) ti = (int)i;
+    if (ti < 0) {
+        Timer t;
+        t.name = name;
+        t.start.resize(g_slots);
+        t.stop.resize(g_slots);
+        for (int i = 0; i < g_slots; ++i) {
+            if (hipEventCreate(&t.start[i]) != hipSuccess || hipEventCreate(&t.stop[i]) != hipSuccess) return -1;
+        }
+        g_timers.push_back(t);
+        ti = (int)g_timers.size() - 1;
+    }
+    Timer &t = g_timers[ti];
+    if (t.launches >= g_slots) return -1;  // ring full: stop recording (keeps the first `slots` launches)
+    const int slot = (int)t.launches;
+    if (hipEventRecord(t.start[slot], st) != hipSuccess) return -1;
+    return ti * 65536 + slot;
+}
+void timer_end(int token, hipStream_t st) {
+    if (token < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Timer &t = g_timers[token / 65536];
+    (void)hipEventRecord(t.stop[token % 65536], st);
+    t.launches += 1;
+}
+}  // namespace lav
+
+extern "C" int lav_profile_enable(int slots) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &t : g_timers) {
+        for (auto e : t.start) (void)hipEventDestroy(e);
+        for (auto e : t.stop) (void)hipEventDestroy(e);
+    }
+    g_timers.clear();
+    g_slots = slots > 0 ? (slots < 65536 ? slots : 65535) : 0;
+    return LAV_OK;
+}
+
+extern "C" int lav_profile_read(const char *kernel, double *total_ms, int *launches) {
+    LAV_REQUIRE(kernel && total_ms && launches, "lav_profile_read: null");
+    std::lock_guard<std::mutex> lk(g_mu);
+    *total_ms = 0;
+    *launches = 0;
+    for (auto &t : g_timers) {
+        if (t.name != kernel) continue;
+        for (long i = 0; i < t.launches; ++i) {
+            LAV_HIP(hipEventSynchronize(t.stop[i]));
+            float ms = 0.f;
+            LAV_HIP(hipEventElapsedTime(&ms, t.start[i], t.stop[i]));
+            *total_ms += ms;
+        }
+        *launches = (int)t.launches;
+        return LAV_OK;
+    }
+    return LAV_OK;
+}

@@ -81,7 +81,9 @@ extern "C" int lav_paint(const float *lidar, int n, int lidar_dim, const float *
     for (int c = 0; c < ncam; ++c) a.cam[c] = h_cams[c];
     for (int c = ncam; c < MAX_CAM; ++c) a.cam[c] = h_cams[0];
     a.ncam = ncam; a.n = n; a.lidar_dim = lidar_dim; a.sem_c = sem_c; a.h = h; a.w = w;
+    const int tok = timer_begin("paint", static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL((k_paint<4>), dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a, lidar, sem, fused, uvz);
+    timer_end(tok, static_cast<hipStream_t>(stream));
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }

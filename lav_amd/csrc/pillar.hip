@@ -508,12 +508,14 @@ int launch_pointnet(const PillarArgs &a, const TileGeo &tg, const Workspace &w, 
         LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pointnet_scatter<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
+    const int tok = timer_begin("pointnet_scatter", st);
     if (use_valu_impl())
         hipLaunchKernelGGL((k_pointnet_scatter<D, false>), dim3(grid), dim3(256), lds, st, a, tg, w.key, w.sorted_idx,
                            w.cell_offset, net->w1, net->b1, net->w2, net->b2, canvas);
     else
         hipLaunchKernelGGL((k_pointnet_scatter<D, true>), dim3(grid), dim3(256), lds, st, a, tg, w.key, w.sorted_idx,
                            w.cell_offset, net->w1, net->b1, net->w2, net->b2, canvas);
+    timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }
@@ -560,6 +562,7 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
 
     const long ncells = (long)batch * a.KX * a.KY;
     const long total = (long)batch * max_points;
+    const int tok_prep = timer_begin("pillar_prep", st);
     LAV_HIP(hipMemsetAsync(w.cell_count, 0, ncells * sizeof(int), st));
     if (total > 0) {
         hipLaunchKernelGGL(k_key_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.cell_count);
@@ -571,6 +574,7 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
         hipLaunchKernelGGL(k_place, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, w.key, w.slot, w.cell_offset, w.sorted_idx);
         LAV_LAUNCH_CHECK();
     }
+    timer_end(tok_prep, st);
     const TileGeo tg = tile_geometry(a.nx);
     switch (D) {
         case 11: rc = launch_pointnet<11>(a, tg, w, net, canvas, st); break;

@@ -1,0 +1,115 @@
+"""Camera-side models with the reference's state_dict keys (team_code_v2/models/rgb.py:36-83,
+lav/models/attention.py, lav/models/segmentation.py): the ERFNet segmenter that feeds point painting and the
+brake predictor.  Both run on PyTorch-ROCm in this round (the brake net is called every frame by the agent,
+lav_agent_fast.py:323, but is not one of the north-star kernels).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .erfnet import ERFNet
+from . import resnet as _hip_resnet
+
+
+class Normalize(nn.Module):
+    def __init__(self, mean, std):
+        super().__init__()
+        self.mean = nn.Parameter(torch.tensor(mean), requires_grad=False)
+        self.std = nn.Parameter(torch.tensor(std), requires_grad=False)
+
+    def forward(self, x):
+        return (x - self.mean[None, :, None, None]) / self.std[None, :, None, None]
+
+
+class RGBSegmentationModel(nn.Module):
+    def __init__(self, seg_channels):
+        super().__init__()
+        self.erfnet = ERFNet(len(seg_channels) + 1)
+
+    def forward(self, rgb):
+        return self.erfnet((rgb / 255. - .5) * 2)
+
+
+class SegmentationHead(nn.Module):
+    def __init__(self, input_channels, num_labels):
+        super().__init__()
+        chans = [input_channels, 256, 128, 64]
+        mods = []
+        for a, b in zip(chans[:-1], chans[1:]):
+            mods += [nn.ConvTranspose2d(a, b, 3, 2, 1, 1), nn.BatchNorm2d(b), nn.ReLU(True)]
+        mods.append(nn.Conv2d(64, num_labels, 1, 1, 0))
+        self.upconv = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.upconv(x)
+
+
+def positionalencoding1d(d_model, length):
+    pe = torch.zeros(length, d_model)
+    pos = torch.arange(0, length).unsqueeze(1).float()
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class Attention(nn.Module):
+    """Single learned query per head pooling the (h*w) tokens of the ResNet map (lav/models/attention.py:6-38)."""
+
+    def __init__(self, dim, num_heads=8):
+        super().__init__()
+        self.num_heads, self.dim_head = num_heads, dim // num_heads
+        self.q = nn.Parameter(torch.randn(1, num_heads, 1, self.dim_head))
+        self.linear_kv = nn.Linear(dim, dim * 2)
+        self.scale = self.dim_head ** -0.5
+
+    def forward(self, x):
+        b, d, h, w = x.shape
+        tok = x.flatten(2).transpose(1, 2)                                        # b (h w) d
+        k, v = self.linear_kv(tok).chunk(2, dim=-1)
+        k = k.view(b, h * w, self.num_heads, self.dim_head).transpose(1, 2)       # b heads n dh
+        v = v.view(b, h * w, self.num_heads, self.dim_head).transpose(1, 2)
+        k = k + positionalencoding1d(self.dim_head, h * w).to(k.device)
+        attn = torch.softmax(torch.matmul(self.q.expand(b, -1, -1, -1), k.transpose(-1, -2)) * self.scale, dim=-1)
+        return torch.matmul(attn, v).transpose(1, 2).reshape(b, d)
+
+
+class _TorchResNet18(nn.Module):
+    """ResNet-18 trunk on PyTorch-ROCm with the same keys as lav_amd.resnet.ResNet (for the brake net)."""
+
+    def __init__(self, num_channels=3):
+        super().__init__()
+        proto = _hip_resnet.ResNet((2, 2, 2, 2), num_channels=num_channels)
+        for name, mod in proto.named_children():
+            setattr(self, name, mod)
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        for i in range(1, 5):
+            for blk in getattr(self, f"layer{i}"):
+                idt = x if blk.downsample is None else blk.downsample(x)
+                x = F.relu(blk.bn2(blk.conv2(F.relu(blk.bn1(blk.conv1(x))))) + idt)
+        return x
+
+
+class RGBBrakePredictionModel(nn.Module):
+    def __init__(self, seg_channels, pretrained=False):
+        super().__init__()
+        self.conv_backbone = _TorchResNet18(3)
+        self.normalize = Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+        self.seg_head = SegmentationHead(512, len(seg_channels) + 1)
+        self.attn1 = Attention(512, num_heads=8)
+        self.attn2 = Attention(512, num_heads=8)
+        self.classifier = nn.Sequential(nn.Linear(1024, 1), nn.Sigmoid())
+
+    def forward(self, rgb1, rgb2, mask=False):
+        x1 = self.conv_backbone(self.normalize(rgb1 / 255.))
+        x2 = self.conv_backbone(self.normalize(rgb2 / 255.))
+        pred = self.classifier(torch.cat([self.attn1(x1), self.attn2(x2)], dim=1))
+        if mask:
+            return pred[:, 0], F.interpolate(self.seg_head(x1), scale_factor=4), F.interpolate(self.seg_head(x2), scale_factor=4)
+        return pred[:, 0]

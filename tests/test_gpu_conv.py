@@ -1,0 +1,87 @@
+"""lav_conv2d (fp32 MFMA implicit GEMM, through the C ABI) against torch CPU convolutions in float32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lav_amd.ops import ConvLayer
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def rnd(shape, seed, scale=1.0):
+    r = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((r.standard_normal(shape) * scale).astype(np.float32))
+
+
+CASES = [
+    # name, cin, cout, k, stride, pad, dil, transposed, out_pad, H, W
+    ("3x3 s1 64->64", 64, 64, (3, 3), 1, (1, 1), (1, 1), False, 0, 40, 56),
+    ("3x3 s2 64->128", 64, 128, (3, 3), 2, (1, 1), (1, 1), False, 0, 80, 80),
+    ("3x3 s1 128->128 40x40", 128, 128, (3, 3), 1, (1, 1), (1, 1), False, 0, 40, 40),
+    ("3x3 s2 odd size", 64, 64, (3, 3), 2, (1, 1), (1, 1), False, 0, 37, 51),
+    ("1x1 convT 64->128", 64, 128, (1, 1), 1, (0, 0), (1, 1), True, 0, 48, 48),
+    ("4x4 convT s2 p1", 128, 128, (4, 4), 2, (1, 1), (1, 1), True, 0, 24, 20),
+    ("4x4 convT s4 p1 op2", 128, 128, (4, 4), 4, (1, 1), (1, 1), True, 2, 12, 10),
+    ("3x3 convT s2 p1 op1 64->3", 64, 3, (3, 3), 2, (1, 1), (1, 1), True, 1, 32, 40),
+    ("7x7 s2 p3 384->64", 384, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 96),
+    ("1x1 s2 64->128", 64, 128, (1, 1), 2, (0, 0), (1, 1), False, 0, 24, 24),
+    ("3x1 dil 4", 16, 16, (3, 1), 1, (4, 0), (4, 1), False, 0, 36, 32),
+    ("1x3 dil 2 cin 13", 13, 48, (1, 3), 1, (0, 2), (1, 2), False, 0, 20, 33),
+    ("3x3 cin 3", 3, 13, (3, 3), 2, (1, 1), (1, 1), False, 0, 64, 48),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_torch(case):
+    name, cin, cout, k, s, p, d, tr, op, H, W = case
+    B = 2
+    x = rnd((B, cin, H, W), 1)
+    fan = cin * k[0] * k[1]
+    w = rnd((cin, cout, *k) if tr else (cout, cin, *k), 2, scale=1.0 / np.sqrt(fan))
+    if tr:
+        ref = F.conv_transpose2d(x, w, None, s, p, op)
+    else:
+        ref = F.conv2d(x, w, None, s, p, d)
+    layer = ConvLayer(w, stride=s, padding=p, dilation=d, transposed=tr, output_padding=op, device=DEV)
+    y = layer(x.to(DEV)).cpu()
+    assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=name)
+
+
+def test_conv_epilogues_and_channel_windows():
+    B, cin, cout, H, W = 1, 64, 64, 24, 40
+    x = rnd((B, cin + 32, H, W), 3)
+    w = rnd((cout, cin, 3, 3), 4, scale=0.05)
+    bias = rnd((cout,), 5)
+    bn = (rnd((cout,), 6, 0.1), rnd((cout,), 7).abs() + 0.5, rnd((cout,), 8).abs() + 0.5, rnd((cout,), 9, 0.1))
+    res = rnd((B, cout + 16, H, W), 10)
+    xin = x[:, 16:16 + cin]
+    # BEV block: conv -> relu -> bn
+    ref = F.batch_norm(F.relu(F.conv2d(xin, w, None, 1, 1)), bn[0], bn[1], bn[2], bn[3], False, 0., 1e-3)
+    layer = ConvLayer(w, padding=1, bn=bn, bn_eps=1e-3, relu_pre=True, in_c_total=cin + 32, in_c_offset=16,
+                      out_c_total=cout + 16, out_c_offset=8, device=DEV)
+    out = torch.full((B, cout + 16, H, W), 7.0, device=DEV)
+    layer(x.to(DEV), out=out)
+    out = out.cpu()
+    assert_close(out[:, 8:8 + cout].numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what="relu->bn window")
+    assert (out[:, :8] == 7).all() and (out[:, 8 + cout:] == 7).all(), "channels outside the window were touched"
+    # ResNet block tail: conv -> bn -> + identity -> relu ; plus bias and sigmoid
+    ref2 = torch.sigmoid(F.relu(F.batch_norm(F.conv2d(xin, w, bias, 1, 1), bn[0], bn[1], bn[2], bn[3], False, 0., 1e-5) + res[:, :cout]))
+    layer2 = ConvLayer(w, padding=1, bias=bias, bn=bn, bn_eps=1e-5, relu_post=True, sigmoid=True, in_c_total=cin + 32,
+                       in_c_offset=16, device=DEV)
+    y2 = layer2(x.to(DEV), residual=res[:, :cout].contiguous().to(DEV)).cpu()
+    assert_close(y2.numpy(), ref2.numpy(), atol=1e-5, what="bias+bn+residual+relu+sigmoid")
+
+
+def test_conv_transpose_detecting():
+    """A = identity-like weights with an asymmetric input: catches swapped MFMA operands / row-col mixups."""
+    cin = cout = 64
+    w = torch.zeros((cout, cin, 1, 1))
+    for c in range(cout):
+        w[c, (c * 7 + 3) % cin, 0, 0] = 1.0 + c
+    x = torch.arange(cin * 8 * 40, dtype=torch.float32).reshape(1, cin, 8, 40) * 1e-3
+    ref = F.conv2d(x, w)
+    y = ConvLayer(w, device=DEV)(x.to(DEV)).cpu()
+    assert_close(y.numpy(), ref.numpy(), atol=1e-4, rtol=1e-6, what="permutation conv")

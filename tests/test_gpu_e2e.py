@@ -1,0 +1,86 @@
+"""End-to-end parity on the GPU: BEV stack vs the reference goldens, InferModel.forward waypoints within 1e-4
+(BASELINE.json configs #1/#3), and the frame pipeline's first steps."""
+import numpy as np
+import pytest
+import torch
+
+import lav_amd
+from lav_amd import synth
+from tests.util import assert_close, build_models, crc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+@pytest.fixture(scope="module")
+def models():
+    return build_models(DEV)
+
+
+def test_backbone_heads_vs_reference_golden(golden, models):
+    g = golden["bev"]
+    lm, _ = models
+    pts = synth.stacked_lidar(8192)
+    assert crc(pts) == int(g["in_crc"][0])
+    with torch.no_grad():
+        canvas = lm.point_pillar_net([torch.from_numpy(pts).to(DEV)], [len(pts)])
+        assert_close(canvas.double().sum((2, 3))[0].cpu().numpy(), g["canvas_sum"], atol=1e-2, rtol=1e-5, what="canvas sums")
+        feat = lm.backbone(canvas)
+        heads = lm.heads(feat)
+        single = [h(feat) for h in (lm.center_head, lm.box_head, lm.ori_head, lm.seg_head)]
+    f = feat.cpu()
+    assert_close(f[0, :, ::8, ::8].numpy(), g["feat_s"], atol=3e-5, rtol=1e-4, what="features (strided)")
+    assert_close(f[0, :, 120:128, 152:168].numpy(), g["feat_win"], atol=3e-5, rtol=1e-4, what="features (window)")
+    assert_close(f.double().sum((2, 3))[0].numpy(), g["feat_sum"], atol=5e-2, rtol=1e-4, what="feature sums")
+    for h, s, key in zip(heads, single, ("heat_s", "size_s", "ori_s", "seg_s")):
+        assert_close(h[0, :, ::4, ::4].cpu().numpy(), g[key], atol=3e-5, rtol=1e-4, what=key)
+        assert_close(s.cpu().numpy(), h.cpu().numpy(), atol=1e-5, what="fused heads == per-head modules")
+
+
+def test_planner_stages_vs_reference_golden(golden, models):
+    g = golden["planner"]
+    lm, up = models
+    pts = synth.stacked_lidar(8192)
+    im = lav_amd.InferModel(lm, up, 1.5, 2.4, device=DEV)
+    with torch.no_grad():
+        feat = lm.backbone(lm.point_pillar_net([torch.from_numpy(pts).to(DEV)], [len(pts)]))
+        det = [tuple(r) for r in g["det"]]
+        nxp = torch.from_numpy(g["nxp"]).to(DEV)
+        for cmd in (0, 3, 5):
+            e, p, c, oc, om = im.uniplanner_infer(feat[0], det, cmd, nxp)
+            assert_close(p.cpu().numpy(), g[f"ego_plan_{cmd}"], atol=1e-4, what=f"ego plan cmd {cmd}")
+            assert_close(c.cpu().numpy(), g[f"ego_cast_{cmd}"], atol=1e-4, what=f"ego cast cmd {cmd}")
+        assert_close(e.cpu().numpy(), g["ego_embd"], atol=2e-5, rtol=1e-4, what="ego embedding")
+        assert_close(oc.cpu().numpy(), g["other_cast"], atol=1e-4, what="others' forecasts")
+        assert_close(om.cpu().numpy(), g["other_cmds"], atol=1e-5, what="others' command scores")
+        locs = torch.tensor([[-5.0, -20.0], [7.5, -32.5]], device=DEV)
+        oris = torch.tensor([0.3, -1.2], device=DEV)
+        crop2 = up.crop_feature(feat.expand(2, -1, -1, -1), locs, oris, pixels_per_meter=2.0, crop_size=96)
+        assert_close(crop2[:, ::4, ::3, ::3].cpu().numpy(), g["crop2_s"], atol=3e-5, rtol=1e-4, what="rotated crops")
+        embd2 = up.lidar_conv_emb(crop2)
+        assert_close(embd2.cpu().numpy(), g["embd2"], atol=3e-5, rtol=1e-4, what="ResNet-18 embeddings")
+
+
+@pytest.mark.parametrize("name,n,kind", [("a", 32768, "lidar"), ("b", 16384, "uniform")])
+def test_infer_model_forward_vs_reference_golden(golden, models, name, n, kind):
+    """Full InferModel.forward: waypoints within 1e-4 of the reference PyTorch path (BASELINE.json)."""
+    g = golden["e2e"]
+    lm, up = models
+    im = lav_amd.InferModel(lm, up, 1.5, 2.4, device=DEV)
+    pts = synth.stacked_lidar(n, kind=kind)
+    assert crc(pts) == int(g[f"{name}/in_crc"][0])
+    e, p, c, oc, om, bev, det = im(torch.from_numpy(pts).to(DEV), torch.from_numpy(g[f"{name}/nxp"]).to(DEV), int(g[f"{name}/cmd"][0]))
+    for i in (0, 1):
+        ref = g[f"{name}/det{i}"]
+        assert len(det[i]) == len(ref), f"class {i}: {len(det[i])} detections vs {len(ref)}"
+        if len(ref):
+            np.testing.assert_array_equal(np.array(det[i])[:, :2], ref[:, :2])
+            assert_close(np.array(det[i])[:, 2:], ref[:, 2:], atol=1e-4, what="detection attributes")
+    assert_close(p.cpu().numpy(), g[f"{name}/ego_plan"], atol=1e-4, what="ego_plan_locs")
+    assert_close(c.cpu().numpy(), g[f"{name}/ego_cast"], atol=1e-4, what="ego_cast_locs")
+    assert_close(oc.cpu().numpy(), g[f"{name}/other_cast"], atol=1e-4, what="other_cast_locs")
+    assert_close(om.cpu().numpy(), g[f"{name}/other_cmds"], atol=1e-5, what="other_cast_cmds")
+    assert_close(e.cpu().numpy(), g[f"{name}/ego_embd"], atol=3e-5, rtol=1e-4, what="ego_embd")
+    assert_close(bev[0, :, ::4, ::4].cpu().numpy(), g[f"{name}/bev_s"], atol=1e-5, what="pred_bev")
+    if len(g[f"{name}/other_cast"]) == 0:
+        assert oc.device.type == "cpu" and om.device.type == "cpu"   # reference returns CPU zeros (model_inference.py:167-168)

@@ -136,3 +136,16 @@ def test_e2e_oracle_matches_reference(golden):
     assert_close(oc.numpy(), g[f"{name}/other_cast"], atol=1e-4, what="other cast")
     assert_close(om.numpy(), g[f"{name}/other_cmds"], atol=1e-5, what="other cmds")
     assert_close(seg[0, :, ::4, ::4].numpy(), g[f"{name}/bev_s"], atol=1e-5, what="pred_bev")
+
+
+@pytest.mark.parametrize("name", ["lidar", "uniform", "edge", "one_cell"])
+def test_c_oracle_matches_reference(golden, name):
+    """oracle/pillar_c.c (the CPU-baseline restatement) against the same reference goldens."""
+    from oracle import pillar_c
+    g = golden["pillar"]
+    clouds, _ = pillar_cases(g)[name]
+    out = pillar_c.pillar_forward(clouds[0], pointnet_sd_numpy(), *GRID)
+    np.testing.assert_array_equal(out["unique_coords"], g[f"{name}/unique_coords"])
+    np.testing.assert_array_equal(out["inverse"], g[f"{name}/inverse"])
+    ref = opillar.scatter_points(g[f"{name}/feat"], g[f"{name}/unique_coords"].astype(np.int64), 1, 320, 320)
+    assert_close(out["canvas"], ref, atol=3e-6, rtol=1e-5, what="C oracle canvas")
