@@ -77,7 +77,7 @@ def cpu_baseline(sds, host, budget_s=20.0):
     """The oracle's full frame on the host cores (kind "port"), bounded to ~budget_s of CPU work."""
     from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
     from oracle import frame as oframe
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # more threads only oversubscribe these small layers
     seg = RGBSegmentationModel([4, 6, 7, 10]).eval(); seg.load_state_dict(sds["seg"])
     bra = RGBBrakePredictionModel([4, 6, 7, 10]).eval(); bra.load_state_dict(sds["bra"])
     lsd = {k: v for k, v in sds["lidar"].items()}
@@ -151,7 +151,7 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    lib.lav_profile_enable(args.steps + 4)
+    lib.lav_profile_enable(min(65000, 128 * args.steps))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -17,6 +17,10 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblav_amd.so")
 SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "conv.hip"]
+# Parity-critical float32 arithmetic (cell ids, decoration, camera projection) must round every multiply and
+# add separately, like the oracle: these translation units are compiled with FMA contraction off (the header
+# helpers __fadd_rn/__fmul_rn are plain operators that clang would otherwise fuse after inlining).
+EXTRA_FLAGS = {"pillar.hip": ["-ffp-contract=off"], "paint.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
@@ -46,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()

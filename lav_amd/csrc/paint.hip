@@ -11,6 +11,10 @@
 // (4.4 MB) are gathered through L2.
 #include "common.hpp"
 
+// parity-critical float32 arithmetic: no fused multiply-add contraction anywhere in this file
+// (HIP's __fadd_rn/__fmul_rn are plain operators that clang would otherwise fuse)
+#pragma clang fp contract(off)
+
 namespace {
 using namespace lav;
 constexpr int MAX_CAM = 4;

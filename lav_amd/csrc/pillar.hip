@@ -29,6 +29,10 @@
 
 #include "common.hpp"
 
+// parity-critical float32 arithmetic: no fused multiply-add contraction anywhere in this file
+// (HIP's __fadd_rn/__fmul_rn are plain operators that clang would otherwise fuse)
+#pragma clang fp contract(off)
+
 namespace {
 using namespace lav;
 
