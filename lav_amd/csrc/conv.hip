@@ -29,22 +29,57 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MAX_TAPS = 64;
 constexpr int MAX_CLASSES = 16;
+constexpr int CK = 16;        // input channels per LDS stage (compile time: the pair loop is fully unrolled)
+constexpr int TAP_GROUP = 9;  // taps per weight stage (a 7x7 kernel is staged one kernel row at a time)
+constexpr int NPOS_MAX = 12;  // staged input positions per thread: ROWS*Wst <= 256*NPOS_MAX
 
 struct ConvArgs {
     const float *x, *w, *bias, *scale, *shift, *res;
     float *y;
     int in_c_total, in_c_offset, cin, H, W;
     int cout, out_c_total, out_c_offset, OH, OW;
+    int cin_pad, cout_pad;  // packed-weight strides (multiples of CK / 64), zero filled
     int QH, QW, in_s, out_s;
-    int CK, Wst, ROWS, nclasses, taps_per_class;
+    int Wst, ROWS, nclasses, taps_per_class, tap_group;
     int relu_pre, relu_post, sigmoid;
     int cls_ntaps[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES];
     int cls_out_oy[MAX_CLASSES], cls_out_ox[MAX_CLASSES], cls_woff[MAX_CLASSES];
     int toff[MAX_TAPS];  // class c, tap t -> toff[c*taps_per_class + t] = dy*Wst + dx
 };
 
+// Operands of one tap: 8 channel pairs x (MC weight fragments + MP activation fragments)
 template <int MP, int MC>
-__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+struct TapOps {
+    float a[CK / 2][MC], b[CK / 2][MP];
+};
+
+template <int MP, int MC>
+__device__ __forceinline__ void load_tap(TapOps<MP, MC> &o, const float *__restrict__ s_w_tap, const float *__restrict__ s_in,
+                                         const int (&base)[MP], int to, int plane, int l31, int half) {
+    constexpr int CO_T = 32 * MC;
+#pragma unroll
+    for (int cp = 0; cp < CK / 2; ++cp) {
+        const int c = 2 * cp + half;
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) o.a[cp][mc] = s_w_tap[c * CO_T + mc * 32 + l31];
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp) o.b[cp][mp] = s_in[c * plane + base[mp] + to];
+    }
+}
+
+template <int MP, int MC>
+__device__ __forceinline__ void mma_tap(const TapOps<MP, MC> &o, f32x16 (&acc)[MC][MP]) {
+#pragma unroll
+    for (int cp = 0; cp < CK / 2; ++cp)
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp)
+                acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[cp][mc], o.b[cp][mp], acc[mc][mp], 0, 0, 0);
+}
+
+template <int MP, int MC>
+__global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_T = 32 * MC, PIXW = 128 * MP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -52,9 +87,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     const int cb = blockIdx.y * CO_T;
     const int Q = a.QH * a.QW;
     const int q0 = blockIdx.x * PIXW;
-    const int CK = a.CK, Wst = a.Wst, ROWS = a.ROWS, plane = ROWS * Wst;
-    float *s_in = smem;                                  // [CK][ROWS][Wst]
-    float *s_w = smem + ((CK * plane + 3) & ~3);         // [ntaps][CK][CO_T]
+    const int Wst = a.Wst, ROWS = a.ROWS, plane = ROWS * Wst;
+    float *s_in = smem;                                // [CK][ROWS][Wst]
+    float *s_w = smem + ((CK * plane + 3) & ~3);       // [tap_group][CK][CO_T]
     const int ntaps = a.cls_ntaps[cls];
     const int qy0 = q0 / a.QW;
     const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls];
@@ -69,6 +104,17 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         const int qy = q / a.QW, qx = q - qy * a.QW;
         base[mp] = (qy - qy0) * a.in_s * Wst + qx * a.in_s;
     }
+    // input staging map: thread owns tile positions tid + 256*i; global offset inside a channel plane or -1
+    int goff[NPOS_MAX];
+#pragma unroll
+    for (int i = 0; i < NPOS_MAX; ++i) {
+        const int p = tid + 256 * i;
+        const int rr = p / Wst, xx = p - rr * Wst;
+        const int iy = iy_base + rr, ix = in_ox + xx;
+        goff[i] = (p < plane && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+    }
+    const int npos = (plane + 255) >> 8;
+
     f32x16 acc[MC][MP];
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc)
@@ -78,43 +124,49 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[mc][mp][r] = 0.f;
 
     const float *xin = a.x + ((long)n * a.in_c_total + a.in_c_offset) * a.H * a.W;
+    const long cplane = (long)a.H * a.W;
     for (int ci0 = 0; ci0 < a.cin; ci0 += CK) {
-        __syncthreads();
-        for (int pr = wid; pr < CK * ROWS; pr += 4) {
-            const int c = pr / ROWS, rr = pr - c * ROWS;
-            const int ci = ci0 + c, iy = iy_base + rr;
-            const bool rowok = ci < a.cin && iy >= 0 && iy < a.H;
-            const float *src = xin + ((long)ci * a.H + (rowok ? iy : 0)) * a.W;
-            float *dst = s_in + c * plane + rr * Wst;
-            for (int xx = lane; xx < Wst; xx += 64) {
-                const int ix = in_ox + xx;
-                dst[xx] = (rowok && ix >= 0 && ix < a.W) ? src[ix] : 0.f;
+        __syncthreads();  // everyone is done reading the previous input tile
+        // all loads unconditional (clamped address) and selected afterwards: a conditional load makes hipcc
+        // branch around every element and drain vmcnt(0) each time
+#pragma unroll
+        for (int i = 0; i < NPOS_MAX; ++i) {
+            if (i < npos) {  // workgroup-uniform
+                const int p = tid + 256 * i;
+                const int g = goff[i];
+                const float *src = xin + (g < 0 ? 0 : g);
+                float v[CK];
+#pragma unroll
+                for (int c = 0; c < CK; ++c) v[c] = src[min(ci0 + c, a.cin - 1) * cplane];
+                if (p < plane) {
+#pragma unroll
+                    for (int c = 0; c < CK; ++c) s_in[c * plane + p] = (g >= 0 && ci0 + c < a.cin) ? v[c] : 0.f;
+                }
             }
         }
-        for (int pr = wid; pr < ntaps * CK; pr += 4) {
-            const int tap = pr / CK, c = pr - tap * CK;
-            const int ci = ci0 + c;
-            const float *src = wbase + ((long)tap * a.cin + (ci < a.cin ? ci : 0)) * a.cout + cb;
-            float *dst = s_w + pr * CO_T;
-            for (int j = lane; j < CO_T; j += 64) dst[j] = (ci < a.cin && cb + j < a.cout) ? src[j] : 0.f;
-        }
-        __syncthreads();
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int to = toff[tap];
-            const float *wt = s_w + tap * CK * CO_T + l31;
-            for (int cp = 0; cp < CK; cp += 2) {
-                const int c = cp + half;
-                float av[MC], bv[MP];
-#pragma unroll
-                for (int mc = 0; mc < MC; ++mc) av[mc] = wt[c * CO_T + mc * 32];
-#pragma unroll
-                for (int mp = 0; mp < MP; ++mp) bv[mp] = s_in[c * plane + base[mp] + to];
-#pragma unroll
-                for (int mc = 0; mc < MC; ++mc)
-#pragma unroll
-                    for (int mp = 0; mp < MP; ++mp)
-                        acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mc], bv[mp], acc[mc][mp], 0, 0, 0);
+        for (int t0 = 0; t0 < ntaps; t0 += a.tap_group) {
+            const int nt = min(a.tap_group, ntaps - t0);
+            if (t0 > 0) __syncthreads();  // previous weight slab fully consumed
+            // weight slab: rows (tap, c) of CO_T floats, contiguous in the packed layout -> float4 copy
+            constexpr int V = CO_T / 4;
+            for (int f = tid; f < nt * CK * V; f += 256) {
+                const int row = f / V, c4 = f - row * V;
+                const int tap = row / CK, c = row - tap * CK;
+                const float4 w4 = *reinterpret_cast<const float4 *>(wbase + ((long)(t0 + tap) * a.cin_pad + ci0 + c) * a.cout_pad + cb + 4 * c4);
+                *reinterpret_cast<float4 *>(s_w + row * CO_T + 4 * c4) = w4;
             }
+            __syncthreads();
+            // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
+            TapOps<MP, MC> o0, o1;
+            load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, l31, half);
+            int t = 0;
+            for (; t + 1 < nt; t += 2) {
+                load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, l31, half);
+                mma_tap<MP, MC>(o0, acc);
+                if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, l31, half);
+                mma_tap<MP, MC>(o1, acc);
+            }
+            if (t < nt) mma_tap<MP, MC>(o0, acc);
         }
     }
 
@@ -156,6 +208,7 @@ struct Plan {
     std::vector<int> in_oy, in_ox, out_oy, out_ox;
     std::vector<size_t> woff;
     size_t wfloats;
+    int cin_pad, cout_pad;
 };
 
 int build_plan(const lav_conv &c, Plan &p) {
@@ -197,12 +250,14 @@ int build_plan(const lav_conv &c, Plan &p) {
     p.nclasses = (int)p.taps.size();
     LAV_REQUIRE(p.nclasses <= MAX_CLASSES, "lav_conv: stride %d gives %d classes > %d", c.stride, p.nclasses, MAX_CLASSES);
     p.taps_per_class = 0; p.max_dy = 0; p.max_dx = 0;
+    p.cin_pad = (c.cin + CK - 1) / CK * CK;
+    p.cout_pad = (c.cout + 63) / 64 * 64;
     size_t off = 0;
     for (auto &t : p.taps) {
         p.taps_per_class = std::max<int>(p.taps_per_class, (int)t.size());
         for (auto &tp : t) { p.max_dy = std::max(p.max_dy, tp.dy); p.max_dx = std::max(p.max_dx, tp.dx); }
         p.woff.push_back(off);
-        off += t.size() * (size_t)c.cin * c.cout;
+        off += t.size() * (size_t)p.cin_pad * p.cout_pad;
     }
     p.wfloats = off;
     LAV_REQUIRE(p.taps_per_class * p.nclasses <= MAX_TAPS, "lav_conv: %d taps x %d classes exceed %d", p.taps_per_class, p.nclasses, MAX_TAPS);
@@ -248,6 +303,7 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
     Plan p;
     int rc = build_plan(*c, p);
     if (rc) return rc;
+    for (size_t i = 0; i < p.wfloats; ++i) h_packed[i] = 0.f;
     for (int cls = 0; cls < p.nclasses; ++cls) {
         float *dst = h_packed + p.woff[cls];
         const auto &t = p.taps[cls];
@@ -257,7 +313,7 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
                     const size_t src = c->transposed
                                            ? (((size_t)ci * c->cout + co) * c->kh + t[ti].ky) * c->kw + t[ti].kx
                                            : (((size_t)co * c->cin + ci) * c->kh + t[ti].ky) * c->kw + t[ti].kx;
-                    dst[(ti * c->cin + ci) * c->cout + co] = h_weight[src];
+                    dst[(ti * p.cin_pad + ci) * p.cout_pad + co] = h_weight[src];
                 }
     }
     return LAV_OK;
@@ -278,25 +334,32 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     a.nclasses = p.nclasses; a.taps_per_class = p.taps_per_class;
     a.relu_pre = c->relu_pre; a.relu_post = c->relu_post; a.sigmoid = c->sigmoid;
 
-    // tile shape: the largest tile that still gives the 256 CUs >= 2 workgroups each
+    a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
+    // tile shape: 256x64 when that still gives every CU two workgroups, else 128x64; 32-cout tiles only for
+    // narrow outputs (small tiles pay the LDS staging once per MFMA instead of once per 2-4)
     const long Q = (long)p.QH * p.QW;
     auto nwg = [&](int mp, int mc) { return ((Q + 128 * mp - 1) / (128 * mp)) * ((c->cout + 32 * mc - 1) / (32 * mc)) * c->batch * p.nclasses; };
-    int MP = 1, MC = c->cout > 32 ? 2 : 1;
-    if (MC == 2 && nwg(2, 2) >= 512) MP = 2;
-    if (MC == 2 && MP == 1 && nwg(1, 2) < 256 && c->cout % 64 != 0) MC = 1;
-    if (MC == 2 && MP == 1 && nwg(1, 2) < 200) MC = 1;
+    // cost model (units: MFMA time of one k-step): a CU runs ceil(nwg/256) workgroups back to back on its
+    // matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch
+    int MP = 1, MC = 1;
+    {
+        double best = 1e30;
+        const int cand[3][2] = {{1, 1}, {1, 2}, {2, 2}};
+        for (auto &cd : cand) {
+            if (cd[1] == 2 && c->cout <= 32) continue;
+            const double t = (double)((nwg(cd[0], cd[1]) + 255) / 256) * (cd[0] * cd[1] + 0.5);
+            if (t < best - 1e-9) { best = t; MP = cd[0]; MC = cd[1]; }
+        }
+    }
     const int PIXW = 128 * MP, CO_T = 32 * MC;
 
     a.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
     const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
     a.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
-    // cin chunk: as large as fits ~64 KB of LDS (2 workgroups per CU), at least 2
-    const int cin_even = (c->cin + 1) & ~1;
-    int CK = 16;
-    auto lds_bytes = [&](int ck) { return (size_t)((((size_t)ck * a.ROWS * a.Wst + 3) & ~(size_t)3) + (size_t)p.taps_per_class * ck * CO_T) * 4; };
-    while (CK > 2 && (lds_bytes(CK) > 64 * 1024 || CK > cin_even)) CK >>= 1;
-    LAV_REQUIRE(lds_bytes(CK) <= 160 * 1024, "lav_conv2d: tile needs %zu bytes of LDS", lds_bytes(CK));
-    a.CK = CK;
+    LAV_REQUIRE((long)a.ROWS * a.Wst <= 256 * NPOS_MAX, "lav_conv2d: input tile %dx%d too large for the staging map", a.ROWS, a.Wst);
+    a.tap_group = p.taps_per_class <= TAP_GROUP ? p.taps_per_class : (c->kw <= TAP_GROUP ? c->kw : TAP_GROUP);
+    auto lds_bytes = [&]() { return (size_t)((((size_t)CK * a.ROWS * a.Wst + 3) & ~(size_t)3) + (size_t)a.tap_group * CK * CO_T) * 4; };
+    LAV_REQUIRE(lds_bytes() <= 160 * 1024, "lav_conv2d: tile needs %zu bytes of LDS", lds_bytes());
     for (int i = 0; i < MAX_CLASSES; ++i) {
         const bool live = i < p.nclasses;
         a.cls_ntaps[i] = live ? (int)p.taps[i].size() : 0;
@@ -309,7 +372,7 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         for (size_t t = 0; t < p.taps[cl].size(); ++t) a.toff[cl * p.taps_per_class + t] = p.taps[cl][t].dy * a.Wst + p.taps[cl][t].dx;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = lds_bytes(CK);
+    const size_t lds = lds_bytes();
     if (MP == 2 && MC == 2) return launch<2, 2>(a, p, c->batch, lds, st);
     if (MP == 1 && MC == 2) return launch<1, 2>(a, p, c->batch, lds, st);
     return launch<1, 1>(a, p, c->batch, lds, st);

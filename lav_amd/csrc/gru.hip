@@ -31,7 +31,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // H = 64 fixed by the register layout (one W_hh row of 64 floats per thread, 3H = 192 threads)
 constexpr int CAST_H = 64;
 
-__global__ __launch_bounds__(192) void k_gru_cast(const float *__restrict__ embd, int embd_dim, int num_cmds, int T,
+constexpr int CAST_THREADS = 768;  // 12 waves share the 192x512 input projection; waves 0-2 run the recurrence
+
+__global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restrict__ embd, int embd_dim, int num_cmds, int T,
                                                   const float *__restrict__ w_ih, const float *__restrict__ w_hh,
                                                   const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                                   const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
@@ -44,15 +46,28 @@ __global__ __launch_bounds__(192) void k_gru_cast(const float *__restrict__ embd
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float *e = embd + (long)b * embd_dim;
     const float *wih = w_ih + (long)cmd * G * embd_dim;
-    // input projection, once: wave `wid` owns rows wid*64 .. wid*64+63, lanes stride the 512-long row
-    for (int rr = 0; rr < 64; ++rr) {
-        const int row = wid * 64 + rr;
-        const float *wr = wih + (long)row * embd_dim;
-        float acc = 0.f;
-        for (int k = lane; k < embd_dim; k += 64) acc = fmaf(wr[k], e[k], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) gi[row] = acc + b_ih[cmd * G + row];
+    // input projection, once: wave `wid` owns 16 rows, done 8 at a time with independent accumulators so the
+    // 64 coalesced row loads and the 8 butterfly reductions of a batch are all in flight together
+    for (int r0 = wid * 16; r0 < wid * 16 + 16; r0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int k = lane; k < embd_dim; k += 64) {
+            const float ev = e[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wih[(long)(r0 + j) * embd_dim + k], ev, acc[j]);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], d, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gi[r0 + j] = acc[j] + b_ih[cmd * G + r0 + j];
+        }
     }
+    __syncthreads();  // gi[] complete and visible
+    if (tid >= G) return;  // the nine helper waves are done (terminated waves drop out of later barriers)
     float w[H];
     {
         const float *wr = w_hh + ((long)cmd * G + tid) * H;
@@ -143,14 +158,24 @@ __global__ __launch_bounds__(256) void k_plan_step(PlanArgs a, int it, int t) {
             for (int i = 0; i < PLAN_MAXK; ++i) hv[rr][i] = i < nk ? hp[lane + 64 * i] : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int rr = 0; rr < PLAN_RC; ++rr) {
+            if (rr < nr) {  // workgroup-uniform: inference has a single live state row
+                float acc[6];
 #pragma unroll
-            for (int rr = 0; rr < PLAN_RC; ++rr) {
-                float acc = 0.f;
+                for (int q = 0; q < 6; ++q) {
+                    acc[q] = 0.f;
 #pragma unroll
-                for (int i = 0; i < PLAN_MAXK; ++i) acc = fmaf(w[q][i], hv[rr][i], acc);
-                acc = wave_sum(acc);
-                if (lane == 0) gh_s[wid * 6 + q][rr] = acc + bh[q];
+                    for (int i = 0; i < PLAN_MAXK; ++i) acc[q] = fmaf(w[q][i], hv[rr][i], acc[q]);
+                }
+                // six independent butterfly reductions, interleaved so their shuffle latencies overlap
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc[q] += __shfl_xor(acc[q], d, 64);
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) gh_s[wid * 6 + q][rr] = acc[q] + bh[q];
+                }
             }
         }
         __syncthreads();
@@ -227,7 +252,7 @@ extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int n
     if (B == 0) return LAV_OK;
     LAV_REQUIRE(embd && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_gru_cast: null argument");
     const int tok = timer_begin("gru_cast", static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(192), 0, static_cast<hipStream_t>(stream), embd, embd_dim,
+    hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(CAST_THREADS), 0, static_cast<hipStream_t>(stream), embd, embd_dim,
                        num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out);
     timer_end(tok, static_cast<hipStream_t>(stream));
     LAV_LAUNCH_CHECK();

@@ -64,7 +64,8 @@ def test_gru_cast_plan_vs_reference_golden(golden, models):
     for cmd in (0, 3, 5):  # single-branch evaluation == that slice of the full result
         one = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=cmd)
         assert_close(one[:, :, 0].cpu().numpy(), g["gru_plan"][:, :, cmd], atol=1e-4, what=f"plan cmd {cmd}")
-    assert_close(up.cast_cmd_pred(embd).cpu().numpy(), g["gru_cmd"], atol=1e-6, what="cmd")
+    with torch.no_grad():
+        assert_close(up.cast_cmd_pred(embd).cpu().numpy(), g["gru_cmd"], atol=1e-6, what="cmd")
 
 
 def test_gru_vs_oracle_other_batch(models):
