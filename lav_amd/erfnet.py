@@ -1,12 +1,23 @@
 """ERFNet (5-class semantic segmentation of the three 288x256 cameras) with the reference's state_dict keys
-(lav/models/erfnet.py).  Not one of the hand-written kernels of this round: it runs on PyTorch-ROCm (MIOpen)
-and is listed as the next conv family to move onto lav_conv2d.
+(lav/models/erfnet.py).  In eval mode on the GPU every convolution - 3x3/s2 downsamplers, the factorised
+3x1 / 1x3 (dilated) pairs, the 3x3/s2 and 2x2/s2 transposed convolutions - is one lav_conv2d launch with its
+bias, BatchNorm affine, residual add and ReLU fused into the epilogue (the reference issues ~6 kernels per
+non_bottleneck_1d convolution pair; MIOpen falls back to naive kernels for the dilated asymmetric shapes).
+The torch forward below is kept for training mode.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .ops import ConvLayer
+
+
+def _affine(bn, sl):
+    s = (bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps))
+    t = bn.bias.detach().double() - bn.running_mean.detach().double() * s
+    return s[sl].float()[None, :, None, None].contiguous(), t[sl].float()[None, :, None, None].contiguous()
 
 
 class DownsamplerBlock(nn.Module):
@@ -18,6 +29,19 @@ class DownsamplerBlock(nn.Module):
 
     def forward(self, x):
         return F.relu(self.bn(torch.cat([self.conv(x), self.pool(x)], 1)))
+
+    def engine(self, device):
+        nconv = self.conv.out_channels
+        cout = self.bn.num_features
+        conv = ConvLayer.from_module(self.conv, self.bn, slice(0, nconv), relu_post=True, out_c_total=cout, device=device)
+        ps, pt = _affine(self.bn, slice(nconv, cout))
+        ps, pt = ps.to(device), pt.to(device)
+
+        def run(x):
+            out = conv(x)                                                    # channels [0, nconv): conv+bias -> BN -> ReLU
+            out[:, nconv:] = torch.relu(F.max_pool2d(x, 2, 2) * ps + pt)     # channels [nconv, cout): pool -> BN -> ReLU
+            return out
+        return run
 
 
 class non_bottleneck_1d(nn.Module):  # name kept: it is part of pickled/traced checkpoints' qualified names
@@ -39,6 +63,13 @@ class non_bottleneck_1d(nn.Module):  # name kept: it is part of pickled/traced c
             y = self.dropout(y)
         return F.relu(y + x)
 
+    def engine(self, device):
+        a = ConvLayer.from_module(self.conv3x1_1, relu_post=True, device=device)
+        b = ConvLayer.from_module(self.conv1x3_1, self.bn1, relu_post=True, device=device)
+        c = ConvLayer.from_module(self.conv3x1_2, relu_post=True, device=device)
+        d = ConvLayer.from_module(self.conv1x3_2, self.bn2, relu_post=True, device=device)   # (+x) then ReLU
+        return lambda x: d(c(b(a(x))), residual=x)
+
 
 class UpsamplerBlock(nn.Module):
     def __init__(self, cin, cout):
@@ -48,6 +79,9 @@ class UpsamplerBlock(nn.Module):
 
     def forward(self, x):
         return F.relu(self.bn(self.conv(x)))
+
+    def engine(self, device):
+        return ConvLayer.from_module(self.conv, self.bn, relu_post=True, device=device)
 
 
 class Encoder(nn.Module):
@@ -84,6 +118,35 @@ class ERFNet(nn.Module):
         super().__init__()
         self.encoder = Encoder(num_classes)
         self.decoder = Decoder(num_classes)
+        object.__setattr__(self, "_eng", None)
+
+    def _drop(self):
+        object.__setattr__(self, "_eng", None)
+
+    def _apply(self, fn, *a, **k):
+        self._drop()
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):
+        self._drop()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._drop()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _engine(self, device):
+        if self._eng is None or self._eng[0] != device:
+            stages = [self.encoder.initial_block.engine(device)]
+            stages += [m.engine(device) for m in self.encoder.layers]
+            stages += [m.engine(device) for m in self.decoder.layers]
+            stages.append(ConvLayer.from_module(self.decoder.output_conv, device=device))
+            object.__setattr__(self, "_eng", (device, stages))
+        return self._eng[1]
 
     def forward(self, x):
-        return self.decoder(self.encoder(x))
+        if self.training or not x.is_cuda:
+            return self.decoder(self.encoder(x))
+        for stage in self._engine(x.device):
+            x = stage(x)
+        return x

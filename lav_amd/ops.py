@@ -186,6 +186,22 @@ class ConvLayer:
             self.scale = scale.to(torch.float32).to(dev)
             self.shift = (beta - mean * scale).to(torch.float32).to(dev)
 
+    @classmethod
+    def from_module(cls, conv, bn=None, bn_slice=None, **kw):
+        """Build from nn.Conv2d / nn.ConvTranspose2d (+ optional nn.BatchNorm2d, optionally a channel slice of it)."""
+        import torch.nn as nn
+        tr = isinstance(conv, nn.ConvTranspose2d)
+        if conv.stride[0] != conv.stride[1]:
+            raise RuntimeError("anisotropic stride unsupported")
+        bnt, eps = None, 1e-5
+        if bn is not None:
+            sl = bn_slice if bn_slice is not None else slice(None)
+            bnt = tuple(t[sl] for t in (bn.running_mean, bn.running_var, bn.weight, bn.bias))
+            eps = bn.eps
+        return cls(conv.weight, stride=conv.stride[0], padding=tuple(conv.padding), dilation=tuple(conv.dilation),
+                   transposed=tr, output_padding=conv.output_padding[0] if tr else 0, bias=conv.bias, bn=bnt, bn_eps=eps,
+                   device=kw.pop("device", conv.weight.device), **kw)
+
     def out_hw(self, h: int, w: int):
         d = Conv.from_buffer_copy(self.desc)
         d.h, d.w = h, w

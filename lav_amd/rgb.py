@@ -1,7 +1,7 @@
 """Camera-side models with the reference's state_dict keys (team_code_v2/models/rgb.py:36-83,
 lav/models/attention.py, lav/models/segmentation.py): the ERFNet segmenter that feeds point painting and the
-brake predictor.  Both run on PyTorch-ROCm in this round (the brake net is called every frame by the agent,
-lav_agent_fast.py:323, but is not one of the north-star kernels).
+brake predictor.  Their convolutions run on liblav_amd's MFMA convolution in eval mode on the GPU (the brake net is called every
+frame by the agent, lav_agent_fast.py:323); the single-query attention pooling stays on torch ops.
 """
 from __future__ import annotations
 
@@ -78,16 +78,16 @@ class Attention(nn.Module):
         return torch.matmul(attn, v).transpose(1, 2).reshape(b, d)
 
 
-class _TorchResNet18(nn.Module):
-    """ResNet-18 trunk on PyTorch-ROCm with the same keys as lav_amd.resnet.ResNet (for the brake net)."""
+class _ResNet18(_hip_resnet.ResNet):
+    """ResNet-18 trunk of the brake net: lav_amd.resnet.ResNet (MFMA convolutions) in eval mode on the GPU,
+    plain torch ops otherwise (CPU baseline / training)."""
 
     def __init__(self, num_channels=3):
-        super().__init__()
-        proto = _hip_resnet.ResNet((2, 2, 2, 2), num_channels=num_channels)
-        for name, mod in proto.named_children():
-            setattr(self, name, mod)
+        super().__init__((2, 2, 2, 2), num_channels=num_channels)
 
     def forward(self, x):
+        if not self.training and x.is_cuda:
+            return super().forward(x)
         x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
         for i in range(1, 5):
             for blk in getattr(self, f"layer{i}"):
@@ -99,7 +99,7 @@ class _TorchResNet18(nn.Module):
 class RGBBrakePredictionModel(nn.Module):
     def __init__(self, seg_channels, pretrained=False):
         super().__init__()
-        self.conv_backbone = _TorchResNet18(3)
+        self.conv_backbone = _ResNet18(3)
         self.normalize = Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
         self.seg_head = SegmentationHead(512, len(seg_channels) + 1)
         self.attn1 = Attention(512, num_heads=8)

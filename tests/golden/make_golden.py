@@ -235,8 +235,18 @@ def gold_rgb():
          logits_sum=t2n(logits.double().sum((2, 3))), pred_bra=t2n(pred_bra))
 
 
+def gold_keys(lm, up):
+    import json
+    seg = RGBSegmentationModel([4, 6, 7, 10]); bra = RGBBrakePredictionModel([4, 6, 7, 10])
+    d = {n: [[k, list(v.shape)] for k, v in m.state_dict().items()] for n, m in
+         dict(lidar=lm, uniplanner=up, seg=seg, bra=bra).items()}
+    json.dump(d, open(os.path.join(HERE, "state_dict_keys.json"), "w"))
+    print("state_dict_keys.json", sum(len(v) for v in d.values()), "keys")
+
+
 if __name__ == "__main__":
     lm, up = build_reference()
+    gold_keys(lm, up)
     gold_pillar(lm)
     gold_paint(lm, up)
     feat = gold_bev(lm, up)

@@ -1,0 +1,139 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol include/lav_amd.h
+declares; host-side helpers (weight packing, plan geometry, BatchNorm folding, state_dict keys) are right.
+No compute call needs a GPU here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import lav_amd
+from lav_amd import _lib, synth
+from lav_amd._lib import Conv
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "lav_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lav_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/lav_amd.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in lav_amd/_lib.py"
+    assert lib.lav_abi_version() == _lib.ABI_VERSION
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    ppn = lav_amd.PointPillarNet(16, [64, 64]).eval()
+    with pytest.raises(RuntimeError, match="HBM|device|HIP"):
+        ppn([torch.zeros(8, 11)], [8])
+
+
+def conv_desc(cin, cout, k, s, p, tr=False, op=0, h=8, w=8):
+    return Conv(1, cin, 0, cin, h, w, cout, k, k, s, p, p, 1, 1, int(tr), op, cout, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,tr,op", [(5, 7, 3, 1, 1, False, 0), (6, 3, 4, 2, 1, True, 0), (4, 5, 4, 4, 1, True, 2),
+                                                  (3, 2, 3, 2, 1, True, 1), (2, 3, 1, 1, 0, True, 0)])
+def test_conv_weight_packing_and_class_decomposition(cin, cout, k, s, p, tr, op):
+    """Emulate the kernel's gather from the packed layout on the CPU and compare with torch: checks the host-side
+    plan (parity classes, tap order, padded strides) without a GPU."""
+    lib = _lib.load()
+    H = W = 7
+    d = conv_desc(cin, cout, k, s, p, tr, op, H, W)
+    r = np.random.Generator(np.random.PCG64(3))
+    w = torch.from_numpy(r.standard_normal((cin, cout, k, k) if tr else (cout, cin, k, k)).astype(np.float32))
+    n = lib.lav_conv_packed_weight_floats(C.byref(d))
+    packed = torch.zeros(n)
+    assert lib.lav_conv_pack_weights(C.byref(d), w.data_ptr(), packed.data_ptr()) == 0
+    oh, ow = C.c_int(), C.c_int()
+    assert lib.lav_conv_out_hw(C.byref(d), C.byref(oh), C.byref(ow)) == 0
+    x = torch.from_numpy(r.standard_normal((1, cin, H, W)).astype(np.float32))
+    ref = torch.nn.functional.conv_transpose2d(x, w, None, s, p, op) if tr else torch.nn.functional.conv2d(x, w, None, s, p)
+    assert (oh.value, ow.value) == tuple(ref.shape[2:])
+    cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 63) // 64 * 64
+    pk = packed.numpy()
+    out = np.zeros((cout, oh.value, ow.value), np.float64)
+    xn = x[0].numpy()
+    if not tr:
+        taps = [(ky, kx) for ky in range(k) for kx in range(k)]
+        for t, (ky, kx) in enumerate(taps):
+            wt = pk[t * cin_pad * cout_pad:(t + 1) * cin_pad * cout_pad].reshape(cin_pad, cout_pad)[:cin, :cout]
+            for oy in range(oh.value):
+                for ox in range(ow.value):
+                    iy, ix = oy * s - p + ky, ox * s - p + kx
+                    if 0 <= iy < H and 0 <= ix < W:
+                        out[:, oy, ox] += xn[:, iy, ix] @ wt
+    else:
+        off = 0
+        for ry in range(s):
+            for rx in range(s):
+                nty = (k - ry + s - 1) // s if ry < k else 0
+                ntx = (k - rx + s - 1) // s if rx < k else 0
+                for dy in range(nty):
+                    for dx in range(ntx):
+                        wt = pk[off:off + cin_pad * cout_pad].reshape(cin_pad, cout_pad)[:cin, :cout]
+                        off += cin_pad * cout_pad
+                        for qy in range((oh.value - 1 + p) // s + 1):
+                            for qx in range((ow.value - 1 + p) // s + 1):
+                                oy, ox = s * qy + ry - p, s * qx + rx - p
+                                iy, ix = qy - (nty - 1) + dy, qx - (ntx - 1) + dx
+                                if 0 <= oy < oh.value and 0 <= ox < ow.value and 0 <= iy < H and 0 <= ix < W:
+                                    out[:, oy, ox] += xn[:, iy, ix] @ wt
+    np.testing.assert_allclose(out, ref[0].numpy(), atol=1e-4)
+
+
+def test_pointnet_batchnorm_folding_matches_unfolded_math():
+    from oracle import pillar as opillar
+    from tests.util import pointnet_sd_numpy, state_dicts, sub_sd
+    lsd, _ = state_dicts()
+    ppn = lav_amd.PointPillarNet(16, [64, 64]).eval()
+    ppn.load_state_dict(sub_sd(lsd, "point_pillar_net."))
+    w1, b1, w2, b2 = [t.numpy().astype(np.float64) for t in ppn.point_net.folded(torch.device("cpu"))]
+    f = np.random.Generator(np.random.PCG64(0)).standard_normal((50, 16)).astype(np.float32)
+    ref = opillar.point_net(f, pointnet_sd_numpy())
+    h = np.maximum(np.maximum(f @ w1 + b1, 0) @ w2 + b2, 0)
+    np.testing.assert_allclose(h, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout():
+    """Key lists recorded from the reference modules by tests/golden/make_golden.py."""
+    ref = json.load(open(os.path.join(REPO, "tests", "golden", "state_dict_keys.json")))
+    from tests.util import build_models
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    lm, up = build_models("cpu")
+    got = dict(lidar=lm, uniplanner=up, seg=RGBSegmentationModel([4, 6, 7, 10]), bra=RGBBrakePredictionModel([4, 6, 7, 10]))
+    for name, m in got.items():
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref[name], name
+
+
+def test_world_size_2_gloo_replica_timing_reduction():
+    """bench.py's N>1 contract on CPU: barrier + MAX-reduced wall time over ranks (gloo, world_size 2)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, time, torch, torch.distributed as dist
+dist.init_process_group("gloo")
+r = dist.get_rank()
+dist.barrier(); t0 = time.perf_counter(); time.sleep(0.05 * (r + 1)); dt = time.perf_counter() - t0
+t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.item() >= 0.1 - 1e-3, t
+if r == 0: print("MAX_OK", round(t.item(), 2))
+dist.destroy_process_group()
+'''
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29613", "-c", code] if False else
+                         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(REPO, "tests", "_gloo_worker.py")],
+                         capture_output=True, text=True, timeout=180)
+    assert "MAX_OK" in out.stdout, out.stdout + out.stderr

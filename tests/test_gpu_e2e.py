@@ -84,3 +84,26 @@ def test_infer_model_forward_vs_reference_golden(golden, models, name, n, kind):
     assert_close(bev[0, :, ::4, ::4].cpu().numpy(), g[f"{name}/bev_s"], atol=1e-5, what="pred_bev")
     if len(g[f"{name}/other_cast"]) == 0:
         assert oc.device.type == "cpu" and om.device.type == "cpu"   # reference returns CPU zeros (model_inference.py:167-168)
+
+
+def test_camera_nets_vs_reference_golden_and_torch_cpu(golden):
+    """ERFNet on the MFMA convolution vs the reference's logits; brake ResNet trunk vs the same module on torch CPU."""
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    g = golden["rgb"]
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval()
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]); bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra.")); bra.eval()
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]
+    all_rgb = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float()
+    wide = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float()
+    tel_rgb = torch.tensor(tel[..., :3][..., ::-1][:-96][None].copy()).permute(0, 3, 1, 2).float()
+    with torch.no_grad():
+        cpu_trunk = bra.conv_backbone(bra.normalize(wide / 255.))
+        cpu_bra = bra(wide, tel_rgb)
+        seg.to(DEV); bra.to(DEV)
+        logits = seg(all_rgb.to(DEV))
+        assert_close(logits[:, :, ::4, ::4].cpu().numpy(), g["logits_s"], atol=2e-4, rtol=1e-4, what="ERFNet logits")
+        assert_close(logits.double().sum((2, 3)).cpu().numpy(), g["logits_sum"], atol=0.5, rtol=1e-4, what="ERFNet logit sums")
+        gpu_trunk = bra.conv_backbone(bra.normalize(wide.to(DEV) / 255.))
+        assert_close(gpu_trunk.cpu().numpy(), cpu_trunk.numpy(), atol=1e-3, rtol=1e-4, what="brake ResNet-18 trunk")
+        assert_close(bra(wide.to(DEV), tel_rgb.to(DEV)).cpu().numpy(), cpu_bra.numpy(), atol=1e-5, what="pred_bra")
