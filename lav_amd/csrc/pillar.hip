@@ -3,28 +3,39 @@
 // Replaces PointPillarNet.forward of the reference (lav/models/point_pillar.py:92-116) including the two
 // torch_scatter calls (:33, :62) and coords.unique(dim=0) (:82).  gfx950 only.
 //
-// Data flow (all buffers in HBM, sizes for the v2 agent: N ~ 196k points x 11 floats, 320x320 cells, C = 64):
+// Data flow of the canvas path (all buffers in HBM; v2 agent: N ~ 196k points x 11 floats, 320x320 cells, C = 64).
+// Points are binned by CANVAS TILE (one canvas row x 160 columns = the unit one workgroup writes), not by cell:
 //
-//   k_key_count   1 thread / point   reads x,y                -> key[i] (cell id or -1), slot[i] = arrival
-//                                                                 number inside its cell (int atomic, order free)
-//   scan          exclusive prefix sum of the per-cell counts -> cell_offset[cells+1]   (counting sort)
-//   k_place       1 thread / point                            -> sorted_idx[cell_offset[key]+slot] = i
-//   k_pointnet_scatter  one workgroup per (cloud, canvas row, column tile):
-//        the cells of one canvas row are contiguous in key order, hence so are their points in sorted_idx;
-//        the workgroup  (a) sums xyz per cell in LDS with 64-bit fixed-point atomics (order independent =>
-//        run-to-run deterministic; exact to 2^-32 m),  (b) decorates each point (16 features) and runs the
-//        2-layer PointNet,  (c) max-reduces into an LDS tile [C][tile_w] (values >= 0 after ReLU, so an
-//        unsigned integer max on the float bits is exact),  (d) streams the tile - zeros for empty cells
-//        included - to the NCHW canvas with 16-byte coalesced stores.  The canvas is written exactly once
-//        and never read or memset: algorithmic traffic 4*(N*D + C*ny*nx) bytes.
+//   k_tile_count   1 thread / point : float32 cell id exactly as the reference, tile id, slot = arrival number
+//                                     inside the tile (int atomic on 640 counters; order is irrelevant, see below)
+//   k_tile_scan    1 workgroup      : exclusive prefix of the tile counters
+//   k_tile_place   1 thread / point : writes a contiguous 48-byte record {11 floats, cell key} at
+//                                     rec[tile_offset + slot]  -> the big kernel never chases indices
+//   k_tile_pointnet  one workgroup per (cloud, canvas row, column tile):
+//        (a) per-cell xyz sums and counts in LDS (64-bit fixed-point atomics: order independent, so the result
+//            is bit-identical for ANY arrival order / input permutation; exact to 2^-32 m), means
+//        (b) every wave takes passes of 32 records and runs BOTH PointNet layers on the matrix cores with all
+//            activations in registers (v_mfma_f32_32x32x2_f32, exact fp32):
+//              layer 1 (transposed)  D1[c][p]  = sum_k W1[k][c] * F[k][p]     A = weights, B = point features
+//                 lane l supplies feature 2s+(l>>5) of point l&31 at k-step s; the bias rides as feature 16 (=1).
+//                 D1 leaves lane (p, half) holding channels c = 32*mt + (r&3) + 8*(r>>2) + 4*half  (r = 0..15)
+//              layer 2               D2[p][c2] = sum_c H1[p][c] * W2[c][c2]   A = relu(D1) AS IT SITS, B = weights
+//                 k-step (mt, r) uses k = 32*mt + (r&3) + 8*(r>>2) + 4*half - a permutation of 0..63, which a
+//                 sum does not care about - so no lane shuffles or LDS round trip between the layers.
+//        (c) unsigned-integer max of the float bits (values >= 0 after ReLU) into an LDS tile [C][tile_w|1]
+//            (odd stride: conflict-free)
+//        (d) the tile - zeros for empty cells included - streams to the NCHW canvas, 256 B per wave-instruction.
+//            The canvas is written exactly once and never read or memset: algorithmic traffic
+//            4*(N*D + C*ny*nx) bytes.  Tiles without points skip (a)-(c) and stream zeros.
 //
-// Index outputs (unique_coords / inverse, the "bit-exact pillar indices" of the parity contract) are produced
-// by extra scans only when requested.
+// Index outputs (unique_coords / inverse, the "bit-exact pillar indices" of the parity contract) come from a
+// separate per-cell occupancy path (count, two scans) that only runs when they are requested.
 //
 // Cell-id arithmetic is float32 exactly as the reference's: (x - min_x) * ppm, subtraction and multiplication
-// rounded separately, then truncation.  Because the product can round up to exactly nx (resp. ny) - e.g.
-// y = nextafter(40,0) with min_y=-40 gives yi = 320 - the key space has one extra row and column; the canvas
-// write clamps them like the reference (:89) with "later pillar in unique order wins".
+// rounded separately (this file is compiled with FMA contraction off), then truncation.  Because the product can
+// round up to exactly nx (resp. ny) - y = nextafter(40,0) with min_y=-40 gives yi = 320 - the key space has one
+// extra row and column; the canvas write clamps them like the reference (:89) and lets the LATER pillar in unique
+// order win, by processing such "overflow" cells as extra layers after the regular ones.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -39,6 +50,8 @@ using namespace lav;
 constexpr int C = 64;            // PointNet width (config num_features [64,64])
 constexpr int MAX_BATCH = 64;    // per-call limit on clouds (kernel-argument table)
 constexpr int TILE_MAX_W = 176;  // canvas columns per workgroup tile (LDS tile [64][tile_w|1] floats)
+constexpr int MAX_LAYERS = 64;   // regular + overflow layers a tile may have (2-4 for square grids)
+constexpr int REC_MAX = 16;      // dwords per point record the workspace is sized for (D <= 15)
 constexpr double FIX_SCALE = 4294967296.0;  // 2^32 fixed-point scale of the per-cell coordinate sums
 
 struct PillarArgs {
@@ -46,13 +59,33 @@ struct PillarArgs {
     int batch, max_points, D;
     int n[MAX_BATCH];
     float min_x, max_x, min_y, max_y, ppm;
-    int nx, ny;  // nx = number of xi cells = canvas columns count; ny = number of yi cells = canvas rows count
+    int nx, ny;  // nx = number of xi cells = canvas columns; ny = number of yi cells = canvas rows
     int KX, KY;  // key space (nx+1) x (ny+1)
+    int T, TW;   // column tiles per canvas row, columns per tile
 };
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// cell key of a point, or -1 (grid_locations, point_pillar.py:70-79)
+__device__ __forceinline__ int cell_key(const PillarArgs &a, int b, float x, float y) {
+    // NaN fails every comparison and is dropped, as in torch
+    if (!(x >= a.min_x && x < a.max_x && y >= a.min_y && y < a.max_y)) return -1;
+    const float fx = (x - a.min_x) * a.ppm;  // two roundings (contraction is off)
+    const float fy = (y - a.min_y) * a.ppm;
+    const int xi = (int)fx, yi = (int)fy;    // truncation; both are in [0, nx] x [0, ny]
+    return (b * a.KX + xi) * a.KY + yi;
+}
+
+// canvas tile that cell (b, xi, yi) lands on (scatter_points clamp, point_pillar.py:89)
+__device__ __forceinline__ int tile_of(const PillarArgs &a, int b, int xi, int yi) {
+    const int r = min(max(a.ny - 1 - xi, 0), a.ny - 1);
+    const int col = min(yi, a.nx - 1);
+    return (b * a.ny + r) * a.T + col / a.TW;
+}
+
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_key_count(PillarArgs a, int *__restrict__ key, int *__restrict__ slot,
-                                                   int *__restrict__ cell_count) {
+__global__ __launch_bounds__(256) void k_tile_count(PillarArgs a, int *__restrict__ key, int *__restrict__ slot,
+                                                    int *__restrict__ tile_count) {
     const long total = (long)a.batch * a.max_points;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -61,25 +94,305 @@ __global__ __launch_bounds__(256) void k_key_count(PillarArgs a, int *__restrict
     int k = -1;
     if (i < a.n[b]) {
         const float *pt = a.points + gid * a.D;
-        const float x = pt[0], y = pt[1];
-        // NaN fails every comparison and is dropped, as in torch
-        if (x >= a.min_x && x < a.max_x && y >= a.min_y && y < a.max_y) {
-            const float fx = __fmul_rn(__fsub_rn(x, a.min_x), a.ppm);
-            const float fy = __fmul_rn(__fsub_rn(y, a.min_y), a.ppm);
-            const int xi = (int)fx, yi = (int)fy;  // truncation; both are in [0, nx] x [0, ny]
-            k = (b * a.KX + xi) * a.KY + yi;
-        }
+        k = cell_key(a, b, pt[0], pt[1]);
     }
     key[gid] = k;
-    if (k >= 0) slot[gid] = atomicAdd(&cell_count[k], 1);
+    if (k >= 0) {
+        const int cellk = k - b * a.KX * a.KY;
+        slot[gid] = atomicAdd(&tile_count[tile_of(a, b, cellk / a.KY, cellk % a.KY)], 1);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_place(long total, const int *__restrict__ key, const int *__restrict__ slot,
-                                               const int *__restrict__ cell_offset, int *__restrict__ sorted_idx) {
+// exclusive prefix of the tile counters (ntiles is a few hundred to a few thousand): one workgroup
+__global__ __launch_bounds__(1024) void k_tile_scan(const int *__restrict__ count, int n, int *__restrict__ offset) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? count[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int s = wsum[w];
+            if (w < wid) wbase += s;
+            tot += s;
+        }
+        const int carry = carry_s;
+        if (i < n) offset[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) offset[n] = carry_s;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_tile_place(PillarArgs a, const int *__restrict__ key, const int *__restrict__ slot,
+                                                    const int *__restrict__ tile_offset, float *__restrict__ rec) {
+    constexpr int RS = D + 1;
+    const long total = (long)a.batch * a.max_points;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int k = key[gid];
-    if (k >= 0) sorted_idx[cell_offset[k] + slot[gid]] = (int)gid;
+    if (k < 0) return;
+    const int b = (int)(gid / a.max_points);
+    const int cellk = k - b * a.KX * a.KY;
+    const long j = tile_offset[tile_of(a, b, cellk / a.KY, cellk % a.KY)] + slot[gid];
+    const float *pt = a.points + gid * D;
+    float v[RS];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = pt[d];
+    v[D] = __int_as_float(k);
+    float *o = rec + j * RS;
+    if constexpr (RS % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < RS / 4; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < RS; ++d) o[d] = v[d];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void load_record(const float *__restrict__ rec, long j, float (&v)[D + 1]) {
+    constexpr int RS = D + 1;
+    const float *p = rec + j * RS;
+    if constexpr (RS % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < RS / 4; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(p)[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < RS; ++d) v[d] = p[d];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void decorate(const PillarArgs &a, const float *pt, const float *mean3, int xi, int yi, float *f) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) f[d] = pt[d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) f[D + d] = pt[d] - mean3[d];
+    // reference decorate(): x - (yi/ppm + min_x), y - (xi/ppm + min_y)  (sic: swapped, un-centred; :57-58)
+    f[D + 3] = pt[0] - ((float)yi / a.ppm + a.min_x);
+    f[D + 4] = pt[1] - ((float)xi / a.ppm + a.min_y);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int D, bool USE_MFMA>
+__global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const float *__restrict__ rec,
+                                                          const int *__restrict__ tile_offset,
+                                                          const float *__restrict__ w1, const float *__restrict__ b1,
+                                                          const float *__restrict__ w2, const float *__restrict__ b2,
+                                                          float *__restrict__ canvas) {
+    constexpr int K1 = D + 5;          // decorated features
+    constexpr int KS1 = (K1 + 2) / 2;  // layer-1 k-steps incl. the bias feature (K1=16 -> 9)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TW = a.TW, TWP = TW | 1;
+    float *tile = reinterpret_cast<float *>(smem);                                                        // [C][TWP]
+    unsigned long long *sums = reinterpret_cast<unsigned long long *>(smem + ((C * TWP * 4 + 15) & ~15));  // [TW][3]
+    float *means = reinterpret_cast<float *>(sums + TW * 3);                                              // [TW][3]
+    int *cnt = reinterpret_cast<int *>(means + TW * 3);                                                   // [TW]
+    int *nl = cnt + ((TW + 3) & ~3);                                                                      // [MAX_LAYERS]
+    float *w2s = reinterpret_cast<float *>(nl + MAX_LAYERS);                                              // [C][C]
+
+    const int wg = blockIdx.x;
+    const int t = wg % a.T;
+    const int r = (wg / a.T) % a.ny;  // canvas row
+    const int b = wg / (a.T * a.ny);
+    const int c0 = t * TW;
+    const int c1 = min(a.nx, c0 + TW);
+    const int tw = c1 - c0;  // live columns in this tile
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int p0 = tile_offset[wg], p1 = tile_offset[wg + 1];
+    float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
+    const long cstride = (long)a.ny * a.nx;
+
+    if (p0 == p1) {  // empty tile: stream zeros (workgroup-uniform)
+        for (int ch = wid; ch < C; ch += 4)
+            for (int j = lane; j < tw; j += 64) dst[ch * cstride + j] = 0.f;
+        return;
+    }
+    for (int i = tid; i < C * TWP; i += 256) tile[i] = 0.f;
+    if (tid < MAX_LAYERS) nl[tid] = 0;
+    if (USE_MFMA)
+        for (int i = tid; i < C * C; i += 256) w2s[i] = w2[i];
+
+    // key rows that land on canvas row r, and overflow columns of the last tile (reference clamp, :89)
+    const int xi_lo = r > 0 ? a.ny - 1 - r : max(a.ny - 1, 0);
+    const int xi_hi = r > 0 ? xi_lo : a.nx;
+    const int n_over = (c1 == a.nx) ? max(0, a.ny - a.nx + 1) : 0;
+    const int nlay_y = n_over + 1;
+    const int nlayers = (xi_hi - xi_lo + 1) * nlay_y;
+    const int cellbase = b * a.KX * a.KY;
+    // record -> (layer, tile column, xi, yi).  Layers are ordered like the reference's sorted unique rows.
+    auto classify = [&](int k, int &layer, int &col, int &xi, int &yi) {
+        const int cellk = k - cellbase;
+        xi = cellk / a.KY;
+        yi = cellk - xi * a.KY;
+        const int over = yi >= a.nx ? yi - a.nx + 1 : 0;
+        layer = (xi - xi_lo) * nlay_y + over;
+        col = min(yi, a.nx - 1) - c0;
+    };
+
+    float a1[2][KS1];  // layer-1 A operand: W1[2s+half][32*mt + l31], bias as k = K1
+    float b2v[2];
+    const int npass = (p1 - p0 + 31) >> 5;
+    if (USE_MFMA && wid < npass) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const int k = 2 * s + half;
+                const int c = 32 * mt + l31;
+                a1[mt][s] = k < K1 ? w1[k * C + c] : (k == K1 ? b1[c] : 0.f);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b2v[nt] = b2[32 * nt + l31];
+    }
+
+    for (int L = 0; L < min(nlayers, MAX_LAYERS); ++L) {
+        if (L > 0 && nl[L] == 0) continue;  // workgroup-uniform; nl[] is complete after layer 0's first barrier pair
+        __syncthreads();
+        for (int j = tid; j < TW * 3; j += 256) sums[j] = 0ull;
+        for (int j = tid; j < TW; j += 256) cnt[j] = 0;
+        __syncthreads();
+        // (a) per-cell coordinate sums and counts of this layer
+        for (int j = p0 + tid; j < p1; j += 256) {
+            const float *rp = rec + (long)j * (D + 1);
+            int layer, col, xi, yi;
+            classify(__float_as_int(rp[D]), layer, col, xi, yi);
+            if (L == 0) atomicAdd(&nl[min(layer, MAX_LAYERS - 1)], 1);
+            if (layer == L) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const long long q = __double2ll_rn((double)rp[d] * FIX_SCALE);
+                    atomicAdd(&sums[col * 3 + d], (unsigned long long)q);
+                }
+                atomicAdd(&cnt[col], 1);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < tw; j += 256) {
+            const int n = cnt[j];
+            if (n > 0) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    means[j * 3 + d] = (float)((double)(long long)sums[j * 3 + d] / ((double)n * FIX_SCALE));
+            }
+        }
+        if (L > 0) {  // a later pillar replaces whatever an earlier one put on the same canvas cell
+            for (int i = tid; i < C * tw; i += 256) {
+                const int ch = i / tw, j = i - ch * tw;
+                if (cnt[j] > 0) tile[ch * TWP + j] = 0.f;
+            }
+        }
+        __syncthreads();
+
+        if constexpr (!USE_MFMA) {
+            // cross-check path: one point per thread, plain fp32 FMAs (slow; selected by LAV_PILLAR_IMPL=valu)
+            for (int j = p0 + tid; j < p1; j += 256) {
+                float v[D + 1];
+                load_record<D>(rec, j, v);
+                int layer, col, xi, yi;
+                classify(__float_as_int(v[D]), layer, col, xi, yi);
+                if (layer != L) continue;
+                float f[K1];
+                decorate<D>(a, v, means + col * 3, xi, yi, f);
+                float h1[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float acc = b1[c];
+#pragma unroll
+                    for (int k = 0; k < K1; ++k) acc = fmaf(f[k], w1[k * C + c], acc);
+                    h1[c] = acc > 0.f ? acc : 0.f;
+                }
+                for (int c = 0; c < C; ++c) {
+                    float acc = b2[c];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) acc = fmaf(h1[k], w2[k * C + c], acc);
+                    const float o = acc > 0.f ? acc : 0.f;
+                    atomicMax(reinterpret_cast<unsigned *>(&tile[c * TWP + col]), __float_as_uint(o));
+                }
+            }
+        } else {
+            for (int pass = wid; pass < npass; pass += 4) {
+                const int j = p0 + pass * 32 + l31;
+                bool live = j < p1;
+                float v[D + 1];
+                load_record<D>(rec, live ? j : p0, v);
+                int layer, col, xi, yi;
+                classify(__float_as_int(v[D]), layer, col, xi, yi);
+                live = live && layer == L;
+                const int mycol = live ? col : -1;
+                float f[K1];
+                decorate<D>(a, v, means + (live ? col : 0) * 3, xi, yi, f);
+                float fe[KS1];
+#pragma unroll
+                for (int s = 0; s < KS1; ++s) {
+                    const float ev = 2 * s < K1 ? f[2 * s < K1 ? 2 * s : 0] : (2 * s == K1 ? 1.f : 0.f);
+                    const float od = 2 * s + 1 < K1 ? f[2 * s + 1 < K1 ? 2 * s + 1 : 0] : (2 * s + 1 == K1 ? 1.f : 0.f);
+                    fe[s] = live ? (half ? od : ev) : 0.f;
+                }
+                // layer 1
+                f32x16 d1[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) d1[mt][q] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s) d1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], fe[s], d1[mt], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) d1[mt][q] = d1[mt][q] > 0.f ? d1[mt][q] : 0.f;
+                }
+                // after layer 2 this lane holds channel c2 of the 16 points in MFMA rows (q&3)+8*(q>>2)+4*half;
+                // their tile columns come from the lanes that loaded them
+                int cols[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cols[q] = __shfl(mycol, (q & 3) + 8 * (q >> 2) + 4 * half, 64);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x16 d2;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) d2[q] = b2v[nt];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) {
+                            // B operand: W2[k][32*nt + l31] with k = 32*mt + (rr&3) + 8*(rr>>2) + 4*half
+                            const float wv = w2s[(32 * mt + (rr & 3) + 8 * (rr >> 2) + 4 * half) * C + 32 * nt + l31];
+                            d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[mt][rr], wv, d2, 0, 0, 0);
+                        }
+                    unsigned *trow = reinterpret_cast<unsigned *>(tile + (32 * nt + l31) * TWP);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float o = d2[q] > 0.f ? d2[q] : 0.f;  // also maps -0 and NaN to +0
+                        if (cols[q] >= 0) atomicMax(trow + cols[q], __float_as_uint(o));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (d) stream the tile out; canvas [B][C][ny][nx]
+    for (int ch = wid; ch < C; ch += 4) {
+        const float *src = tile + ch * TWP;
+        float *d = dst + ch * cstride;
+        for (int j = lane; j < tw; j += 64) d[j] = src[j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -176,270 +489,14 @@ int exclusive_scan(const int *in, long n, int mode, int *out, int *block_sums, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// PointNet + scatter-max + canvas tile.
-//
-// Workgroup = 4 waves = one (cloud, canvas row, column tile).  Per "layer" (see the override rules above):
-//   (a) per-cell xyz sums in LDS (64-bit fixed point, order independent), means
-//   (b) every wave takes passes of 32 sorted points and runs BOTH PointNet layers on the matrix cores with all
-//       activations in registers (v_mfma_f32_32x32x2_f32, exact fp32):
-//         layer 1 (transposed)  D1[c][p]  = sum_k W1[k][c] * F[k][p]     A = weights, B = point features
-//             lane l supplies feature 2s+(l>>5) of point l&31 at k-step s; the bias rides as feature 16 (=1).
-//             D1 leaves lane (p, half) holding channels c = 32*mt + (r&3) + 8*(r>>2) + 4*half  (r = 0..15)
-//         layer 2               D2[p][c2] = sum_c H1[p][c] * W2[c][c2]   A = relu(D1) AS IT SITS, B = weights
-//             k-step (mt, r) uses k = 32*mt + (r&3) + 8*(r>>2) + 4*half - a permutation of 0..63, which a sum
-//             does not care about - so no lane shuffles or LDS round trip between the layers.
-//             D2 leaves lane (c2, half) holding 16 points.  Sorted point j of the pass is given to MFMA row
-//             p(j) = (j&3) + 8*((j&15)>>2) + 4*(j>>4), so those 16 points are CONSECUTIVE sorted points and
-//             equal-cell runs are folded in registers before one LDS max per run.
-//   (c) integer max of the float bits into the LDS tile [C][tile_w|1] (odd stride: conflict-free)
-//   (d) the tile - zeros included - streams to the NCHW canvas, 256 B per wave-instruction.
-struct TileGeo {
-    int tiles_per_row;  // T
-    int TW;             // columns per tile
-};
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// shared prologue of a layer: zero sums, accumulate, means, override-zeroing.  Returns with a barrier done.
-template <int D>
-__device__ __forceinline__ void layer_means(const PillarArgs &a, const int *__restrict__ key, const int *__restrict__ sorted_idx,
-                                            const int *__restrict__ cell_offset, int cell0, int ncell, int p0, int p1,
-                                            int yi0, int c0, bool overriding, int TWP, float *tile,
-                                            unsigned long long *sums, float *means, int *occupied) {
-    const int tid = threadIdx.x;
-    __syncthreads();
-    for (int j = tid; j < ncell * 3; j += 256) sums[j] = 0ull;
-    __syncthreads();
-    for (int j = p0 + tid; j < p1; j += 256) {
-        const int idx = sorted_idx[j];
-        const int cell = key[idx] - cell0;
-        const float *pt = a.points + (long)idx * D;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const long long q = __double2ll_rn((double)pt[d] * FIX_SCALE);
-            atomicAdd(&sums[cell * 3 + d], (unsigned long long)q);
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < ncell; j += 256) {
-        const int cnt = cell_offset[cell0 + j + 1] - cell_offset[cell0 + j];
-        occupied[j] = cnt > 0;
-        if (cnt > 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-                means[j * 3 + d] = (float)((double)(long long)sums[j * 3 + d] / ((double)cnt * FIX_SCALE));
-        }
-    }
-    __syncthreads();
-    if (overriding) {  // a later pillar replaces whatever an earlier one put on the same canvas cell
-        for (int i = tid; i < C * ncell; i += 256) {
-            const int ch = i / ncell, j = i - ch * ncell;
-            const int col = min(yi0 + j, a.nx - 1) - c0;
-            if (occupied[j]) tile[ch * TWP + col] = 0.f;
-        }
-        __syncthreads();
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void decorate(const PillarArgs &a, const float *pt, const float *mean3, int xi, int yi, float *f) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) f[d] = pt[d];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) f[D + d] = __fsub_rn(f[d], mean3[d]);
-    // reference decorate(): x - (yi/ppm + min_x), y - (xi/ppm + min_y)  (sic: swapped, un-centred; :57-58)
-    f[D + 3] = __fsub_rn(f[0], __fadd_rn(__fdiv_rn((float)yi, a.ppm), a.min_x));
-    f[D + 4] = __fsub_rn(f[1], __fadd_rn(__fdiv_rn((float)xi, a.ppm), a.min_y));
-}
-
-template <int D, bool USE_MFMA>
-__global__ __launch_bounds__(256, 2) void k_pointnet_scatter(PillarArgs a, TileGeo tg, const int *__restrict__ key,
-                                                          const int *__restrict__ sorted_idx,
-                                                          const int *__restrict__ cell_offset,
-                                                          const float *__restrict__ w1, const float *__restrict__ b1,
-                                                          const float *__restrict__ w2, const float *__restrict__ b2,
-                                                          float *__restrict__ canvas) {
-    constexpr int K1 = D + 5;             // decorated features
-    constexpr int KS1 = (K1 + 2) / 2;     // layer-1 k-steps incl. the bias feature (K1=16 -> 9)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int TW = tg.TW, TWP = TW | 1;
-    float *tile = reinterpret_cast<float *>(smem);                                                     // [C][TWP]
-    unsigned long long *sums = reinterpret_cast<unsigned long long *>(smem + ((C * TWP * 4 + 15) & ~15));  // [TW][3]
-    float *means = reinterpret_cast<float *>(sums + TW * 3);                                           // [TW][3]
-    int *occupied = reinterpret_cast<int *>(means + TW * 3);                                           // [TW]
-    float *w2s = reinterpret_cast<float *>(occupied + ((TW + 3) & ~3));                                // [C][C] layer-2 weights
-
-    int wg = blockIdx.x;
-    const int t = wg % tg.tiles_per_row;
-    wg /= tg.tiles_per_row;
-    const int r = wg % a.ny;  // canvas row
-    const int b = wg / a.ny;
-    const int c0 = t * TW;
-    const int c1 = min(a.nx, c0 + TW);
-    const int tw = c1 - c0;  // live columns in this tile
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-
-    for (int i = tid; i < C * TWP; i += 256) tile[i] = 0.f;
-
-    // weights in registers (MFMA path), loaded lazily by waves that have work
-    float a1[2][KS1];   // layer-1 A operand: W1[2s+half][32*mt + l31], bias as k = K1
-    float b2v[2];
-    bool weights_loaded = false, w2_staged = false;
-
-    // key rows that land on canvas row r (reference clamp semantics, point_pillar.py:89)
-    int xi_lo, xi_hi;
-    if (r > 0) {
-        xi_lo = xi_hi = a.ny - 1 - r;
-    } else {
-        xi_lo = max(a.ny - 1, 0);
-        xi_hi = a.nx;
-    }
-    for (int xi = xi_lo; xi <= min(xi_hi, a.nx); ++xi) {
-        // layers: first the cells that map 1:1 onto the tile's columns, then (last tile only) the overflow
-        // cells yi in [nx, ny] which all clamp onto column nx-1
-        const int yi_direct_hi = min(c1 - 1, a.ny);
-        const int n_over = (c1 == a.nx) ? max(0, a.ny - a.nx + 1) : 0;
-        for (int layer = 0; layer <= n_over; ++layer) {
-            int yi0, ncell;
-            if (layer == 0) {
-                yi0 = c0;
-                ncell = yi_direct_hi - c0 + 1;
-            } else {
-                yi0 = a.nx + layer - 1;
-                ncell = 1;
-            }
-            if (ncell <= 0) continue;
-            const int cell0 = (b * a.KX + xi) * a.KY + yi0;
-            const int p0 = cell_offset[cell0], p1 = cell_offset[cell0 + ncell];
-            if (p0 == p1) continue;  // workgroup-uniform
-            const bool overriding = (layer > 0) || (xi > xi_lo);
-            if (USE_MFMA && !w2_staged) {  // layer-2 weights -> LDS once per workgroup (B operand of every pass)
-                w2_staged = true;
-                for (int i = tid; i < C * C; i += 256) w2s[i] = w2[i];
-            }
-            layer_means<D>(a, key, sorted_idx, cell_offset, cell0, ncell, p0, p1, yi0, c0, overriding, TWP, tile, sums, means, occupied);
-
-            if constexpr (!USE_MFMA) {
-                // cross-check path: one point per thread, plain fp32 FMAs (slow; selected by LAV_PILLAR_IMPL=valu)
-                for (int j = p0 + tid; j < p1; j += 256) {
-                    const int idx = sorted_idx[j];
-                    const int cell = key[idx] - cell0;
-                    const int yi = yi0 + cell;
-                    float f[K1];
-                    decorate<D>(a, a.points + (long)idx * D, means + cell * 3, xi, yi, f);
-                    float h1[C];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float acc = b1[c];
-#pragma unroll
-                        for (int k = 0; k < K1; ++k) acc = fmaf(f[k], w1[k * C + c], acc);
-                        h1[c] = acc > 0.f ? acc : 0.f;
-                    }
-                    const int col = min(yi, a.nx - 1) - c0;
-                    for (int c = 0; c < C; ++c) {
-                        float acc = b2[c];
-#pragma unroll
-                        for (int k = 0; k < C; ++k) acc = fmaf(h1[k], w2[k * C + c], acc);
-                        const float v = acc > 0.f ? acc : 0.f;
-                        atomicMax(reinterpret_cast<unsigned *>(&tile[c * TWP + col]), __float_as_uint(v));
-                    }
-                }
-            } else {
-                const int npass = (p1 - p0 + 31) >> 5;
-                if (wid < npass && !weights_loaded) {
-                    weights_loaded = true;
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int s = 0; s < KS1; ++s) {
-                            const int k = 2 * s + half;
-                            const int c = 32 * mt + l31;
-                            a1[mt][s] = k < K1 ? w1[k * C + c] : (k == K1 ? b1[c] : 0.f);
-                        }
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) b2v[nt] = b2[32 * nt + l31];
-                }
-                // MFMA row of this lane's point -> position inside the pass's 32 sorted points
-                const int sp = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);
-                for (int pass = wid; pass < npass; pass += 4) {
-                    const int j = p0 + pass * 32 + sp;
-                    const bool live = j < p1;
-                    const int idx = live ? sorted_idx[j] : 0;
-                    const int cell = live ? key[idx] - cell0 : 0;
-                    const int yi = yi0 + cell;
-                    const int mycol = live ? min(yi, a.nx - 1) - c0 : -1;
-                    float f[K1];
-                    decorate<D>(a, a.points + (long)idx * D, means + cell * 3, xi, yi, f);
-                    float fe[KS1];
-#pragma unroll
-                    for (int s = 0; s < KS1; ++s) {
-                        const float ev = 2 * s < K1 ? f[2 * s < K1 ? 2 * s : 0] : (2 * s == K1 ? 1.f : 0.f);
-                        const float od = 2 * s + 1 < K1 ? f[2 * s + 1 < K1 ? 2 * s + 1 : 0] : (2 * s + 1 == K1 ? 1.f : 0.f);
-                        fe[s] = live ? (half ? od : ev) : 0.f;
-                    }
-                    // layer 1
-                    f32x16 d1[2];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) d1[mt][q] = 0.f;
-#pragma unroll
-                        for (int s = 0; s < KS1; ++s) d1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], fe[s], d1[mt], 0, 0, 0);
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) d1[mt][q] = d1[mt][q] > 0.f ? d1[mt][q] : 0.f;
-                    }
-                    // the 16 points this lane will hold after layer 2 are sorted positions 16*half + q;
-                    // their tile columns come from the lanes that loaded them (MFMA row = (q&3)+8*(q>>2)+4*half)
-                    int cols[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) cols[q] = __shfl(mycol, (q & 3) + 8 * (q >> 2) + 4 * half, 64);
-                    // layer 2 + run-folded max
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        f32x16 d2;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) d2[q] = b2v[nt];
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                            for (int rr = 0; rr < 16; ++rr) {
-                                // B operand: W2[k][32*nt + l31] with k = 32*mt + (rr&3) + 8*(rr>>2) + 4*half
-                                const float wv = w2s[(32 * mt + (rr & 3) + 8 * (rr >> 2) + 4 * half) * C + 32 * nt + l31];
-                                d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[mt][rr], wv, d2, 0, 0, 0);
-                            }
-                        unsigned *trow = reinterpret_cast<unsigned *>(tile + (32 * nt + l31) * TWP);
-                        int cur = cols[0];
-                        float best = d2[0] > 0.f ? d2[0] : 0.f;
-#pragma unroll
-                        for (int q = 1; q < 16; ++q) {
-                            const float v = d2[q] > 0.f ? d2[q] : 0.f;
-                            if (cols[q] != cur) {
-                                if (cur >= 0) atomicMax(trow + cur, __float_as_uint(best));
-                                cur = cols[q];
-                                best = v;
-                            } else {
-                                best = fmaxf(best, v);
-                            }
-                        }
-                        if (cur >= 0) atomicMax(trow + cur, __float_as_uint(best));
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // (d) stream the tile out; canvas [B][C][ny][nx]
-    float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
-    const long cstride = (long)a.ny * a.nx;
-    for (int ch = wid; ch < C; ch += 4) {
-        const float *src = tile + ch * TWP;
-        float *d = dst + ch * cstride;
-        for (int j = lane; j < tw; j += 64) d[j] = src[j];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Index outputs
+__global__ __launch_bounds__(256) void k_cell_count(long total, const int *__restrict__ key, int *__restrict__ cell_count) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int k = key[gid];
+    if (k >= 0) atomicAdd(&cell_count[k], 1);
+}
+
 __global__ __launch_bounds__(256) void k_unique_coords(PillarArgs a, const int *__restrict__ cell_count,
                                                        const int *__restrict__ cell_rank, long ncells,
                                                        int *__restrict__ unique_coords) {
@@ -466,30 +523,34 @@ __global__ void k_counts(const int *p_total, const int *kept_total, int *counts)
     counts[1] = *kept_total;
 }
 
-TileGeo tile_geometry(int nx) {
-    TileGeo tg;
-    tg.tiles_per_row = (nx + TILE_MAX_W - 1) / TILE_MAX_W;
-    int tw = (nx + tg.tiles_per_row - 1) / tg.tiles_per_row;
-    tg.TW = (tw + 3) / 4 * 4;
-    return tg;
+void tile_geometry(int nx, int &T, int &TW) {
+    T = (nx + TILE_MAX_W - 1) / TILE_MAX_W;
+    const int tw = (nx + T - 1) / T;
+    TW = (tw + 3) / 4 * 4;
 }
 
 struct Workspace {
-    int *cell_count, *cell_offset, *key, *slot, *sorted_idx, *block_sums, *cell_rank, *kept_rank, *totals;
+    int *tile_count, *tile_offset, *key, *slot;
+    float *rec;
+    int *cell_count, *cell_rank, *kept_rank, *block_sums, *totals;
 };
 
 size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid *g) {
+    int T, TW;
+    tile_geometry(g->nx, T, TW);
+    const size_t ntiles = (size_t)batch * g->ny * T;
     const size_t ncells = (size_t)batch * (g->nx + 1) * (g->ny + 1);
     const size_t total = (size_t)batch * max_points;
     const size_t nmax = ncells > total ? ncells : total;
-    w.cell_count = ar.take<int>(ncells);
-    w.cell_offset = ar.take<int>(ncells + 1);
+    w.tile_count = ar.take<int>(ntiles + 1);
+    w.tile_offset = ar.take<int>(ntiles + 1);
     w.key = ar.take<int>(total);
     w.slot = ar.take<int>(total);
-    w.sorted_idx = ar.take<int>(total);
-    w.block_sums = ar.take<int>((nmax + SCAN_TILE - 1) / SCAN_TILE + 1);
+    w.rec = ar.take<float>(total * REC_MAX);
+    w.cell_count = ar.take<int>(ncells);
     w.cell_rank = ar.take<int>(ncells + 1);
     w.kept_rank = ar.take<int>(total + 1);
+    w.block_sums = ar.take<int>((nmax + SCAN_TILE - 1) / SCAN_TILE + 1);
     w.totals = ar.take<int>(4);
     return align_up(ar.used, 256);
 }
@@ -500,25 +561,36 @@ bool use_valu_impl() {
 }
 
 template <int D>
-int launch_pointnet(const PillarArgs &a, const TileGeo &tg, const Workspace &w, const lav_pointnet *net, float *canvas,
-                    hipStream_t st) {
-    const int TWP = tg.TW | 1;
-    const size_t lds = (((size_t)C * TWP * 4 + 15) & ~(size_t)15) + (size_t)tg.TW * 3 * 8 + (size_t)tg.TW * 3 * 4 +
-                       (size_t)((tg.TW + 3) & ~3) * 4 + (size_t)C * C * 4;
-    const int grid = a.batch * a.ny * tg.tiles_per_row;
+int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, hipStream_t st) {
+    const long total = (long)a.batch * a.max_points;
+    const int ntiles = a.batch * a.ny * a.T;
+    const int tok_prep = timer_begin("pillar_prep", st);
+    LAV_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)(ntiles + 1) * sizeof(int), st));
+    if (total > 0) {
+        hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_count);
+        LAV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.tile_count, ntiles, w.tile_offset);
+    LAV_LAUNCH_CHECK();
+    if (total > 0) {
+        hipLaunchKernelGGL((k_tile_place<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_offset, w.rec);
+        LAV_LAUNCH_CHECK();
+    }
+    timer_end(tok_prep, st);
+    const int TWP = a.TW | 1;
+    const size_t lds = (((size_t)C * TWP * 4 + 15) & ~(size_t)15) + (size_t)a.TW * 3 * 8 + (size_t)a.TW * 3 * 4 +
+                       (size_t)((a.TW + 3) & ~3) * 4 + (size_t)MAX_LAYERS * 4 + (size_t)C * C * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pointnet_scatter<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pointnet_scatter<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int tok = timer_begin("pointnet_scatter", st);
     if (use_valu_impl())
-        hipLaunchKernelGGL((k_pointnet_scatter<D, false>), dim3(grid), dim3(256), lds, st, a, tg, w.key, w.sorted_idx,
-                           w.cell_offset, net->w1, net->b1, net->w2, net->b2, canvas);
+        hipLaunchKernelGGL((k_tile_pointnet<D, false>), dim3(ntiles), dim3(256), lds, st, a, w.rec, w.tile_offset, net->w1, net->b1, net->w2, net->b2, canvas);
     else
-        hipLaunchKernelGGL((k_pointnet_scatter<D, true>), dim3(grid), dim3(256), lds, st, a, tg, w.key, w.sorted_idx,
-                           w.cell_offset, net->w1, net->b1, net->w2, net->b2, canvas);
+        hipLaunchKernelGGL((k_tile_pointnet<D, true>), dim3(ntiles), dim3(256), lds, st, a, w.rec, w.tile_offset, net->w1, net->b1, net->w2, net->b2, canvas);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
@@ -544,6 +616,7 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
     LAV_REQUIRE(grid->nx > 0 && grid->ny > 0, "lav_pillar_scatter: empty grid");
     LAV_REQUIRE((long)batch * (grid->nx + 1) * (grid->ny + 1) < (1l << 30) && (long)batch * max_points < (1l << 30),
                 "lav_pillar_scatter: problem too large for 32-bit indices");
+    LAV_REQUIRE(D + 1 <= REC_MAX, "lav_pillar_scatter: point width %d too large", D);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
     Arena ar(workspace, workspace_bytes);
@@ -563,33 +636,30 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
     for (int b = batch; b < MAX_BATCH; ++b) a.n[b] = 0;
     a.min_x = grid->min_x; a.max_x = grid->max_x; a.min_y = grid->min_y; a.max_y = grid->max_y; a.ppm = grid->ppm;
     a.nx = grid->nx; a.ny = grid->ny; a.KX = grid->nx + 1; a.KY = grid->ny + 1;
+    tile_geometry(a.nx, a.T, a.TW);
+    {   // canvas row 0 collects key rows ny-1..nx, the last column tile collects key columns nx-1..ny (reference clamp)
+        const long lay = (long)(a.nx - (a.ny - 1) + 1 > 1 ? a.nx - (a.ny - 1) + 1 : 1) * ((a.ny - a.nx + 1 > 0 ? a.ny - a.nx + 1 : 0) + 1);
+        LAV_REQUIRE(lay <= MAX_LAYERS, "lav_pillar_scatter: grid %dx%d needs %ld clamp layers (max %d)", a.nx, a.ny, lay, MAX_LAYERS);
+    }
 
-    const long ncells = (long)batch * a.KX * a.KY;
-    const long total = (long)batch * max_points;
-    const int tok_prep = timer_begin("pillar_prep", st);
-    LAV_HIP(hipMemsetAsync(w.cell_count, 0, ncells * sizeof(int), st));
-    if (total > 0) {
-        hipLaunchKernelGGL(k_key_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.cell_count);
-        LAV_LAUNCH_CHECK();
-    }
-    int rc = exclusive_scan(w.cell_count, ncells, 0, w.cell_offset, w.block_sums, nullptr, st);
-    if (rc) return rc;
-    if (total > 0) {
-        hipLaunchKernelGGL(k_place, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, w.key, w.slot, w.cell_offset, w.sorted_idx);
-        LAV_LAUNCH_CHECK();
-    }
-    timer_end(tok_prep, st);
-    const TileGeo tg = tile_geometry(a.nx);
+    int rc;
     switch (D) {
-        case 11: rc = launch_pointnet<11>(a, tg, w, net, canvas, st); break;
-        case 4: rc = launch_pointnet<4>(a, tg, w, net, canvas, st); break;
-        case 5: rc = launch_pointnet<5>(a, tg, w, net, canvas, st); break;
-        case 8: rc = launch_pointnet<8>(a, tg, w, net, canvas, st); break;
+        case 11: rc = launch_canvas<11>(a, w, net, canvas, st); break;
+        case 4: rc = launch_canvas<4>(a, w, net, canvas, st); break;
+        case 5: rc = launch_canvas<5>(a, w, net, canvas, st); break;
+        case 8: rc = launch_canvas<8>(a, w, net, canvas, st); break;
         default: return fail(LAV_EINVAL, "lav_pillar_scatter: point width D=%d not instantiated (4,5,8,11)", D);
     }
     if (rc) return rc;
 
     if (unique_coords || inverse || counts) {
+        const long ncells = (long)batch * a.KX * a.KY;
+        const long total = (long)batch * max_points;
+        LAV_HIP(hipMemsetAsync(w.cell_count, 0, ncells * sizeof(int), st));
+        if (total > 0) {
+            hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, w.key, w.cell_count);
+            LAV_LAUNCH_CHECK();
+        }
         rc = exclusive_scan(w.cell_count, ncells, 1, w.cell_rank, w.block_sums, w.totals + 0, st);
         if (rc) return rc;
         if (total > 0) {
