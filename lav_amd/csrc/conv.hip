@@ -41,6 +41,7 @@ struct ConvArgs {
     int cin_pad, cout_pad;  // packed-weight strides (multiples of CK / 64), zero filled
     int QH, QW, in_s, out_s;
     int Wst, ROWS, nclasses, taps_per_class, tap_group;
+    int rowblock, xblocks;  // 1: tiles are PIXW-wide segments of ONE output-grid row (wide images); 0: linearised pixels
     int relu_pre, relu_post, sigmoid;
     int cls_ntaps[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES];
     int cls_out_oy[MAX_CLASSES], cls_out_ox[MAX_CLASSES], cls_woff[MAX_CLASSES];
@@ -86,23 +87,40 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int cls = blockIdx.z % a.nclasses, n = blockIdx.z / a.nclasses;
     const int cb = blockIdx.y * CO_T;
     const int Q = a.QH * a.QW;
-    const int q0 = blockIdx.x * PIXW;
     const int Wst = a.Wst, ROWS = a.ROWS, plane = ROWS * Wst;
     float *s_in = smem;                                // [CK][ROWS][Wst]
     float *s_w = smem + ((CK * plane + 3) & ~3);       // [tap_group][CK][CO_T]
     const int ntaps = a.cls_ntaps[cls];
-    const int qy0 = q0 / a.QW;
+    // tile origin: first output-grid row, first staged input column (relative to in_ox)
+    const int xb = a.rowblock ? (int)(blockIdx.x % a.xblocks) : 0;
+    const int q0 = a.rowblock ? 0 : blockIdx.x * PIXW;
+    const int qy0 = a.rowblock ? (int)(blockIdx.x / a.xblocks) : q0 / a.QW;
+    const int xs0 = xb * PIXW * a.in_s;
     const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls];
-    const int in_ox = a.cls_in_ox[cls];
+    const int in_ox = a.cls_in_ox[cls] + xs0;
     const float *wbase = a.w + a.cls_woff[cls];
     const int *toff = a.toff + cls * a.taps_per_class;
 
+    // this lane's MP output-grid pixels
+    int pqy[MP], pqx[MP];
+    bool pvalid[MP];
     int base[MP];
 #pragma unroll
     for (int mp = 0; mp < MP; ++mp) {
-        const int q = min(q0 + (wid * MP + mp) * 32 + l31, Q - 1);
-        const int qy = q / a.QW, qx = q - qy * a.QW;
-        base[mp] = (qy - qy0) * a.in_s * Wst + qx * a.in_s;
+        const int local = (wid * MP + mp) * 32 + l31;
+        if (a.rowblock) {
+            pqy[mp] = qy0;
+            pqx[mp] = xb * PIXW + local;
+            pvalid[mp] = pqx[mp] < a.QW;
+            pqx[mp] = min(pqx[mp], a.QW - 1);
+        } else {
+            const int q = q0 + local;
+            pvalid[mp] = q < Q;
+            const int qc = min(q, Q - 1);
+            pqy[mp] = qc / a.QW;
+            pqx[mp] = qc - pqy[mp] * a.QW;
+        }
+        base[mp] = (pqy[mp] - qy0) * a.in_s * Wst + pqx[mp] * a.in_s - xs0;
     }
     // input staging map: thread owns tile positions tid + 256*i; global offset inside a channel plane or -1
     int goff[NPOS_MAX];
@@ -173,10 +191,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
 #pragma unroll
     for (int mp = 0; mp < MP; ++mp) {
-        const int q = q0 + (wid * MP + mp) * 32 + l31;
-        if (q >= Q) continue;
-        const int qy = q / a.QW, qx = q - qy * a.QW;
-        const int oy = qy * a.out_s + out_oy, ox = qx * a.out_s + out_ox;
+        if (!pvalid[mp]) continue;
+        const int oy = pqy[mp] * a.out_s + out_oy, ox = pqx[mp] * a.out_s + out_ox;
         if (oy < 0 || oy >= a.OH || ox < 0 || ox >= a.OW) continue;
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc) {
@@ -272,7 +288,7 @@ int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t 
         attr_set = true;
     }
     const int Q = p.QH * p.QW;
-    dim3 grid((Q + 128 * MP - 1) / (128 * MP), (a.cout + 32 * MC - 1) / (32 * MC), batch * p.nclasses);
+    dim3 grid(a.rowblock ? p.QH * a.xblocks : (Q + 128 * MP - 1) / (128 * MP), (a.cout + 32 * MC - 1) / (32 * MC), batch * p.nclasses);
     const int tok = timer_begin("conv2d", st);
     hipLaunchKernelGGL((k_conv<MP, MC>), grid, dim3(256), lds, st, a);
     timer_end(tok, st);
@@ -353,9 +369,17 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     }
     const int PIXW = 128 * MP, CO_T = 32 * MC;
 
+    a.rowblock = 0; a.xblocks = 1;
     a.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
     const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
     a.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
+    if ((long)a.ROWS * a.Wst > 256 * NPOS_MAX || ((size_t)CK * a.ROWS * a.Wst * 4 > 96 * 1024 && p.QW >= PIXW)) {
+        // wide image: tiles become PIXW-wide segments of one output-grid row
+        a.rowblock = 1;
+        a.xblocks = (p.QW + PIXW - 1) / PIXW;
+        a.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
+        a.ROWS = p.max_dy + 1;
+    }
     LAV_REQUIRE((long)a.ROWS * a.Wst <= 256 * NPOS_MAX, "lav_conv2d: input tile %dx%d too large for the staging map", a.ROWS, a.Wst);
     a.tap_group = p.taps_per_class <= TAP_GROUP ? p.taps_per_class : (c->kw <= TAP_GROUP ? c->kw : TAP_GROUP);
     auto lds_bytes = [&]() { return (size_t)((((size_t)CK * a.ROWS * a.Wst + 3) & ~(size_t)3) + (size_t)a.tap_group * CK * CO_T) * 4; };

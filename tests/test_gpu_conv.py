@@ -31,6 +31,8 @@ CASES = [
     ("3x1 dil 4", 16, 16, (3, 1), 1, (4, 0), (4, 1), False, 0, 36, 32),
     ("1x3 dil 2 cin 13", 13, 48, (1, 3), 1, (0, 2), (1, 2), False, 0, 20, 33),
     ("3x3 cin 3", 3, 13, (3, 3), 2, (1, 1), (1, 1), False, 0, 64, 48),
+    ("7x7 s2 wide image (row-blocked tiles)", 3, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 768),
+    ("3x3 s1 wide 16ch", 16, 64, (3, 3), 1, (1, 1), (1, 1), False, 0, 12, 1000),
 ]
 
 

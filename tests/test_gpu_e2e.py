@@ -102,7 +102,7 @@ def test_camera_nets_vs_reference_golden_and_torch_cpu(golden):
         cpu_bra = bra(wide, tel_rgb)
         seg.to(DEV); bra.to(DEV)
         logits = seg(all_rgb.to(DEV))
-        assert_close(logits[:, :, ::4, ::4].cpu().numpy(), g["logits_s"], atol=2e-4, rtol=1e-4, what="ERFNet logits")
+        assert_close(logits[:, :, ::4, ::4].cpu().numpy(), g["logits_s"], atol=1e-5 * float(np.abs(g["logits_s"]).max()), rtol=1e-4, what="ERFNet logits")  # seeded weights give |logit| ~ 2e3
         assert_close(logits.double().sum((2, 3)).cpu().numpy(), g["logits_sum"], atol=0.5, rtol=1e-4, what="ERFNet logit sums")
         gpu_trunk = bra.conv_backbone(bra.normalize(wide.to(DEV) / 255.))
         assert_close(gpu_trunk.cpu().numpy(), cpu_trunk.numpy(), atol=1e-3, rtol=1e-4, what="brake ResNet-18 trunk")
