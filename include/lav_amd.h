@@ -171,6 +171,9 @@ size_t lav_conv_packed_weight_floats(const lav_conv *c);
 /* host-side repack of a PyTorch-layout weight (Conv2d: [cout][cin][kh][kw]; ConvTranspose2d:
  * [cin][cout][kh][kw]) into the kernel's [class][tap][cin][cout] layout.  Pure host code. */
 int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed);
+/* introspection of the launch plan (host only, no device access): info[0..5] = { MP, MC, row-blocked tiles,
+ * staged tile width, staged tile rows, LDS bytes }.  Fails exactly when lav_conv2d would reject the shape. */
+int lav_conv_tile_info(const lav_conv *c, int *info);
 /* x, y, w_packed: device.  bias / scale / shift: [cout] device or NULL.  residual: same shape and
  * channel window as y, or NULL. */
 int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,

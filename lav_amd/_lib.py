@@ -55,6 +55,7 @@ SIGNATURES = {
     "lav_conv_out_hw": (_I, [C.POINTER(Conv), C.POINTER(_I), C.POINTER(_I)]),
     "lav_conv_packed_weight_floats": (_Z, [C.POINTER(Conv)]),
     "lav_conv_pack_weights": (_I, [C.POINTER(Conv), _P, _P]),
+    "lav_conv_tile_info": (_I, [C.POINTER(Conv), C.POINTER(_I)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -280,6 +280,68 @@ int build_plan(const lav_conv &c, Plan &p) {
     return LAV_OK;
 }
 
+// Tile shape + staging geometry.  Cost model (units: MFMA time of one k-step): a CU runs ceil(nwg/256) workgroups
+// back to back on its matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch.
+// Wide images switch to row-blocked tiles (a tile = PIXW pixels of ONE output-grid row) when the full-width rows of
+// a linearised tile do not fit the staging map / LDS.
+int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds) {
+    a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
+    a.tap_group = p.taps_per_class <= TAP_GROUP ? p.taps_per_class : (c.kw <= TAP_GROUP ? c.kw : TAP_GROUP);
+    const long Q = (long)p.QH * p.QW;
+    struct Geo { int rowblock, xblocks, Wst, ROWS; size_t lds; long nwg; bool ok; };
+    auto geo = [&](int mp, int mc) {
+        Geo g;
+        const int PIXW = 128 * mp, CO_T = 32 * mc;
+        g.rowblock = 0; g.xblocks = 1;
+        g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
+        const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
+        g.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
+        auto bytes = [&]() { return (size_t)((((size_t)CK * g.ROWS * g.Wst + 3) & ~(size_t)3) + (size_t)a.tap_group * CK * CO_T) * 4; };
+        if ((long)g.ROWS * g.Wst > 256 * NPOS_MAX || bytes() > 150 * 1024) {
+            g.rowblock = 1;
+            g.xblocks = (p.QW + PIXW - 1) / PIXW;
+            g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
+            g.ROWS = p.max_dy + 1;
+        }
+        g.lds = bytes();
+        g.ok = (long)g.ROWS * g.Wst <= 256 * NPOS_MAX && g.lds <= 160 * 1024;
+        const long xt = g.rowblock ? (long)p.QH * g.xblocks : (Q + PIXW - 1) / PIXW;
+        g.nwg = xt * ((c.cout + CO_T - 1) / CO_T) * c.batch * p.nclasses;
+        return g;
+    };
+    double best = 1e30;
+    Geo bg{};
+    bool found = false;
+    const int cand[3][2] = {{1, 1}, {1, 2}, {2, 2}};
+    for (auto &cd : cand) {
+        if (cd[1] == 2 && c.cout <= 32) continue;
+        const Geo g = geo(cd[0], cd[1]);
+        if (!g.ok) continue;
+        const double t = (double)((g.nwg + 255) / 256) * (cd[0] * cd[1] + 0.5);
+        if (t < best - 1e-9) { best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; }
+    }
+    LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
+    a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
+    lds = bg.lds;
+    return LAV_OK;
+}
+}  // namespace
+
+extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
+    LAV_REQUIRE(c && info, "lav_conv_tile_info: null");
+    Plan p;
+    int rc = build_plan(*c, p);
+    if (rc) return rc;
+    ConvArgs a;
+    int MP, MC;
+    size_t lds;
+    rc = choose_tile(*c, p, a, MP, MC, lds);
+    if (rc) return rc;
+    info[0] = MP; info[1] = MC; info[2] = a.rowblock; info[3] = a.Wst; info[4] = a.ROWS; info[5] = (int)lds;
+    return LAV_OK;
+}
+
+namespace {
 template <int MP, int MC>
 int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t st) {
     static bool attr_set = false;
@@ -350,40 +412,10 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     a.nclasses = p.nclasses; a.taps_per_class = p.taps_per_class;
     a.relu_pre = c->relu_pre; a.relu_post = c->relu_post; a.sigmoid = c->sigmoid;
 
-    a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
-    // tile shape: 256x64 when that still gives every CU two workgroups, else 128x64; 32-cout tiles only for
-    // narrow outputs (small tiles pay the LDS staging once per MFMA instead of once per 2-4)
-    const long Q = (long)p.QH * p.QW;
-    auto nwg = [&](int mp, int mc) { return ((Q + 128 * mp - 1) / (128 * mp)) * ((c->cout + 32 * mc - 1) / (32 * mc)) * c->batch * p.nclasses; };
-    // cost model (units: MFMA time of one k-step): a CU runs ceil(nwg/256) workgroups back to back on its
-    // matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch
-    int MP = 1, MC = 1;
-    {
-        double best = 1e30;
-        const int cand[3][2] = {{1, 1}, {1, 2}, {2, 2}};
-        for (auto &cd : cand) {
-            if (cd[1] == 2 && c->cout <= 32) continue;
-            const double t = (double)((nwg(cd[0], cd[1]) + 255) / 256) * (cd[0] * cd[1] + 0.5);
-            if (t < best - 1e-9) { best = t; MP = cd[0]; MC = cd[1]; }
-        }
-    }
-    const int PIXW = 128 * MP, CO_T = 32 * MC;
-
-    a.rowblock = 0; a.xblocks = 1;
-    a.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
-    const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
-    a.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
-    if ((long)a.ROWS * a.Wst > 256 * NPOS_MAX || ((size_t)CK * a.ROWS * a.Wst * 4 > 96 * 1024 && p.QW >= PIXW)) {
-        // wide image: tiles become PIXW-wide segments of one output-grid row
-        a.rowblock = 1;
-        a.xblocks = (p.QW + PIXW - 1) / PIXW;
-        a.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
-        a.ROWS = p.max_dy + 1;
-    }
-    LAV_REQUIRE((long)a.ROWS * a.Wst <= 256 * NPOS_MAX, "lav_conv2d: input tile %dx%d too large for the staging map", a.ROWS, a.Wst);
-    a.tap_group = p.taps_per_class <= TAP_GROUP ? p.taps_per_class : (c->kw <= TAP_GROUP ? c->kw : TAP_GROUP);
-    auto lds_bytes = [&]() { return (size_t)((((size_t)CK * a.ROWS * a.Wst + 3) & ~(size_t)3) + (size_t)a.tap_group * CK * CO_T) * 4; };
-    LAV_REQUIRE(lds_bytes() <= 160 * 1024, "lav_conv2d: tile needs %zu bytes of LDS", lds_bytes());
+    int MP, MC;
+    size_t lds;
+    rc = choose_tile(*c, p, a, MP, MC, lds);
+    if (rc) return rc;
     for (int i = 0; i < MAX_CLASSES; ++i) {
         const bool live = i < p.nclasses;
         a.cls_ntaps[i] = live ? (int)p.taps[i].size() : 0;
@@ -396,7 +428,6 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         for (size_t t = 0; t < p.taps[cl].size(); ++t) a.toff[cl * p.taps_per_class + t] = p.taps[cl][t].dy * a.Wst + p.taps[cl][t].dx;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = lds_bytes();
     if (MP == 2 && MC == 2) return launch<2, 2>(a, p, c->batch, lds, st);
     if (MP == 1 && MC == 2) return launch<1, 2>(a, p, c->batch, lds, st);
     return launch<1, 1>(a, p, c->batch, lds, st);

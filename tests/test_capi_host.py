@@ -137,3 +137,64 @@ dist.destroy_process_group()
                           "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(REPO, "tests", "_gloo_worker.py")],
                          capture_output=True, text=True, timeout=180)
     assert "MAX_OK" in out.stdout, out.stdout + out.stderr
+
+
+def _conv_shapes_of(model, x_shape):
+    """(conv module, input shape) for every Conv2d / ConvTranspose2d reached by a CPU forward of `model`."""
+    shapes = []
+    hooks = []
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out: shapes.append((mod, tuple(inp[0].shape)))))
+    with torch.no_grad():
+        model(*[torch.zeros(s) for s in x_shape])
+    for h in hooks:
+        h.remove()
+    return shapes
+
+
+def test_every_layer_shape_of_the_frame_has_a_launch_plan():
+    """Host-side plan feasibility (tile shape, staging map, LDS) for every convolution the frame runs,
+    without a GPU: ERFNet on 3x(288x256), brake ResNet on 288x768 and 192x480, BEV stack, ResNet-18 on crops."""
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    lib = _lib.load()
+    seg = RGBSegmentationModel([4, 6, 7, 10]).eval()
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]).eval()
+    todo = _conv_shapes_of(seg, [(3, 3, 288, 256)]) + _conv_shapes_of(bra, [(1, 3, 288, 768), (1, 3, 192, 480)])
+    res = lav_amd.resnet18(num_channels=384)
+    res.train(False)
+    # torch-only walk over the ResNet / BEV modules (their HIP forward needs a GPU): enumerate by hand
+    def walk(convs, x):
+        for conv in convs:
+            todo.append((conv, tuple(x.shape)))
+            with torch.no_grad():
+                x = conv(x)
+        return x
+    bb = lav_amd.ConvBackbone(64)
+    x1 = walk([m for m in bb.conv1 if isinstance(m, torch.nn.Conv2d)], torch.zeros(1, 64, 320, 320))
+    x2 = walk([m for m in bb.conv2 if isinstance(m, torch.nn.Conv2d)], x1)
+    x3 = walk([m for m in bb.conv3 if isinstance(m, torch.nn.Conv2d)], x2)
+    for up, x in ((bb.upconv1[0], x1), (bb.upconv2[0], x2), (bb.upconv3[0], x3)):
+        todo.append((up, tuple(x.shape)))
+    head = lav_amd.Head(384, 3)
+    todo += [(head.net[0], (1, 384, 160, 160)), (head.net[3], (1, 64, 160, 160))]
+    todo.append((torch.nn.Conv2d(384, 256, 3, 1, 1), (1, 384, 160, 160)))           # the fused 4-head convolution
+    for nb in (1, 16):
+        x = walk([res.conv1], torch.zeros(nb, 384, 96, 96))
+        x = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+        for i in range(1, 5):
+            for blk in getattr(res, f"layer{i}"):
+                if blk.downsample is not None:
+                    todo.append((blk.downsample[0], tuple(x.shape)))
+                x = walk([blk.conv1, blk.conv2], x)
+    assert len(todo) > 150
+    info = (C.c_int * 6)()
+    for conv, shp in todo:
+        tr = isinstance(conv, torch.nn.ConvTranspose2d)
+        cin, cout = (conv.in_channels, conv.out_channels)
+        d = Conv(shp[0], cin, 0, cin, shp[2], shp[3], cout, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0],
+                 conv.padding[0], conv.padding[1], conv.dilation[0], conv.dilation[1], int(tr),
+                 conv.output_padding[0] if tr else 0, cout, 0, 0, 0, 0)
+        rc = lib.lav_conv_tile_info(C.byref(d), info)
+        assert rc == 0, f"{conv} on {shp}: {lib.lav_last_error().decode()}"
+        assert info[3] * info[4] <= 256 * 12 and info[5] <= 160 * 1024
