@@ -181,6 +181,29 @@ def main():
                     avg_kernel_us=round(avg_s * 1e6, 2), launches=n_pn)
     per_frame_us = {k: round(v[0] / args.steps * 1e3, 1) for k, v in prof.items()}
 
+    def pillar_micro(n_per_sweep, reps=100):
+        """BASELINE.json config #2 in isolation: back-to-back pillar launches on one synthetic cloud, so the
+        HIP-event figures are pure kernel time (the frame loop above is host-bound between launches)."""
+        from lav_amd import synth
+        pts = torch.from_numpy(synth.stacked_lidar(n_per_sweep)).to(device)
+        ppn = pipe.infer_model.lidar_model.point_pillar_net
+        for _ in range(5):
+            ppn([pts], [len(pts)])
+        torch.cuda.synchronize()
+        lib.lav_profile_enable(reps + 4)
+        for _ in range(reps):
+            ppn([pts], [len(pts)])
+        torch.cuda.synchronize()
+        k_ms, k_n = read("pointnet_scatter")
+        p_ms, p_n = read("pillar_prep")
+        lib.lav_profile_enable(0)
+        nb = 4 * (len(pts) * 11 + 64 * 320 * 320)
+        ks, ps = k_ms / max(k_n, 1) * 1e-3, p_ms / max(p_n, 1) * 1e-3
+        return dict(points=len(pts), algorithmic_bytes=nb, kernel_us=round(ks * 1e6, 2), prep_us=round(ps * 1e6, 2),
+                    achieved=round(nb / ks / 1e9, 1), frac=round(nb / ks / 1e9 / HBM_PEAK_GBS, 4),
+                    pipeline_achieved=round(nb / (ks + ps) / 1e9, 1), unit="GB/s", peak=HBM_PEAK_GBS)
+    micro = {"config2_32768pts": pillar_micro(10923), "agent_196608pts": pillar_micro(65536)} if rank == 0 else None
+
     if rank == 0:
         res = dict(metric="frames/s full agent fwd (32k-pt LiDAR + 3 cams)", value=round(world * args.steps / dt, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -190,7 +213,7 @@ def main():
                                         f"({n_pts} pts x 11) + 3x288x256 RGB + 288x480 tele; ERFNet seg, paint, pillar 320x320x64, "
                                         "BEV backbone+heads, uniplanner (cast+plan GRUs), brake net",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1])),
-                   roofline=roofline, hip_kernel_us_per_frame=per_frame_us)
+                   roofline=roofline, roofline_pillar_isolated=micro, hip_kernel_us_per_frame=per_frame_us)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, host)
         else:

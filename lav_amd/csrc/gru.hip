@@ -213,27 +213,41 @@ __global__ __launch_bounds__(256) void k_plan_step(PlanArgs a, int it, int t) {
     }
 }
 
-// After the T steps of iteration `it`: loc[r][t] = cumsum_t(mlp(h_t)) + prev[r][t].  One wave per state row.
-__global__ __launch_bounds__(64) void k_plan_out(PlanArgs a, int it) {
-    const int r = blockIdx.x, lane = threadIdx.x, H = a.H;
+// After the T steps of iteration `it`: loc[r][t] = cumsum_t(mlp(h_t)) + prev[r][t].  One workgroup per state row:
+// the T dot products run on separate waves, the 20-term cumulative sum on one thread.
+constexpr int OUT_WAVES = 8;
+__global__ __launch_bounds__(64 * OUT_WAVES) void k_plan_out(PlanArgs a, int it) {
+    __shared__ float wp[64][2];  // T <= 64
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, H = a.H;
     int b, ci, c;
     row_decode(a, r, b, ci, c);
-    float run0 = 0.f, run1 = 0.f;
-    float *o = a.out + ((((long)b * a.iters + it) * a.NC + ci) * a.T) * 2;
-    for (int t = 0; t < a.T; ++t) {
+    for (int t = wid; t < a.T; t += OUT_WAVES) {
         const float *h = a.hseq + ((long)t * a.R + r) * H;
         float s0 = 0.f, s1 = 0.f;
         for (int k = lane; k < H; k += 64) {
-            s0 = fmaf(a.mlp_w[k], h[k], s0);
-            s1 = fmaf(a.mlp_w[H + k], h[k], s1);
+            const float hv = h[k];
+            s0 = fmaf(a.mlp_w[k], hv, s0);
+            s1 = fmaf(a.mlp_w[H + k], hv, s1);
         }
-        s0 = wave_sum(s0);
-        s1 = wave_sum(s1);
-        run0 += s0 + a.mlp_b[0];
-        run1 += s1 + a.mlp_b[1];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            s0 += __shfl_xor(s0, d, 64);
+            s1 += __shfl_xor(s1, d, 64);
+        }
         if (lane == 0) {
+            wp[t][0] = s0 + a.mlp_b[0];
+            wp[t][1] = s1 + a.mlp_b[1];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float run0 = 0.f, run1 = 0.f;
+        float *o = a.out + ((((long)b * a.iters + it) * a.NC + ci) * a.T) * 2;
+        for (int t = 0; t < a.T; ++t) {
             const float *prev = it == 0 ? a.cast_locs + (((long)b * a.num_cmds + c) * a.T + t) * 2
                                         : a.out + ((((long)b * a.iters + (it - 1)) * a.NC + ci) * a.T + t) * 2;
+            run0 += wp[t][0];
+            run1 += wp[t][1];
             o[t * 2 + 0] = run0 + prev[0];
             o[t * 2 + 1] = run1 + prev[1];
         }
@@ -267,7 +281,7 @@ extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *ca
                             int T, int iters, int cmd, float pixels_per_meter, float crop_size, const float *w_ih,
                             const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
                             const float *mlp_b, float *out, void *workspace, size_t workspace_bytes, void *stream) {
-    LAV_REQUIRE(B >= 0 && num_cmds > 0 && T > 0 && iters > 0, "lav_gru_plan: bad sizes");
+    LAV_REQUIRE(B >= 0 && num_cmds > 0 && T > 0 && T <= 64 && iters > 0, "lav_gru_plan: bad sizes");
     LAV_REQUIRE(H % 64 == 0 && H <= 64 * PLAN_MAXK && H % PLAN_UNITS == 0, "lav_gru_plan: hidden size %d unsupported", H);
     LAV_REQUIRE(cmd >= -1 && cmd < num_cmds, "lav_gru_plan: cmd %d out of range", cmd);
     if (B == 0) return LAV_OK;
@@ -288,7 +302,7 @@ extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *ca
         for (int t = 0; t < T; ++t) {
             hipLaunchKernelGGL(k_plan_step, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, it, t);
         }
-        hipLaunchKernelGGL(k_plan_out, dim3(a.R), dim3(64), 0, st, a, it);
+        hipLaunchKernelGGL(k_plan_out, dim3(a.R), dim3(64 * OUT_WAVES), 0, st, a, it);
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();

@@ -49,7 +49,8 @@ using namespace lav;
 
 constexpr int C = 64;            // PointNet width (config num_features [64,64])
 constexpr int MAX_BATCH = 64;    // per-call limit on clouds (kernel-argument table)
-constexpr int TILE_MAX_W = 176;  // canvas columns per workgroup tile (LDS tile [64][tile_w|1] floats)
+constexpr int TILE_MAX_W = 80;   // canvas columns per workgroup tile (LDS tile [64][tile_w|1] floats): 4 workgroups per CU
+constexpr int NSUB = 8;          // arrival counters per tile, on different cache lines, to spread the atomic traffic
 constexpr int MAX_LAYERS = 64;   // regular + overflow layers a tile may have (2-4 for square grids)
 constexpr int REC_MAX = 16;      // dwords per point record the workspace is sized for (D <= 15)
 constexpr double FIX_SCALE = 4294967296.0;  // 2^32 fixed-point scale of the per-cell coordinate sums
@@ -99,12 +100,17 @@ __global__ __launch_bounds__(256) void k_tile_count(PillarArgs a, int *__restric
     key[gid] = k;
     if (k >= 0) {
         const int cellk = k - b * a.KX * a.KY;
-        slot[gid] = atomicAdd(&tile_count[tile_of(a, b, cellk / a.KY, cellk % a.KY)], 1);
+        // counters are laid out [sub][tile]; the sub-bucket only decorrelates concurrent arrivals
+        const int sub = (threadIdx.x ^ (threadIdx.x >> 6) ^ blockIdx.x) & (NSUB - 1);
+        const int ntiles = a.batch * a.ny * a.T;
+        slot[gid] = sub | (atomicAdd(&tile_count[sub * ntiles + tile_of(a, b, cellk / a.KY, cellk % a.KY)], 1) << 3);
     }
 }
 
-// exclusive prefix of the tile counters (ntiles is a few hundred to a few thousand): one workgroup
+// exclusive prefix of the arrival counters in (tile, sub) order - a tile's NSUB buckets end up contiguous - read from
+// their [sub][tile] layout; n = ntiles*NSUB is a few thousand: one workgroup
 __global__ __launch_bounds__(1024) void k_tile_scan(const int *__restrict__ count, int n, int *__restrict__ offset) {
+    const int ntiles = n / NSUB;
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const int *__restrict__ coun
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
-        const int v = i < n ? count[i] : 0;
+        const int v = i < n ? count[(i % NSUB) * ntiles + i / NSUB] : 0;
         int inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -148,7 +154,8 @@ __global__ __launch_bounds__(256) void k_tile_place(PillarArgs a, const int *__r
     if (k < 0) return;
     const int b = (int)(gid / a.max_points);
     const int cellk = k - b * a.KX * a.KY;
-    const long j = tile_offset[tile_of(a, b, cellk / a.KY, cellk % a.KY)] + slot[gid];
+    const int sl = slot[gid];
+    const long j = tile_offset[tile_of(a, b, cellk / a.KY, cellk % a.KY) * NSUB + (sl & (NSUB - 1))] + (sl >> 3);
     const float *pt = a.points + gid * D;
     float v[RS];
 #pragma unroll
@@ -193,7 +200,7 @@ __device__ __forceinline__ void decorate(const PillarArgs &a, const float *pt, c
 
 // ---------------------------------------------------------------------------------------------------------
 template <int D, bool USE_MFMA>
-__global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const float *__restrict__ rec,
+__global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const float *__restrict__ rec,
                                                           const int *__restrict__ tile_offset,
                                                           const float *__restrict__ w1, const float *__restrict__ b1,
                                                           const float *__restrict__ w2, const float *__restrict__ b2,
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const fl
     const int c1 = min(a.nx, c0 + TW);
     const int tw = c1 - c0;  // live columns in this tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int p0 = tile_offset[wg], p1 = tile_offset[wg + 1];
+    const int p0 = tile_offset[wg * NSUB], p1 = tile_offset[(wg + 1) * NSUB];
     float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
     const long cstride = (long)a.ny * a.nx;
 
@@ -226,10 +233,44 @@ __global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const fl
             for (int j = lane; j < tw; j += 64) dst[ch * cstride + j] = 0.f;
         return;
     }
+    // Issue every global load that depends only on (p0, p1) before touching LDS, so the workgroup pays ONE memory
+    // round trip here instead of one per phase: layer-2 weights, layer-1 weights, this thread's record for the
+    // sums sweep and this lane's record for the wave's first PointNet pass.
+    constexpr int W2R = C * C / 256;
+    float w2r[W2R];
+    if (USE_MFMA) {
+#pragma unroll
+        for (int i = 0; i < W2R; ++i) w2r[i] = w2[tid + 256 * i];
+    }
+    float a1[2][KS1];  // layer-1 A operand: W1[2s+half][32*mt + l31], bias as k = K1
+    float b2v[2];
+    const int npass = (p1 - p0 + 31) >> 5;
+    if (USE_MFMA && wid < npass) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const int k = 2 * s + half;
+                const int c = 32 * mt + l31;
+                a1[mt][s] = k < K1 ? w1[k * C + c] : (k == K1 ? b1[c] : 0.f);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b2v[nt] = b2[32 * nt + l31];
+    }
+    float srec[4];  // x, y, z, key of record p0 + tid (first chunk of the sums sweep)
+    {
+        const float *rp = rec + (long)min(p0 + tid, p1 - 1) * (D + 1);
+        srec[0] = rp[0]; srec[1] = rp[1]; srec[2] = rp[2]; srec[3] = rp[D];
+    }
+    float prec[D + 1];  // record of this lane for the wave's first pass
+    if (USE_MFMA) load_record<D>(rec, min(p0 + wid * 32 + l31, p1 - 1), prec);
+
     for (int i = tid; i < C * TWP; i += 256) tile[i] = 0.f;
     if (tid < MAX_LAYERS) nl[tid] = 0;
-    if (USE_MFMA)
-        for (int i = tid; i < C * C; i += 256) w2s[i] = w2[i];
+    if (USE_MFMA) {
+#pragma unroll
+        for (int i = 0; i < W2R; ++i) w2s[tid + 256 * i] = w2r[i];
+    }
 
     // key rows that land on canvas row r, and overflow columns of the last tile (reference clamp, :89)
     const int xi_lo = r > 0 ? a.ny - 1 - r : max(a.ny - 1, 0);
@@ -248,38 +289,30 @@ __global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const fl
         col = min(yi, a.nx - 1) - c0;
     };
 
-    float a1[2][KS1];  // layer-1 A operand: W1[2s+half][32*mt + l31], bias as k = K1
-    float b2v[2];
-    const int npass = (p1 - p0 + 31) >> 5;
-    if (USE_MFMA && wid < npass) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) {
-                const int k = 2 * s + half;
-                const int c = 32 * mt + l31;
-                a1[mt][s] = k < K1 ? w1[k * C + c] : (k == K1 ? b1[c] : 0.f);
-            }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b2v[nt] = b2[32 * nt + l31];
-    }
-
     for (int L = 0; L < min(nlayers, MAX_LAYERS); ++L) {
         if (L > 0 && nl[L] == 0) continue;  // workgroup-uniform; nl[] is complete after layer 0's first barrier pair
         __syncthreads();
         for (int j = tid; j < TW * 3; j += 256) sums[j] = 0ull;
         for (int j = tid; j < TW; j += 256) cnt[j] = 0;
         __syncthreads();
-        // (a) per-cell coordinate sums and counts of this layer
+        // (a) per-cell coordinate sums and counts of this layer (first 256 records were prefetched)
         for (int j = p0 + tid; j < p1; j += 256) {
-            const float *rp = rec + (long)j * (D + 1);
+            float x, y, z;
+            int k;
+            if (j == p0 + tid) {
+                x = srec[0]; y = srec[1]; z = srec[2]; k = __float_as_int(srec[3]);
+            } else {
+                const float *rp = rec + (long)j * (D + 1);
+                x = rp[0]; y = rp[1]; z = rp[2]; k = __float_as_int(rp[D]);
+            }
             int layer, col, xi, yi;
-            classify(__float_as_int(rp[D]), layer, col, xi, yi);
-            if (L == 0) atomicAdd(&nl[min(layer, MAX_LAYERS - 1)], 1);
+            classify(k, layer, col, xi, yi);
+            if (L == 0 && layer != 0) atomicAdd(&nl[min(layer, MAX_LAYERS - 1)], 1);
             if (layer == L) {
+                const float xyz[3] = {x, y, z};
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
-                    const long long q = __double2ll_rn((double)rp[d] * FIX_SCALE);
+                    const long long q = __double2ll_rn((double)xyz[d] * FIX_SCALE);
                     atomicAdd(&sums[col * 3 + d], (unsigned long long)q);
                 }
                 atomicAdd(&cnt[col], 1);
@@ -333,7 +366,12 @@ __global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const fl
                 const int j = p0 + pass * 32 + l31;
                 bool live = j < p1;
                 float v[D + 1];
-                load_record<D>(rec, live ? j : p0, v);
+                if (pass == wid) {
+#pragma unroll
+                    for (int d = 0; d <= D; ++d) v[d] = prec[d];
+                } else {
+                    load_record<D>(rec, live ? j : p0, v);
+                }
                 int layer, col, xi, yi;
                 classify(__float_as_int(v[D]), layer, col, xi, yi);
                 live = live && layer == L;
@@ -388,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_pointnet(PillarArgs a, const fl
     }
     __syncthreads();
     // (d) stream the tile out; canvas [B][C][ny][nx]
+#pragma unroll 4
     for (int ch = wid; ch < C; ch += 4) {
         const float *src = tile + ch * TWP;
         float *d = dst + ch * cstride;
@@ -542,8 +581,8 @@ size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid 
     const size_t ncells = (size_t)batch * (g->nx + 1) * (g->ny + 1);
     const size_t total = (size_t)batch * max_points;
     const size_t nmax = ncells > total ? ncells : total;
-    w.tile_count = ar.take<int>(ntiles + 1);
-    w.tile_offset = ar.take<int>(ntiles + 1);
+    w.tile_count = ar.take<int>(ntiles * NSUB + 1);
+    w.tile_offset = ar.take<int>(ntiles * NSUB + 1);
     w.key = ar.take<int>(total);
     w.slot = ar.take<int>(total);
     w.rec = ar.take<float>(total * REC_MAX);
@@ -565,12 +604,12 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     const long total = (long)a.batch * a.max_points;
     const int ntiles = a.batch * a.ny * a.T;
     const int tok_prep = timer_begin("pillar_prep", st);
-    LAV_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)(ntiles + 1) * sizeof(int), st));
+    LAV_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)(ntiles * NSUB + 1) * sizeof(int), st));
     if (total > 0) {
         hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_count);
         LAV_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.tile_count, ntiles, w.tile_offset);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, w.tile_count, ntiles * NSUB, w.tile_offset);
     LAV_LAUNCH_CHECK();
     if (total > 0) {
         hipLaunchKernelGGL((k_tile_place<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_offset, w.rec);
