@@ -45,6 +45,8 @@ int lav_device_count(void);
  * event pair; lav_profile_enable(0) disarms.  lav_profile_read synchronises those events and returns
  * the summed duration and the launch count.  Not part of the reference's surface. */
 int lav_profile_enable(int slots);
+/* forget recorded launches but keep the (already created) events: call after a warm-up, before the timed region */
+int lav_profile_reset(void);
 int lav_profile_read(const char *kernel, double *total_ms, int *launches);
 
 /* ------------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ SIGNATURES = {
     "lav_last_error": (C.c_char_p, []),
     "lav_device_count": (_I, []),
     "lav_profile_enable": (_I, [_I]),
+    "lav_profile_reset": (_I, []),
     "lav_profile_read": (_I, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I)]),
     "lav_pillar_workspace_bytes": (_Z, [_I, _I, C.POINTER(Grid)]),
     "lav_pillar_scatter": (_I, [_P, C.POINTER(_I), _I, _I, _I, C.POINTER(Grid), C.POINTER(PointNet), _P, _P, _P, _P,

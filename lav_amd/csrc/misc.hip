@@ -77,6 +77,12 @@ extern "C" int lav_profile_enable(int slots) {
     return LAV_OK;
 }
 
+extern "C" int lav_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &t : g_timers) t.launches = 0;
+    return LAV_OK;
+}
+
 extern "C" int lav_profile_read(const char *kernel, double *total_ms, int *launches) {
     LAV_REQUIRE(kernel && total_ms && launches, "lav_profile_read: null");
     std::lock_guard<std::mutex> lk(g_mu);

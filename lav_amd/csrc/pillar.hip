@@ -107,40 +107,44 @@ __global__ __launch_bounds__(256) void k_tile_count(PillarArgs a, int *__restric
     }
 }
 
-// exclusive prefix of the arrival counters in (tile, sub) order - a tile's NSUB buckets end up contiguous - read from
-// their [sub][tile] layout; n = ntiles*NSUB is a few thousand: one workgroup
+// Exclusive prefix of the arrival counters in (tile, sub) order - a tile's NSUB buckets end up contiguous - read from
+// their [sub][tile] layout, and re-zeroing of nothing: n = ntiles*NSUB is a few thousand, so one workgroup does it with
+// a serial run of ceil(n/1024) items per thread and a single 1024-wide block scan.
 __global__ __launch_bounds__(1024) void k_tile_scan(const int *__restrict__ count, int n, int *__restrict__ offset) {
-    const int ntiles = n / NSUB;
     __shared__ int wsum[16];
-    __shared__ int carry_s;
+    const int ntiles = n / NSUB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = i < n ? count[(i % NSUB) * ntiles + i / NSUB] : 0;
-        int inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if (lane == 63) wsum[wid] = inc;
-        __syncthreads();
-        int wbase = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int s = wsum[w];
-            if (w < wid) wbase += s;
-            tot += s;
-        }
-        const int carry = carry_s;
-        if (i < n) offset[i] = carry + wbase + inc - v;
-        __syncthreads();
-        if (tid == 0) carry_s = carry + tot;
-        __syncthreads();
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per;
+    int sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int i = i0 + j;
+        if (i < n) sum += count[(i % NSUB) * ntiles + i / NSUB];
     }
-    if (tid == 0) offset[n] = carry_s;
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int run = inc - sum;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+        if (w < wid) run += wsum[w];
+    for (int j = 0; j < per; ++j) {
+        const int i = i0 + j;
+        if (i < n) {
+            offset[i] = run;
+            run += count[(i % NSUB) * ntiles + i / NSUB];
+        }
+    }
+    if (i0 < n && i0 + per >= n) offset[n] = run;  // the thread owning the last item writes the grand total
+}
+
+__global__ __launch_bounds__(256) void k_zero_ints(int *__restrict__ p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0;
 }
 
 template <int D>
@@ -604,7 +608,8 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     const long total = (long)a.batch * a.max_points;
     const int ntiles = a.batch * a.ny * a.T;
     const int tok_prep = timer_begin("pillar_prep", st);
-    LAV_HIP(hipMemsetAsync(w.tile_count, 0, (size_t)(ntiles * NSUB + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(k_zero_ints, dim3((ntiles * NSUB + 255) / 256), dim3(256), 0, st, w.tile_count, ntiles * NSUB + 1);
+    LAV_LAUNCH_CHECK();
     if (total > 0) {
         hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_count);
         LAV_LAUNCH_CHECK();

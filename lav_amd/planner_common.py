@@ -27,7 +27,9 @@ def crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, offs
     uniplanner.py:310-352): theta = k*R(ori) with the (offset_x, offset_y) pivot, bilinear, zeros outside,
     align_corners=True.  torch's affine_grid/grid_sample for now (row a15 of SURVEY 8a, 'next' kernel)."""
     B, C, H, W = features.shape
-    rel_locs = rel_locs.view(-1, 2) * pixels_per_meter / torch.tensor([H / 2, W / 2], dtype=rel_locs.dtype, device=rel_locs.device)
+    rel_locs = rel_locs.view(-1, 2) * pixels_per_meter
+    # same arithmetic as `* ppm / tensor([H/2, W/2])` without creating a tensor from host data (HIP-graph capturable)
+    rel_locs = torch.stack([rel_locs[:, 0] / (H / 2), rel_locs[:, 1] / (W / 2)], dim=-1)
     cos, sin = torch.cos(rel_oris), torch.sin(rel_oris)
     k = crop_size / H
     rot_x = -k * offset_x * cos + k * offset_y * sin + offset_x

@@ -48,6 +48,17 @@ class SegmentationHead(nn.Module):
         return self.upconv(x)
 
 
+_PE_CACHE = {}
+
+
+def _pe_on(device, d_model, length):
+    """Positional encoding resident on `device` (built once: no host->device copy per frame, graph capturable)."""
+    key = (str(device), d_model, length)
+    if key not in _PE_CACHE:
+        _PE_CACHE[key] = positionalencoding1d(d_model, length).to(device)
+    return _PE_CACHE[key]
+
+
 def positionalencoding1d(d_model, length):
     pe = torch.zeros(length, d_model)
     pos = torch.arange(0, length).unsqueeze(1).float()
@@ -73,7 +84,7 @@ class Attention(nn.Module):
         k, v = self.linear_kv(tok).chunk(2, dim=-1)
         k = k.view(b, h * w, self.num_heads, self.dim_head).transpose(1, 2)       # b heads n dh
         v = v.view(b, h * w, self.num_heads, self.dim_head).transpose(1, 2)
-        k = k + positionalencoding1d(self.dim_head, h * w).to(k.device)
+        k = k + _pe_on(k.device, self.dim_head, h * w)
         attn = torch.softmax(torch.matmul(self.q.expand(b, -1, -1, -1), k.transpose(-1, -2)) * self.scale, dim=-1)
         return torch.matmul(attn, v).transpose(1, 2).reshape(b, d)
 

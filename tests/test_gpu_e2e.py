@@ -107,3 +107,35 @@ def test_camera_nets_vs_reference_golden_and_torch_cpu(golden):
         gpu_trunk = bra.conv_backbone(bra.normalize(wide.to(DEV) / 255.))
         assert_close(gpu_trunk.cpu().numpy(), cpu_trunk.numpy(), atol=1e-3, rtol=1e-4, what="brake ResNet-18 trunk")
         assert_close(bra(wide.to(DEV), tel_rgb.to(DEV)).cpu().numpy(), cpu_bra.numpy(), atol=1e-5, what="pred_bra")
+
+
+def test_graphed_frame_pipeline_matches_eager(models):
+    """HIP-graph replay of the frame (static buffers, NaN padding, ring history) == the eager FramePipeline
+    over 18 frames (history fill, ring wrap-around, varying poses, two command values)."""
+    from lav_amd.frame import FramePipeline, GraphedFramePipeline
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    lm, up = models
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval().to(DEV)
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]); bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra.")); bra.eval().to(DEV)
+    eager = FramePipeline(lm, up, seg, bra, 1.5, 2.4, device=DEV)
+    graph = GraphedFramePipeline(lm, up, seg, bra, 1.5, 2.4, device=DEV, points_per_tick=8192)
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]
+    all_rgb = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float().to(DEV)
+    wide = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float().to(DEV)
+    tel_rgb = torch.tensor(tel[..., :3][..., ::-1][:-96][None].copy()).permute(0, 3, 1, 2).float().to(DEV)
+    nxp = torch.tensor([1.0, -9.0], device=DEV)
+    for i in range(19):
+        n = 8192 if i % 3 else 7000                       # ticks shorter than the static buffer are NaN padded
+        tick = torch.from_numpy(synth.lidar_sweep(n, name=f"g{i}")).to(DEV)
+        loc, ori = np.array([0.3 * i, 0.05 * i]), 0.02 * i
+        cmd = 3 if i < 12 else 1
+        a = eager.step(tick, all_rgb, wide, tel_rgb, loc, ori, nxp, cmd)
+        b = graph.step(tick, all_rgb, wide, tel_rgb, loc, ori, nxp, cmd)
+        if a is None:
+            assert b is None
+            continue
+        assert a["det"][0] == b["det"][0] and [d[:2] for d in a["det"][1]] == [d[:2] for d in b["det"][1]], f"frame {i}"
+        for k in ("ego_plan_locs", "ego_cast_locs", "other_cast_locs", "other_cast_cmds", "pred_bra"):
+            assert_close(b[k].cpu().numpy(), a[k].cpu().numpy(), atol=2e-5, what=f"frame {i} {k}")
+        assert_close(b["pred_bev"].cpu().numpy(), a["pred_bev"].cpu().numpy(), atol=1e-5, what=f"frame {i} pred_bev")
