@@ -37,12 +37,21 @@ class BEVPlanner(DecoderMixin, _Engine):
     def _drop(self):
         super()._drop()
         self._drop_dec()
+        object.__setattr__(self, "_offsets", None)
+
+    def offsets(self):
+        """(offset_x, offset_y) as host floats, read from the parameters once (no device->host sync per frame;
+        keeps the forward HIP-graph capturable)."""
+        if getattr(self, "_offsets", None) is None:
+            object.__setattr__(self, "_offsets", (float(self.offset_x), float(self.offset_y)))
+        return self._offsets
 
     def _cast_modules(self):
         return self.cast_grus, self.cast_mlps
 
     def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
-        return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, float(self.offset_x), float(self.offset_y))
+        ox, oy = self.offsets()
+        return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
 
     @torch.no_grad()
     def infer(self, bev, nxps):

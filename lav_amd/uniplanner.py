@@ -42,18 +42,28 @@ class UniPlanner(DecoderMixin, _Engine):
     def _drop(self):
         super()._drop()
         self._drop_dec()
+        object.__setattr__(self, "_offsets", None)
+
+    def offsets(self):
+        """(offset_x, offset_y) as host floats, read from the parameters once (no device->host sync per frame;
+        keeps the forward HIP-graph capturable)."""
+        if getattr(self, "_offsets", None) is None:
+            object.__setattr__(self, "_offsets", (float(self.offset_x), float(self.offset_y)))
+        return self._offsets
 
     def _cast_modules(self):
         return self.cast_grus_ego, self.cast_mlps_ego
 
     def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
-        return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, float(self.offset_x), float(self.offset_y))
+        ox, oy = self.offsets()
+        return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
 
     def others_from_detections(self, det, H, W):
         """Pixel detections -> ego-frame metres and headings, skipping the ego's own box
         (uniplanner.py:194-212 / model_inference.py:125-144)."""
-        cx = float(W / 2 + float(self.offset_x) * W / 2)
-        cy = float(H / 2 + float(self.offset_y) * H / 2)
+        ox, oy = self.offsets()
+        cx = float(W / 2 + ox * W / 2)
+        cy = float(H / 2 + oy * H / 2)
         locs, oris = [], []
         for X, Y, h, w, cos, sin in det:
             if np.linalg.norm([X - cx, Y - cy]) <= 4:
