@@ -201,11 +201,11 @@ class GraphedFramePipeline(FramePipeline):
         return dict(other_cast_locs=cast, other_cast_cmds=cmds)
 
     def _capture(self, fn, *args):
+        # every graph gets a PRIVATE memory pool: graphs that share one may only be replayed in capture order, and
+        # here a later-captured frame graph (new command value) runs before earlier-captured others-graphs
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        with torch.cuda.graph(g):
             out = fn(*args)
-        if self.pool is None:
-            self.pool = g.pool()
         return g, out
 
     def _set_pose_buffers(self):
