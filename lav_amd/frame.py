@@ -137,6 +137,7 @@ class GraphedFramePipeline(FramePipeline):
         for i in range(num_sweeps):
             onehot[i, :, i] = 1
         self.b_onehot = onehot
+        self.b_features = None   # (1,384,160,160): shared by every frame graph, read by the others-graphs
         self.b_locs = torch.zeros((15, 2), **f)
         self.b_oris = torch.zeros((15,), **f)
         self.graphs_a, self.graphs_b, self.out_a, self.out_b = {}, {}, {}, {}
@@ -165,7 +166,11 @@ class GraphedFramePipeline(FramePipeline):
         xyz = torch.baddbmm(self.b_t, sw[..., :3], self.b_R)                            # xyz @ R + t  (move_lidar_points)
         lidar_points = torch.cat([xyz, sw[..., 3:], self.b_onehot], dim=-1).view(-1, 11)
         lm = im.lidar_model
-        features = lm.backbone(lm.point_pillar_net([lidar_points], [lidar_points.shape[0]]))
+        canvas = lm.point_pillar_net([lidar_points], [lidar_points.shape[0]])
+        if self.b_features is None:
+            self.b_features = torch.empty((1, lm.backbone.out_channels, canvas.shape[2] // 2, canvas.shape[3] // 2),
+                                          dtype=torch.float32, device=canvas.device)
+        features = lm.backbone(canvas, out=self.b_features)
         heat, size, ori, pred_bev = lm.heads(features)
         hm = torch.sigmoid(heat[0])
         rows = []
@@ -190,7 +195,7 @@ class GraphedFramePipeline(FramePipeline):
 
     def _part_b(self, n):
         up = self.infer_model.uniplanner
-        feats = self.out_features
+        feats = self.b_features
         locs, oris = self.b_locs[:n], self.b_oris[:n]
         crops = up.crop_feature(feats.expand(n, -1, -1, -1), locs, oris, up.pixels_per_meter / 2, up.crop_size)
         embd = up.lidar_conv_emb(crops)
@@ -269,7 +274,6 @@ class GraphedFramePipeline(FramePipeline):
         if N > 0:
             self.b_locs[:N].copy_(torch.tensor(locs[:N], dtype=torch.float32), non_blocking=True)
             self.b_oris[:N].copy_(torch.tensor(oris[:N], dtype=torch.float32), non_blocking=True)
-            self.out_features = oa["features"]
             if N not in self.graphs_b:
                 self._part_b(N)
                 torch.cuda.synchronize()

@@ -93,7 +93,8 @@ class ConvBackbone(_Engine):
         object.__setattr__(self, "_eng", eng)
         return eng
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """`out`: optional preallocated (B, 6*num_feature, H/2, W/2) buffer the three up-convolutions write into."""
         self._need_eval()
         e = self._engine(x.device)
         feats = []
@@ -102,7 +103,8 @@ class ConvBackbone(_Engine):
                 x = layer(x)
             feats.append(x)
         oh, ow = e["ups"][0].out_hw(feats[0].shape[2], feats[0].shape[3])
-        out = torch.empty((x.shape[0], self.out_channels, oh, ow), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((x.shape[0], self.out_channels, oh, ow), dtype=torch.float32, device=x.device)
         for up, f in zip(e["ups"], feats):
             up(f, out=out)
         return out
