@@ -34,13 +34,13 @@ constexpr int TAP_GROUP = 9;  // taps per weight stage (a 7x7 kernel is staged o
 constexpr int NPOS_MAX = 12;  // staged input positions per thread: ROWS*Wst <= 256*NPOS_MAX
 
 struct ConvArgs {
-    const float *x, *w, *bias, *scale, *shift, *res;
+    const float *x, *w, *bias, *scale, *shift, *res, *zero_page;
     float *y;
     int in_c_total, in_c_offset, cin, H, W;
     int cout, out_c_total, out_c_offset, OH, OW;
     int cin_pad, cout_pad;  // packed-weight strides (multiples of CK / 64), zero filled
     int QH, QW, in_s, out_s;
-    int Wst, ROWS, nclasses, taps_per_class, tap_group;
+    int Wst, ROWS, plane_pad, nclasses, taps_per_class, tap_group;
     int rowblock, xblocks;  // 1: tiles are PIXW-wide segments of ONE output-grid row (wide images); 0: linearised pixels
     int relu_pre, relu_post, sigmoid;
     int cls_ntaps[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES];
@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int cls = blockIdx.z % a.nclasses, n = blockIdx.z / a.nclasses;
     const int cb = blockIdx.y * CO_T;
     const int Q = a.QH * a.QW;
-    const int Wst = a.Wst, ROWS = a.ROWS, plane = ROWS * Wst;
-    float *s_in = smem;                                // [CK][ROWS][Wst]
-    float *s_w = smem + ((CK * plane + 3) & ~3);       // [tap_group][CK][CO_T]
+    const int Wst = a.Wst, ROWS = a.ROWS, plane = a.plane_pad;  // channel stride in LDS (ROWS*Wst rounded up to 64)
+    const int in_floats = CK * plane, w_floats = a.tap_group * CK * CO_T;
+    float *s_in0 = smem;                               // [2][CK][plane]   double-buffered input tile
+    float *s_w0 = smem + 2 * in_floats;                // [2][tap_group][CK][CO_T]   double-buffered weight slab
     const int ntaps = a.cls_ntaps[cls];
     // tile origin: first output-grid row, first staged input column (relative to in_ox)
     const int xb = a.rowblock ? (int)(blockIdx.x % a.xblocks) : 0;
@@ -129,9 +130,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         const int p = tid + 256 * i;
         const int rr = p / Wst, xx = p - rr * Wst;
         const int iy = iy_base + rr, ix = in_ox + xx;
-        goff[i] = (p < plane && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+        goff[i] = (p < ROWS * Wst && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
     }
-    const int npos = (plane + 255) >> 8;
 
     f32x16 acc[MC][MP];
 #pragma unroll
@@ -143,72 +143,110 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 
     const float *xin = a.x + ((long)n * a.in_c_total + a.in_c_offset) * a.H * a.W;
     const long cplane = (long)a.H * a.W;
-    for (int ci0 = 0; ci0 < a.cin; ci0 += CK) {
-        __syncthreads();  // everyone is done reading the previous input tile
-        // all loads unconditional (clamped address) and selected afterwards: a conditional load makes hipcc
-        // branch around every element and drain vmcnt(0) each time
+    const int ngroups = (ntaps + a.tap_group - 1) / a.tap_group;
+    const int nchunks = (a.cin + CK - 1) / CK;
+    const int nstages = nchunks * ngroups;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+
+    // Asynchronous global -> LDS DMA (global_load_lds): data never passes through VGPRs, so the loads of stage
+    // s+1 are in flight while stage s runs on the matrix pipes.  The LDS destination of one wave-instruction is
+    // wave-uniform base + lane*size, which is exactly how both tiles are laid out (positions / float4s in thread
+    // order).  Padding and out-of-image positions read a zero page.
+    const long zoff = a.zero_page - xin;  // flat address space: the zero page as an element offset from xin
+    auto issue = [&](int stage) {
+        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        const int ci0 = chunk * CK;
+        if (grp == 0) {
+            float *dst = s_in0 + (chunk & 1) * in_floats + wid * 64;
 #pragma unroll
-        for (int i = 0; i < NPOS_MAX; ++i) {
-            if (i < npos) {  // workgroup-uniform
-                const int p = tid + 256 * i;
-                const int g = goff[i];
-                const float *src = xin + (g < 0 ? 0 : g);
-                float v[CK];
+            for (int i = 0; i < NPOS_MAX; ++i) {
+                if (256 * i + 64 * wid < plane) {  // wave-uniform: this wave's 64 positions lie inside the padded plane
+                    const int g = goff[i];
 #pragma unroll
-                for (int c = 0; c < CK; ++c) v[c] = src[min(ci0 + c, a.cin - 1) * cplane];
-                if (p < plane) {
-#pragma unroll
-                    for (int c = 0; c < CK; ++c) s_in[c * plane + p] = (g >= 0 && ci0 + c < a.cin) ? v[c] : 0.f;
+                    for (int c = 0; c < CK; ++c) {
+                        // integer select (v_cndmask), not a branch around the load: element offset of the point's
+                        // pixel inside channel ci0+c, or of the zero page, both relative to xin
+                        const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
+                        const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
+                        __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + 256 * i), 4, 0, 0);
+                    }
                 }
             }
         }
-        for (int t0 = 0; t0 < ntaps; t0 += a.tap_group) {
-            const int nt = min(a.tap_group, ntaps - t0);
-            if (t0 > 0) __syncthreads();  // previous weight slab fully consumed
-            // weight slab: rows (tap, c) of CO_T floats, contiguous in the packed layout -> float4 copy
-            constexpr int V = CO_T / 4;
-            for (int f = tid; f < nt * CK * V; f += 256) {
-                const int row = f / V, c4 = f - row * V;
-                const int tap = row / CK, c = row - tap * CK;
-                const float4 w4 = *reinterpret_cast<const float4 *>(wbase + ((long)(t0 + tap) * a.cin_pad + ci0 + c) * a.cout_pad + cb + 4 * c4);
-                *reinterpret_cast<float4 *>(s_w + row * CO_T + 4 * c4) = w4;
-            }
-            __syncthreads();
-            // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
-            TapOps<MP, MC> o0, o1;
-            load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, l31, half);
-            int t = 0;
-            for (; t + 1 < nt; t += 2) {
-                load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, l31, half);
-                mma_tap<MP, MC>(o0, acc);
-                if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, l31, half);
-                mma_tap<MP, MC>(o1, acc);
-            }
-            if (t < nt) mma_tap<MP, MC>(o0, acc);
+        const int t0 = grp * a.tap_group;
+        const int nt = min(a.tap_group, ntaps - t0);
+        constexpr int V = CO_T / 4;
+        float *wdst = s_w0 + (stage & 1) * w_floats;
+        for (int f0 = 64 * wid; f0 < nt * CK * V; f0 += 256) {  // wave-uniform bounds (CK*V is a multiple of 64)
+            const int f = f0 + lane;
+            const int row = f / V, c4 = f - row * V;
+            const int tap = row / CK, c = row - tap * CK;
+            const float *src = wbase + ((long)(t0 + tap) * a.cin_pad + ci0 + c) * a.cout_pad + cb + 4 * c4;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + 4 * f0), 16, 0, 0);
         }
+    };
+
+    issue(0);
+    for (int stage = 0; stage < nstages; ++stage) {
+        // stage's DMA has landed for every wave, and every wave is done computing stage-1 (whose buffers stage+1 reuses)
+        __syncthreads();  // hipcc drains vmcnt(0) ahead of the barrier because LDS-DMA is in flight
+        if (stage + 1 < nstages) issue(stage + 1);
+        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        const int t0 = grp * a.tap_group;
+        const int nt = min(a.tap_group, ntaps - t0);
+        const float *s_in = s_in0 + (chunk & 1) * in_floats;
+        const float *s_w = s_w0 + (stage & 1) * w_floats;
+        // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
+        TapOps<MP, MC> o0, o1;
+        load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, l31, half);
+        int t = 0;
+        for (; t + 1 < nt; t += 2) {
+            load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, l31, half);
+            mma_tap<MP, MC>(o0, acc);
+            if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, l31, half);
+            mma_tap<MP, MC>(o1, acc);
+        }
+        if (t < nt) mma_tap<MP, MC>(o0, acc);
     }
 
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
+    const bool has_bias = a.bias != nullptr, has_aff = a.scale != nullptr, has_res = a.res != nullptr;
 #pragma unroll
-    for (int mp = 0; mp < MP; ++mp) {
-        if (!pvalid[mp]) continue;
-        const int oy = pqy[mp] * a.out_s + out_oy, ox = pqx[mp] * a.out_s + out_ox;
-        if (oy < 0 || oy >= a.OH || ox < 0 || ox >= a.OW) continue;
+    for (int mc = 0; mc < MC; ++mc) {
+        // per-channel epilogue vectors of this lane's 16 output channels, loaded once
+        float bv[16], sv[16], tv[16];
+        int cov[16];
 #pragma unroll
-        for (int mc = 0; mc < MC; ++mc) {
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb + mc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            cov[r] = co;
+            const int cc = min(co, a.cout - 1);
+            bv[r] = has_bias ? a.bias[cc] : 0.f;
+            sv[r] = has_aff ? a.scale[cc] : 1.f;
+            tv[r] = has_aff ? a.shift[cc] : 0.f;
+        }
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp) {
+            const int oy = pqy[mp] * a.out_s + out_oy, ox = pqx[mp] * a.out_s + out_ox;
+            const bool pix_ok = pvalid[mp] && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+            const long pix = (long)oy * a.OW + ox;
+            const long cbase = ((long)n * a.out_c_total + a.out_c_offset) * a.OH * a.OW;
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cb + mc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co >= a.cout) continue;
-                float v = acc[mc][mp][r];
-                if (a.bias) v += a.bias[co];
+                const long idx = cbase + (long)min(cov[r], a.cout - 1) * a.OH * a.OW + (pix_ok ? pix : 0);
+                rv[r] = has_res ? a.res[idx] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mc][mp][r] + bv[r];
                 if (a.relu_pre) v = v > 0.f ? v : 0.f;
-                if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
-                const long idx = (((long)n * a.out_c_total + a.out_c_offset + co) * a.OH + oy) * a.OW + ox;
-                if (a.res) v += a.res[idx];
+                v = fmaf(v, sv[r], tv[r]);
+                v += rv[r];
                 if (a.relu_post) v = v > 0.f ? v : 0.f;
                 if (a.sigmoid) v = 1.f / (1.f + expf(-v));
-                a.y[idx] = v;
+                if (pix_ok && cov[r] < a.cout) a.y[cbase + (long)cov[r] * a.OH * a.OW + pix] = v;
             }
         }
     }
@@ -286,9 +324,8 @@ int build_plan(const lav_conv &c, Plan &p) {
 // a linearised tile do not fit the staging map / LDS.
 int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds) {
     a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
-    a.tap_group = p.taps_per_class <= TAP_GROUP ? p.taps_per_class : (c.kw <= TAP_GROUP ? c.kw : TAP_GROUP);
     const long Q = (long)p.QH * p.QW;
-    struct Geo { int rowblock, xblocks, Wst, ROWS; size_t lds; long nwg; bool ok; };
+    struct Geo { int rowblock, xblocks, Wst, ROWS, plane_pad, tap_group; size_t lds; long nwg; bool ok; };
     auto geo = [&](int mp, int mc) {
         Geo g;
         const int PIXW = 128 * mp, CO_T = 32 * mc;
@@ -296,15 +333,28 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
         const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
         g.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
-        auto bytes = [&]() { return (size_t)((((size_t)CK * g.ROWS * g.Wst + 3) & ~(size_t)3) + (size_t)a.tap_group * CK * CO_T) * 4; };
-        if ((long)g.ROWS * g.Wst > 256 * NPOS_MAX || bytes() > 150 * 1024) {
+        // both tiles are double buffered in LDS; the weight slab holds `tap_group` taps (all of them when they fit,
+        // else one kernel row, else a single tap)
+        auto pad = [&]() { return ((long)g.ROWS * g.Wst + 63) / 64 * 64; };
+        auto bytes_with = [&](int tg) { return (size_t)(2 * ((size_t)CK * pad() + (size_t)tg * CK * CO_T)) * 4; };
+        auto pick_group = [&]() {
+            const int opts[3] = {p.taps_per_class, p.nclasses == 1 ? c.kw : 1, 1};
+            for (int tg : opts)
+                if (tg >= 1 && tg <= TAP_GROUP && bytes_with(tg) <= 150 * 1024) return tg;
+            return 1;
+        };
+        auto bytes = [&]() { return bytes_with(g.tap_group); };
+        g.tap_group = pick_group();
+        if ((long)pad() > 256 * NPOS_MAX || bytes() > 150 * 1024) {
             g.rowblock = 1;
             g.xblocks = (p.QW + PIXW - 1) / PIXW;
             g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
             g.ROWS = p.max_dy + 1;
+            g.tap_group = pick_group();
         }
+        g.plane_pad = (int)pad();
         g.lds = bytes();
-        g.ok = (long)g.ROWS * g.Wst <= 256 * NPOS_MAX && g.lds <= 160 * 1024;
+        g.ok = (long)g.plane_pad <= 256 * NPOS_MAX && g.lds <= 160 * 1024;
         const long xt = g.rowblock ? (long)p.QH * g.xblocks : (Q + PIXW - 1) / PIXW;
         g.nwg = xt * ((c.cout + CO_T - 1) / CO_T) * c.batch * p.nclasses;
         return g;
@@ -322,6 +372,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     }
     LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
     a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
+    a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group;
     lds = bg.lds;
     return LAV_OK;
 }
@@ -337,6 +388,14 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     size_t lds;
     rc = choose_tile(*c, p, a, MP, MC, lds);
     if (rc) return rc;
+    {   // 256 zero bytes in HBM that padding / out-of-image lanes of the LDS-DMA read from (created once per process)
+        static float *zero_page = nullptr;
+        if (!zero_page) {
+            LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
+            LAV_HIP(hipMemset(zero_page, 0, 256));
+        }
+        a.zero_page = zero_page;
+    }
     info[0] = MP; info[1] = MC; info[2] = a.rowblock; info[3] = a.Wst; info[4] = a.ROWS; info[5] = (int)lds;
     return LAV_OK;
 }
@@ -416,6 +475,14 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     size_t lds;
     rc = choose_tile(*c, p, a, MP, MC, lds);
     if (rc) return rc;
+    {   // 256 zero bytes in HBM that padding / out-of-image lanes of the LDS-DMA read from (created once per process)
+        static float *zero_page = nullptr;
+        if (!zero_page) {
+            LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
+            LAV_HIP(hipMemset(zero_page, 0, 256));
+        }
+        a.zero_page = zero_page;
+    }
     for (int i = 0; i < MAX_CLASSES; ++i) {
         const bool live = i < p.nclasses;
         a.cls_ntaps[i] = live ? (int)p.taps[i].size() : 0;
