@@ -41,6 +41,7 @@ struct ConvArgs {
     int cin_pad, cout_pad;  // packed-weight strides (multiples of CK / 64), zero filled
     int QH, QW, in_s, out_s;
     int Wst, ROWS, plane_pad, nclasses, taps_per_class, tap_group;
+    int in_bufs;  // 2: input tile double buffered; 1: tile too large for that (wide 7x7 stems) - loaded at chunk start
     int rowblock, xblocks;  // 1: tiles are PIXW-wide segments of ONE output-grid row (wide images); 0: linearised pixels
     int relu_pre, relu_post, sigmoid;
     int cls_ntaps[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int Wst = a.Wst, ROWS = a.ROWS, plane = a.plane_pad;  // channel stride in LDS (ROWS*Wst rounded up to 64)
     const int in_floats = CK * plane, w_floats = a.tap_group * CK * CO_T;
     float *s_in0 = smem;                               // [2][CK][plane]   double-buffered input tile
-    float *s_w0 = smem + 2 * in_floats;                // [2][tap_group][CK][CO_T]   double-buffered weight slab
+    float *s_w0 = smem + a.in_bufs * in_floats;        // [2][tap_group][CK][CO_T]   double-buffered weight slab
     const int ntaps = a.cls_ntaps[cls];
     // tile origin: first output-grid row, first staged input column (relative to in_ox)
     const int xb = a.rowblock ? (int)(blockIdx.x % a.xblocks) : 0;
@@ -154,26 +155,27 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     // wave-uniform base + lane*size, which is exactly how both tiles are laid out (positions / float4s in thread
     // order).  Padding and out-of-image positions read a zero page.
     const long zoff = a.zero_page - xin;  // flat address space: the zero page as an element offset from xin
-    auto issue = [&](int stage) {
-        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+    auto issue_input = [&](int chunk) {
         const int ci0 = chunk * CK;
-        if (grp == 0) {
-            float *dst = s_in0 + (chunk & 1) * in_floats + wid * 64;
+        float *dst = s_in0 + (a.in_bufs == 2 ? (chunk & 1) * in_floats : 0) + wid * 64;
 #pragma unroll
-            for (int i = 0; i < NPOS_MAX; ++i) {
-                if (256 * i + 64 * wid < plane) {  // wave-uniform: this wave's 64 positions lie inside the padded plane
-                    const int g = goff[i];
+        for (int i = 0; i < NPOS_MAX; ++i) {
+            if (256 * i + 64 * wid < plane) {  // wave-uniform: this wave's 64 positions lie inside the padded plane
+                const int g = goff[i];
 #pragma unroll
-                    for (int c = 0; c < CK; ++c) {
-                        // integer select (v_cndmask), not a branch around the load: element offset of the point's
-                        // pixel inside channel ci0+c, or of the zero page, both relative to xin
-                        const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
-                        const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
-                        __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + 256 * i), 4, 0, 0);
-                    }
+                for (int c = 0; c < CK; ++c) {
+                    // integer select (v_cndmask), not a branch around the load: element offset of the point's
+                    // pixel inside channel ci0+c, or of the zero page, both relative to xin
+                    const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
+                    const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + 256 * i), 4, 0, 0);
                 }
             }
         }
+    };
+    auto issue_weights = [&](int stage) {
+        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        const int ci0 = chunk * CK;
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
         constexpr int V = CO_T / 4;
@@ -187,12 +189,20 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
     };
 
-    issue(0);
+    issue_weights(0);
+    if (a.in_bufs == 2) issue_input(0);
     for (int stage = 0; stage < nstages; ++stage) {
+        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        if (a.in_bufs == 1 && grp == 0) {  // single input buffer: everyone must be done with the previous chunk first
+            __syncthreads();
+            issue_input(chunk);
+        }
         // stage's DMA has landed for every wave, and every wave is done computing stage-1 (whose buffers stage+1 reuses)
         __syncthreads();  // hipcc drains vmcnt(0) ahead of the barrier because LDS-DMA is in flight
-        if (stage + 1 < nstages) issue(stage + 1);
-        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        if (stage + 1 < nstages) {
+            issue_weights(stage + 1);
+            if (a.in_bufs == 2 && grp == ngroups - 1) issue_input(chunk + 1);
+        }
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
         const float *s_in = s_in0 + (chunk & 1) * in_floats;
@@ -325,7 +335,7 @@ int build_plan(const lav_conv &c, Plan &p) {
 int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds) {
     a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
     const long Q = (long)p.QH * p.QW;
-    struct Geo { int rowblock, xblocks, Wst, ROWS, plane_pad, tap_group; size_t lds; long nwg; bool ok; };
+    struct Geo { int rowblock, xblocks, Wst, ROWS, plane_pad, tap_group, in_bufs; size_t lds; long nwg; bool ok; };
     auto geo = [&](int mp, int mc) {
         Geo g;
         const int PIXW = 128 * mp, CO_T = 32 * mc;
@@ -336,7 +346,8 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         // both tiles are double buffered in LDS; the weight slab holds `tap_group` taps (all of them when they fit,
         // else one kernel row, else a single tap)
         auto pad = [&]() { return ((long)g.ROWS * g.Wst + 63) / 64 * 64; };
-        auto bytes_with = [&](int tg) { return (size_t)(2 * ((size_t)CK * pad() + (size_t)tg * CK * CO_T)) * 4; };
+        g.in_bufs = 2;
+        auto bytes_with = [&](int tg) { return (size_t)(g.in_bufs * (size_t)CK * pad() + 2 * (size_t)tg * CK * CO_T) * 4; };
         auto pick_group = [&]() {
             const int opts[3] = {p.taps_per_class, p.nclasses == 1 ? c.kw : 1, 1};
             for (int tg : opts)
@@ -351,6 +362,10 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
             g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
             g.ROWS = p.max_dy + 1;
             g.tap_group = pick_group();
+            if (bytes() > 150 * 1024) {  // even one row-block is too big to double buffer
+                g.in_bufs = 1;
+                g.tap_group = pick_group();
+            }
         }
         g.plane_pad = (int)pad();
         g.lds = bytes();
@@ -372,7 +387,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     }
     LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
     a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
-    a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group;
+    a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group; a.in_bufs = bg.in_bufs;
     lds = bg.lds;
     return LAV_OK;
 }
@@ -388,14 +403,6 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     size_t lds;
     rc = choose_tile(*c, p, a, MP, MC, lds);
     if (rc) return rc;
-    {   // 256 zero bytes in HBM that padding / out-of-image lanes of the LDS-DMA read from (created once per process)
-        static float *zero_page = nullptr;
-        if (!zero_page) {
-            LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
-            LAV_HIP(hipMemset(zero_page, 0, 256));
-        }
-        a.zero_page = zero_page;
-    }
     info[0] = MP; info[1] = MC; info[2] = a.rowblock; info[3] = a.Wst; info[4] = a.ROWS; info[5] = (int)lds;
     return LAV_OK;
 }
