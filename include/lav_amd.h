@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 1
+#define LAV_ABI_VERSION 2
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -173,13 +173,28 @@ size_t lav_conv_packed_weight_floats(const lav_conv *c);
 /* host-side repack of a PyTorch-layout weight (Conv2d: [cout][cin][kh][kw]; ConvTranspose2d:
  * [cin][cout][kh][kw]) into the kernel's [class][tap][cin][cout] layout.  Pure host code. */
 int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed);
-/* introspection of the launch plan (host only, no device access): info[0..5] = { MP, MC, row-blocked tiles,
- * staged tile width, staged tile rows, LDS bytes }.  Fails exactly when lav_conv2d would reject the shape. */
+/* introspection of the launch plan (host only, no device access): info[0..7] = { MP, MC, row-blocked tiles,
+ * staged tile width, staged tile rows, LDS bytes, split-K factor, taps per weight slab }.  Fails exactly when
+ * lav_conv2d would reject the shape. */
 int lav_conv_tile_info(const lav_conv *c, int *info);
+/* scratch for the split-K partial sums of small-output / deep-channel layers (0 when the layer is not split) */
+size_t lav_conv_workspace_bytes(const lav_conv *c);
 /* x, y, w_packed: device.  bias / scale / shift: [cout] device or NULL.  residual: same shape and
  * channel window as y, or NULL. */
 int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
-               const float *shift, const float *residual, float *y, void *stream);
+               const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
+               void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 5. Rotated crop of the BEV feature map around each actor.  Replaces crop_feature
+ *    (team_code_v2/model_inference.py:204-238; same maths team_code_v2/models/uniplanner.py:310-352):
+ *    theta = k*R(ori) about the (offset_x, offset_y) pivot, k = crop/H, affine_grid + bilinear grid_sample,
+ *    zeros outside, align_corners=True.
+ *    feat [feat_batch][C][H][W] (feat_batch = 1: the one map is shared by all n crops, the reference's
+ *    features.expand(N, ...)); locs [n][2] metres, oris [n] radians (device); out [n][C][crop][crop].
+ * ------------------------------------------------------------------------------------------ */
+int lav_crop_rotate(const float *feat, int feat_batch, int C, int H, int W, const float *locs, const float *oris, int n,
+                    float pixels_per_meter, int crop, float offset_x, float offset_y, float *out, void *stream);
 
 #ifdef __cplusplus
 }

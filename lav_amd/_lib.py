@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblav_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_CAM = 4
 
 
@@ -57,7 +57,9 @@ SIGNATURES = {
     "lav_conv_packed_weight_floats": (_Z, [C.POINTER(Conv)]),
     "lav_conv_pack_weights": (_I, [C.POINTER(Conv), _P, _P]),
     "lav_conv_tile_info": (_I, [C.POINTER(Conv), C.POINTER(_I)]),
-    "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
+    "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_crop_rotate": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
 }
 
 _lib = None

@@ -41,6 +41,8 @@ struct ConvArgs {
     int cin_pad, cout_pad;  // packed-weight strides (multiples of CK / 64), zero filled
     int QH, QW, in_s, out_s;
     int Wst, ROWS, plane_pad, nclasses, taps_per_class, tap_group;
+    int ksplit;   // >1: the cin chunks are split over `ksplit` workgroups writing raw partial sums to `partial`
+    float *partial;
     int in_bufs;  // 2: input tile double buffered; 1: tile too large for that (wide 7x7 stems) - loaded at chunk start
     int rowblock, xblocks;  // 1: tiles are PIXW-wide segments of ONE output-grid row (wide images); 0: linearised pixels
     int relu_pre, relu_post, sigmoid;
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_T = 32 * MC, PIXW = 128 * MP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int cls = blockIdx.z % a.nclasses, n = blockIdx.z / a.nclasses;
+    const int ks = blockIdx.z % a.ksplit;
+    const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
     const int cb = blockIdx.y * CO_T;
     const int Q = a.QH * a.QW;
     const int Wst = a.Wst, ROWS = a.ROWS, plane = a.plane_pad;  // channel stride in LDS (ROWS*Wst rounded up to 64)
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const float *xin = a.x + ((long)n * a.in_c_total + a.in_c_offset) * a.H * a.W;
     const long cplane = (long)a.H * a.W;
     const int ngroups = (ntaps + a.tap_group - 1) / a.tap_group;
-    const int nchunks = (a.cin + CK - 1) / CK;
-    const int nstages = nchunks * ngroups;
+    const int nchunks_all = (a.cin + CK - 1) / CK;
+    const int chunk_lo = ks * nchunks_all / a.ksplit, chunk_hi = (ks + 1) * nchunks_all / a.ksplit;
+    const int nstages = (chunk_hi - chunk_lo) * ngroups;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
     };
     auto issue_weights = [&](int stage) {
-        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        const int chunk = chunk_lo + stage / ngroups, grp = stage % ngroups;
         const int ci0 = chunk * CK;
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
@@ -189,10 +193,12 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
     };
 
-    issue_weights(0);
-    if (a.in_bufs == 2) issue_input(0);
+    if (nstages > 0) {
+        issue_weights(0);
+        if (a.in_bufs == 2) issue_input(chunk_lo);
+    }
     for (int stage = 0; stage < nstages; ++stage) {
-        const int chunk = stage / ngroups, grp = stage - chunk * ngroups;
+        const int chunk = chunk_lo + stage / ngroups, grp = stage % ngroups;
         if (a.in_bufs == 1 && grp == 0) {  // single input buffer: everyone must be done with the previous chunk first
             __syncthreads();
             issue_input(chunk);
@@ -221,6 +227,24 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     }
 
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
+    if (a.ksplit > 1) {  // raw partial sums [ks][n][cout][OH][OW]; k_conv_reduce adds them up and applies the epilogue
+        const long plane_o = (long)a.OH * a.OW;
+        const int batch = gridDim.z / (a.ksplit * a.nclasses);
+        float *pbase = a.partial + ((long)ks * batch + n) * a.cout * plane_o;
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                const int oy = pqy[mp] * a.out_s + out_oy, ox = pqx[mp] * a.out_s + out_ox;
+                const bool pix_ok = pvalid[mp] && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb + mc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix_ok && co < a.cout) pbase[co * plane_o + (long)oy * a.OW + ox] = acc[mc][mp][r];
+                }
+            }
+        return;
+    }
     const bool has_bias = a.bias != nullptr, has_aff = a.scale != nullptr, has_res = a.res != nullptr;
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) {
@@ -260,6 +284,27 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
             }
         }
     }
+}
+
+// Split-K second pass: y = epilogue( sum_ks partial[ks] ), fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void k_conv_reduce(ConvArgs a, int batch) {
+    const long plane_o = (long)a.OH * a.OW;
+    const long total = (long)batch * a.cout * plane_o;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int n = (int)(e / (a.cout * plane_o));
+    const int co = (int)((e / plane_o) % a.cout);
+    const long pix = e % plane_o;
+    float v = 0.f;
+    for (int ks = 0; ks < a.ksplit; ++ks) v += a.partial[(long)ks * total + e];
+    if (a.bias) v += a.bias[co];
+    if (a.relu_pre) v = v > 0.f ? v : 0.f;
+    if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+    const long idx = ((long)n * a.out_c_total + a.out_c_offset + co) * plane_o + pix;
+    if (a.res) v += a.res[idx];
+    if (a.relu_post) v = v > 0.f ? v : 0.f;
+    if (a.sigmoid) v = 1.f / (1.f + expf(-v));
+    a.y[idx] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ host plan
@@ -343,33 +388,51 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
         const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
         g.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
-        // both tiles are double buffered in LDS; the weight slab holds `tap_group` taps (all of them when they fit,
-        // else one kernel row, else a single tap)
+        const size_t LDS_MAX = 160 * 1024;
         auto pad = [&]() { return ((long)g.ROWS * g.Wst + 63) / 64 * 64; };
-        g.in_bufs = 2;
         auto bytes_with = [&](int tg) { return (size_t)(g.in_bufs * (size_t)CK * pad() + 2 * (size_t)tg * CK * CO_T) * 4; };
+        // weight slab: all taps when they fit, else one kernel row, else a single tap
         auto pick_group = [&]() {
             const int opts[3] = {p.taps_per_class, p.nclasses == 1 ? c.kw : 1, 1};
             for (int tg : opts)
-                if (tg >= 1 && tg <= TAP_GROUP && bytes_with(tg) <= 150 * 1024) return tg;
-            return 1;
+                if (tg >= 1 && tg <= TAP_GROUP && bytes_with(tg) <= LDS_MAX) return tg;
+            return 0;
         };
-        auto bytes = [&]() { return bytes_with(g.tap_group); };
-        g.tap_group = pick_group();
-        if ((long)pad() > 256 * NPOS_MAX || bytes() > 150 * 1024) {
-            g.rowblock = 1;
-            g.xblocks = (p.QW + PIXW - 1) / PIXW;
-            g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
-            g.ROWS = p.max_dy + 1;
+        // try: linearised tile with a double- then single-buffered input, then row-blocked tiles likewise
+        bool placed = false;
+        for (int mode = 0; mode < 4 && !placed; ++mode) {
+            g.rowblock = mode >> 1;
+            g.in_bufs = (mode & 1) ? 1 : 2;
+            if (g.rowblock) {
+                g.xblocks = (p.QW + PIXW - 1) / PIXW;
+                g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
+                g.ROWS = p.max_dy + 1;
+            }
+            if (pad() > 256 * NPOS_MAX) continue;
             g.tap_group = pick_group();
-            if (bytes() > 150 * 1024) {  // even one row-block is too big to double buffer
-                g.in_bufs = 1;
+            // a one-tap slab means a barrier every 8*MP*MC MFMAs: only accept it when nothing better exists
+            if (g.tap_group >= std::min(p.taps_per_class, p.nclasses == 1 ? c.kw : 1)) placed = true;
+        }
+        if (!placed) {  // last resort: whatever fits, single tap
+            for (int mode = 0; mode < 4 && !placed; ++mode) {
+                g.rowblock = mode >> 1;
+                g.in_bufs = (mode & 1) ? 1 : 2;
+                g.xblocks = 1; g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
+                g.ROWS = ((int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH) - 1) * p.in_s + p.max_dy + 1;
+                if (g.rowblock) {
+                    g.xblocks = (p.QW + PIXW - 1) / PIXW;
+                    g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
+                    g.ROWS = p.max_dy + 1;
+                }
+                if (pad() > 256 * NPOS_MAX) continue;
                 g.tap_group = pick_group();
+                placed = g.tap_group >= 1;
             }
         }
+        auto bytes = [&]() { return bytes_with(std::max(g.tap_group, 1)); };
         g.plane_pad = (int)pad();
         g.lds = bytes();
-        g.ok = (long)g.plane_pad <= 256 * NPOS_MAX && g.lds <= 160 * 1024;
+        g.ok = placed && (long)g.plane_pad <= 256 * NPOS_MAX && g.lds <= LDS_MAX;
         const long xt = g.rowblock ? (long)p.QH * g.xblocks : (Q + PIXW - 1) / PIXW;
         g.nwg = xt * ((c.cout + CO_T - 1) / CO_T) * c.batch * p.nclasses;
         return g;
@@ -389,6 +452,15 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
     a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group; a.in_bufs = bg.in_bufs;
     lds = bg.lds;
+    // split-K: layers with few output tiles and a long channel loop (deep ResNet stages, 40x40 BEV stage) leave most
+    // CUs idle while a handful of waves walk K serially; spread the cin chunks over up to 16 workgroups per tile
+    const int nchunks = (c.cin + CK - 1) / CK;
+    a.ksplit = 1;
+    if (bg.nwg < 160 && nchunks >= 4) {
+        int ksp = (int)std::min<long>(16, (256 + bg.nwg - 1) / bg.nwg);
+        ksp = std::min(ksp, nchunks / 2);
+        if (ksp >= 2) a.ksplit = ksp;
+    }
     return LAV_OK;
 }
 }  // namespace
@@ -404,6 +476,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     rc = choose_tile(*c, p, a, MP, MC, lds);
     if (rc) return rc;
     info[0] = MP; info[1] = MC; info[2] = a.rowblock; info[3] = a.Wst; info[4] = a.ROWS; info[5] = (int)lds;
+    info[6] = a.ksplit; info[7] = a.tap_group;
     return LAV_OK;
 }
 
@@ -416,9 +489,13 @@ int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t 
         attr_set = true;
     }
     const int Q = p.QH * p.QW;
-    dim3 grid(a.rowblock ? p.QH * a.xblocks : (Q + 128 * MP - 1) / (128 * MP), (a.cout + 32 * MC - 1) / (32 * MC), batch * p.nclasses);
+    dim3 grid(a.rowblock ? p.QH * a.xblocks : (Q + 128 * MP - 1) / (128 * MP), (a.cout + 32 * MC - 1) / (32 * MC), batch * p.nclasses * a.ksplit);
     const int tok = timer_begin("conv2d", st);
     hipLaunchKernelGGL((k_conv<MP, MC>), grid, dim3(256), lds, st, a);
+    if (a.ksplit > 1) {
+        const long total = (long)batch * a.cout * p.OH * p.OW;
+        hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, batch);
+    }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
@@ -463,8 +540,20 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
     return LAV_OK;
 }
 
+extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
+    if (!c) return 0;
+    Plan p;
+    if (build_plan(*c, p)) return 0;
+    ConvArgs a;
+    int MP, MC;
+    size_t lds;
+    if (choose_tile(*c, p, a, MP, MC, lds)) return 0;
+    return a.ksplit > 1 ? (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float) : 0;
+}
+
 extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
-                          const float *shift, const float *residual, float *y, void *stream) {
+                          const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
+                          void *stream) {
     LAV_REQUIRE(c && x && w_packed && y, "lav_conv2d: null argument");
     LAV_REQUIRE((scale == nullptr) == (shift == nullptr), "lav_conv2d: scale and shift go together");
     Plan p;
@@ -482,6 +571,13 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     size_t lds;
     rc = choose_tile(*c, p, a, MP, MC, lds);
     if (rc) return rc;
+    if (a.ksplit > 1) {
+        const size_t need = (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float);
+        if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, need);
+        a.partial = static_cast<float *>(workspace);
+    } else {
+        a.partial = nullptr;
+    }
     {   // 256 zero bytes in HBM that padding / out-of-image lanes of the LDS-DMA read from (created once per process)
         static float *zero_page = nullptr;
         if (!zero_page) {

@@ -179,6 +179,7 @@ class ConvLayer:
         dev = device if device is not None else weight.device
         self.w = packed.to(dev)
         self.bias = None if bias is None else bias.detach().to(dev, torch.float32).contiguous()
+        self._ws_bytes = {}
         self.scale = self.shift = None
         if bn is not None:  # eval-mode BatchNorm as y = x*scale + shift, folded in float64
             mean, var, gamma, beta = [t.detach().to("cpu", torch.float64) for t in bn]
@@ -225,6 +226,30 @@ class ConvLayer:
             residual = _f32c(residual, "residual")
             if residual.shape != out.shape:
                 raise RuntimeError("residual shape mismatch")
-        check(_lib.load().lav_conv2d(C.byref(d), _ptr(x), _ptr(self.w), _ptr(self.bias), _ptr(self.scale),
-                                     _ptr(self.shift), _ptr(residual), _ptr(out), _stream()), "lav_conv2d")
+        lib = _lib.load()
+        key = (B, h, w)
+        nbytes = self._ws_bytes.get(key)
+        if nbytes is None:
+            nbytes = self._ws_bytes[key] = lib.lav_conv_workspace_bytes(C.byref(d))
+        ws = _workspace("conv", nbytes, x.device) if nbytes else None
+        check(lib.lav_conv2d(C.byref(d), _ptr(x), _ptr(self.w), _ptr(self.bias), _ptr(self.scale), _ptr(self.shift),
+                             _ptr(residual), _ptr(out), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+              "lav_conv2d")
         return out
+
+
+def crop_rotate(features: torch.Tensor, locs: torch.Tensor, oris: torch.Tensor, pixels_per_meter: float, crop: int,
+                offset_x: float, offset_y: float) -> torch.Tensor:
+    """features (1 or N, C, H, W), locs (N,2), oris (N,) in HBM -> (N, C, crop, crop)."""
+    lib = _lib.load()
+    features = _f32c(features, "features")
+    locs = _f32c(locs.reshape(-1, 2), "locs")
+    oris = _f32c(oris.reshape(-1), "oris")
+    fb, Cc, H, W = features.shape
+    n = locs.shape[0]
+    if fb not in (1, n):
+        raise RuntimeError("features batch must be 1 (shared map) or N")
+    out = torch.empty((n, Cc, crop, crop), dtype=torch.float32, device=features.device)
+    check(lib.lav_crop_rotate(_ptr(features), fb, Cc, H, W, _ptr(locs), _ptr(oris), n, float(pixels_per_meter), int(crop),
+                              float(offset_x), float(offset_y), _ptr(out), _stream()), "lav_crop_rotate")
+    return out

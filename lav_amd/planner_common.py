@@ -25,10 +25,17 @@ def plan_weights(gru, mlp, device):
 def crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, offset_x, offset_y):
     """Rotated crop of the feature map around each actor (team_code_v2/model_inference.py:204-238 /
     uniplanner.py:310-352): theta = k*R(ori) with the (offset_x, offset_y) pivot, bilinear, zeros outside,
-    align_corners=True.  torch's affine_grid/grid_sample for now (row a15 of SURVEY 8a, 'next' kernel)."""
+    align_corners=True - one liblav_amd kernel instead of affine_grid + grid_sample.  A feature map that was
+    `expand`ed over the batch (stride 0) is passed once and shared by all crops."""
+    if features.dim() == 4 and features.shape[0] > 1 and features.stride(0) == 0:
+        features = features[:1]
+    return ops.crop_rotate(features, rel_locs, rel_oris, pixels_per_meter, crop_size, offset_x, offset_y)
+
+
+def crop_feature_torch(features, rel_locs, rel_oris, pixels_per_meter, crop_size, offset_x, offset_y):
+    """The same crop with torch's affine_grid/grid_sample (kept for training mode, which needs autograd)."""
     B, C, H, W = features.shape
     rel_locs = rel_locs.view(-1, 2) * pixels_per_meter
-    # same arithmetic as `* ppm / tensor([H/2, W/2])` without creating a tensor from host data (HIP-graph capturable)
     rel_locs = torch.stack([rel_locs[:, 0] / (H / 2), rel_locs[:, 1] / (W / 2)], dim=-1)
     cos, sin = torch.cos(rel_oris), torch.sin(rel_oris)
     k = crop_size / H

@@ -33,6 +33,10 @@ CASES = [
     ("3x3 cin 3", 3, 13, (3, 3), 2, (1, 1), (1, 1), False, 0, 64, 48),
     ("7x7 s2 wide image (row-blocked tiles)", 3, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 768),
     ("3x3 s1 wide 16ch", 16, 64, (3, 3), 1, (1, 1), (1, 1), False, 0, 12, 1000),
+    ("3x3 512->512 on 3x3 (split-K 16)", 512, 512, (3, 3), 1, (1, 1), (1, 1), False, 0, 3, 3),
+    ("3x3 s2 256->512 on 6x6 (split-K)", 256, 512, (3, 3), 2, (1, 1), (1, 1), False, 0, 6, 6),
+    ("1x1 s2 256->512 downsample", 256, 512, (1, 1), 2, (0, 0), (1, 1), False, 0, 6, 6),
+    ("7x7 s2 p3 384->64 batch crop", 384, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 96),
 ]
 
 
@@ -87,3 +91,32 @@ def test_conv_transpose_detecting():
     ref = F.conv2d(x, w)
     y = ConvLayer(w, device=DEV)(x.to(DEV)).cpu()
     assert_close(y.numpy(), ref.numpy(), atol=1e-4, rtol=1e-6, what="permutation conv")
+
+
+def test_split_k_epilogue_matches_unsplit():
+    """bias + BN + residual + ReLU through the split-K reduce kernel (deep layer, tiny image)."""
+    B, cin, cout, H, W = 1, 256, 256, 6, 6
+    x = rnd((B, cin, H, W), 21)
+    w = rnd((cout, cin, 3, 3), 22, scale=0.02)
+    bias = rnd((cout,), 23)
+    bn = (rnd((cout,), 24, 0.1), rnd((cout,), 25).abs() + 0.5, rnd((cout,), 26).abs() + 0.5, rnd((cout,), 27, 0.1))
+    res = rnd((B, cout, H, W), 28)
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, bias, 1, 1), bn[0], bn[1], bn[2], bn[3], False, 0., 1e-5) + res)
+    layer = ConvLayer(w, padding=1, bias=bias, bn=bn, relu_post=True, device=DEV)
+    y = layer(x.to(DEV), residual=res.to(DEV)).cpu()
+    assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what="split-K epilogue")
+
+
+def test_crop_rotate_matches_torch_grid_sample():
+    from lav_amd import ops
+    from lav_amd.planner_common import crop_feature_torch
+    feat = rnd((1, 48, 160, 160), 31)
+    locs = torch.tensor([[0.0, 0.0], [-5.0, -20.0], [7.5, -32.5], [30.0, 10.0], [-12.0, 3.0]])
+    oris = torch.tensor([0.0, 0.3, -1.2, 2.9, -3.1])
+    ref = crop_feature_torch(feat.expand(5, -1, -1, -1), locs, oris, 2.0, 96, 0.0, 0.75)
+    out = ops.crop_rotate(feat.to(DEV), locs.to(DEV), oris.to(DEV), 2.0, 96, 0.0, 0.75).cpu()
+    assert_close(out.numpy(), ref.numpy(), atol=2e-4, what="rotated crop (shared map)")
+    fb = rnd((5, 8, 40, 56), 32)
+    ref = crop_feature_torch(fb, locs, oris, 1.0, 24, 0.1, 0.5)
+    out = ops.crop_rotate(fb.to(DEV), locs.to(DEV), oris.to(DEV), 1.0, 24, 0.1, 0.5).cpu()
+    assert_close(out.numpy(), ref.numpy(), atol=2e-4, what="rotated crop (per-sample maps)")
