@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
-        const float *s_in = s_in0 + (chunk & 1) * in_floats;
+        const float *s_in = s_in0 + (a.in_bufs == 2 ? (chunk & 1) * in_floats : 0);
         const float *s_w = s_w0 + (stage & 1) * w_floats;
         // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
         TapOps<MP, MC> o0, o1;
@@ -400,9 +400,14 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         };
         // try: linearised tile with a double- then single-buffered input, then row-blocked tiles likewise
         bool placed = false;
+        // (rowblock, in_bufs) in order of preference; row blocks only come first when rows are at least a tile wide
+        const int wide[4][2] = {{0, 2}, {1, 2}, {0, 1}, {1, 1}}, narrow[4][2] = {{0, 2}, {0, 1}, {1, 2}, {1, 1}};
+        const int (*order)[2] = p.QW >= PIXW ? wide : narrow;
         for (int mode = 0; mode < 4 && !placed; ++mode) {
-            g.rowblock = mode >> 1;
-            g.in_bufs = (mode & 1) ? 1 : 2;
+            g.rowblock = order[mode][0];
+            g.in_bufs = order[mode][1];
+            g.xblocks = 1; g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
+            g.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
             if (g.rowblock) {
                 g.xblocks = (p.QW + PIXW - 1) / PIXW;
                 g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
