@@ -31,7 +31,7 @@ constexpr int MAX_TAPS = 64;
 constexpr int MAX_CLASSES = 16;
 constexpr int CK = 16;        // input channels per LDS stage (compile time: the pair loop is fully unrolled)
 constexpr int TAP_GROUP = 9;  // taps per weight stage (a 7x7 kernel is staged one kernel row at a time)
-constexpr int NPOS_MAX = 12;  // staged input positions per thread: ROWS*Wst <= 256*NPOS_MAX
+constexpr int NPOS_MAX = 40;  // bound on staged input positions per thread (LDS capacity is the real limit)
 
 struct ConvArgs {
     const float *x, *w, *bias, *scale, *shift, *res, *zero_page;
@@ -127,15 +127,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
         base[mp] = (pqy[mp] - qy0) * a.in_s * Wst + pqx[mp] * a.in_s - xs0;
     }
-    // input staging map: thread owns tile positions tid + 256*i; global offset inside a channel plane or -1
-    int goff[NPOS_MAX];
-#pragma unroll
-    for (int i = 0; i < NPOS_MAX; ++i) {
-        const int p = tid + 256 * i;
-        const int rr = p / Wst, xx = p - rr * Wst;
-        const int iy = iy_base + rr, ix = in_ox + xx;
-        goff[i] = (p < ROWS * Wst && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
-    }
+    // input staging map: thread owns tile positions tid + 256*i, walked incrementally (no per-position division)
+    const int rr0 = tid / Wst, xx0 = tid - rr0 * Wst;
+    const int step_q = 256 / Wst, step_r = 256 - step_q * Wst;
+    const int live = ROWS * Wst;
 
     f32x16 acc[MC][MP];
 #pragma unroll
@@ -161,20 +156,22 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const long zoff = a.zero_page - xin;  // flat address space: the zero page as an element offset from xin
     auto issue_input = [&](int chunk) {
         const int ci0 = chunk * CK;
-        float *dst = s_in0 + (a.in_bufs == 2 ? (chunk & 1) * in_floats : 0) + wid * 64;
+        float *dst = s_in0 + (a.in_bufs == 2 ? (chunk & 1) * in_floats : 0);
+        int rr = rr0, xx = xx0;
+        for (int pb = 64 * wid; pb < plane; pb += 256) {  // wave-uniform: this wave's 64 positions pb..pb+63
+            const int iy = iy_base + rr, ix = in_ox + xx;
+            const int g = (pb + lane < live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
 #pragma unroll
-        for (int i = 0; i < NPOS_MAX; ++i) {
-            if (256 * i + 64 * wid < plane) {  // wave-uniform: this wave's 64 positions lie inside the padded plane
-                const int g = goff[i];
-#pragma unroll
-                for (int c = 0; c < CK; ++c) {
-                    // integer select (v_cndmask), not a branch around the load: element offset of the point's
-                    // pixel inside channel ci0+c, or of the zero page, both relative to xin
-                    const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
-                    const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + 256 * i), 4, 0, 0);
-                }
+            for (int c = 0; c < CK; ++c) {
+                // integer select (v_cndmask), not a branch around the load: element offset of the position's pixel
+                // inside channel ci0+c, or of the zero page, both relative to xin
+                const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
+                const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
+                __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + pb), 4, 0, 0);
             }
+            rr += step_q;
+            xx += step_r;
+            if (xx >= Wst) { xx -= Wst; ++rr; }
         }
     };
     auto issue_weights = [&](int stage) {
