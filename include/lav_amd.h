@@ -173,8 +173,8 @@ size_t lav_conv_packed_weight_floats(const lav_conv *c);
 /* host-side repack of a PyTorch-layout weight (Conv2d: [cout][cin][kh][kw]; ConvTranspose2d:
  * [cin][cout][kh][kw]) into the kernel's [class][tap][cin][cout] layout.  Pure host code. */
 int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed);
-/* introspection of the launch plan (host only, no device access): info[0..7] = { MP, MC, row-blocked tiles,
- * staged tile width, staged tile rows, LDS bytes, split-K factor, taps per weight slab }.  Fails exactly when
+/* introspection of the launch plan (host only, no device access): info[0..8] = { MP, MC, row-blocked tiles,
+ * staged tile width, staged tile rows, LDS bytes, split-K factor, taps per weight slab, chunks per stage }.  Fails exactly when
  * lav_conv2d would reject the shape. */
 int lav_conv_tile_info(const lav_conv *c, int *info);
 /* scratch for the split-K partial sums of small-output / deep-channel layers (0 when the layer is not split) */

@@ -41,6 +41,7 @@ struct ConvArgs {
     int cin_pad, cout_pad;  // packed-weight strides (multiples of CK / 64), zero filled
     int QH, QW, in_s, out_s;
     int Wst, ROWS, plane_pad, nclasses, taps_per_class, tap_group;
+    int cps;      // 16-channel chunks staged per pipeline stage (short layers stage all of K at once)
     int ksplit;   // >1: the cin chunks are split over `ksplit` workgroups writing raw partial sums to `partial`
     float *partial;
     int in_bufs;  // 2: input tile double buffered; 1: tile too large for that (wide 7x7 stems) - loaded at chunk start
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int cb = blockIdx.y * CO_T;
     const int Q = a.QH * a.QW;
     const int Wst = a.Wst, ROWS = a.ROWS, plane = a.plane_pad;  // channel stride in LDS (ROWS*Wst rounded up to 64)
-    const int in_floats = CK * plane, w_floats = a.tap_group * CK * CO_T;
+    const int in_floats = a.cps * CK * plane, w_floats = a.cps * a.tap_group * CK * CO_T;
     float *s_in0 = smem;                               // [2][CK][plane]   double-buffered input tile
     float *s_w0 = smem + a.in_bufs * in_floats;        // [2][tap_group][CK][CO_T]   double-buffered weight slab
     const int ntaps = a.cls_ntaps[cls];
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int ngroups = (ntaps + a.tap_group - 1) / a.tap_group;
     const int nchunks_all = (a.cin + CK - 1) / CK;
     const int chunk_lo = ks * nchunks_all / a.ksplit, chunk_hi = (ks + 1) * nchunks_all / a.ksplit;
-    const int nstages = (chunk_hi - chunk_lo) * ngroups;
+    const int nsuper = (chunk_hi - chunk_lo + a.cps - 1) / a.cps;  // stages stage `cps` chunks at a time
+    const int nstages = nsuper * ngroups;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -154,73 +156,83 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     // wave-uniform base + lane*size, which is exactly how both tiles are laid out (positions / float4s in thread
     // order).  Padding and out-of-image positions read a zero page.
     const long zoff = a.zero_page - xin;  // flat address space: the zero page as an element offset from xin
-    auto issue_input = [&](int chunk) {
-        const int ci0 = chunk * CK;
-        float *dst = s_in0 + (a.in_bufs == 2 ? (chunk & 1) * in_floats : 0);
-        int rr = rr0, xx = xx0;
-        for (int pb = 64 * wid; pb < plane; pb += 256) {  // wave-uniform: this wave's 64 positions pb..pb+63
-            const int iy = iy_base + rr, ix = in_ox + xx;
-            const int g = (pb + lane < live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+    auto issue_input = [&](int sc) {  // super-chunk sc: chunks chunk_lo + sc*cps ... (up to cps of them)
+        float *dst0 = s_in0 + (a.in_bufs == 2 ? (sc & 1) * in_floats : 0);
+        const int c_first = chunk_lo + sc * a.cps, c_last = min(c_first + a.cps, chunk_hi);
+        for (int chunk = c_first; chunk < c_last; ++chunk) {
+            const int ci0 = chunk * CK;
+            float *dst = dst0 + (chunk - c_first) * CK * plane;
+            int rr = rr0, xx = xx0;
+            for (int pb = 64 * wid; pb < plane; pb += 256) {  // wave-uniform: this wave's 64 positions pb..pb+63
+                const int iy = iy_base + rr, ix = in_ox + xx;
+                const int g = (pb + lane < live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
 #pragma unroll
-            for (int c = 0; c < CK; ++c) {
-                // integer select (v_cndmask), not a branch around the load: element offset of the position's pixel
-                // inside channel ci0+c, or of the zero page, both relative to xin
-                const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
-                const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
-                __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + pb), 4, 0, 0);
+                for (int c = 0; c < CK; ++c) {
+                    // integer select (v_cndmask), not a branch around the load: element offset of the position's
+                    // pixel inside channel ci0+c, or of the zero page, both relative to xin
+                    const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
+                    const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + pb), 4, 0, 0);
+                }
+                rr += step_q;
+                xx += step_r;
+                if (xx >= Wst) { xx -= Wst; ++rr; }
             }
-            rr += step_q;
-            xx += step_r;
-            if (xx >= Wst) { xx -= Wst; ++rr; }
         }
     };
     auto issue_weights = [&](int stage) {
-        const int chunk = chunk_lo + stage / ngroups, grp = stage % ngroups;
-        const int ci0 = chunk * CK;
+        const int sc = stage / ngroups, grp = stage % ngroups;
+        const int c_first = chunk_lo + sc * a.cps, c_last = min(c_first + a.cps, chunk_hi);
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
         constexpr int V = CO_T / 4;
-        float *wdst = s_w0 + (stage & 1) * w_floats;
-        for (int f0 = 64 * wid; f0 < nt * CK * V; f0 += 256) {  // wave-uniform bounds (CK*V is a multiple of 64)
-            const int f = f0 + lane;
-            const int row = f / V, c4 = f - row * V;
-            const int tap = row / CK, c = row - tap * CK;
-            const float *src = wbase + ((long)(t0 + tap) * a.cin_pad + ci0 + c) * a.cout_pad + cb + 4 * c4;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + 4 * f0), 16, 0, 0);
+        for (int chunk = c_first; chunk < c_last; ++chunk) {
+            const int ci0 = chunk * CK;
+            float *wdst = s_w0 + (stage & 1) * w_floats + (chunk - c_first) * a.tap_group * CK * CO_T;
+            for (int f0 = 64 * wid; f0 < nt * CK * V; f0 += 256) {  // wave-uniform bounds (CK*V is a multiple of 64)
+                const int f = f0 + lane;
+                const int row = f / V, c4 = f - row * V;
+                const int tap = row / CK, c = row - tap * CK;
+                const float *src = wbase + ((long)(t0 + tap) * a.cin_pad + ci0 + c) * a.cout_pad + cb + 4 * c4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + 4 * f0), 16, 0, 0);
+            }
         }
     };
 
     if (nstages > 0) {
         issue_weights(0);
-        if (a.in_bufs == 2) issue_input(chunk_lo);
+        if (a.in_bufs == 2) issue_input(0);
     }
     for (int stage = 0; stage < nstages; ++stage) {
-        const int chunk = chunk_lo + stage / ngroups, grp = stage % ngroups;
-        if (a.in_bufs == 1 && grp == 0) {  // single input buffer: everyone must be done with the previous chunk first
+        const int sc = stage / ngroups, grp = stage % ngroups;
+        if (a.in_bufs == 1 && grp == 0) {  // single input buffer: everyone must be done with the previous chunks first
             __syncthreads();
-            issue_input(chunk);
+            issue_input(sc);
         }
         // stage's DMA has landed for every wave, and every wave is done computing stage-1 (whose buffers stage+1 reuses)
         __syncthreads();  // hipcc drains vmcnt(0) ahead of the barrier because LDS-DMA is in flight
         if (stage + 1 < nstages) {
             issue_weights(stage + 1);
-            if (a.in_bufs == 2 && grp == ngroups - 1) issue_input(chunk + 1);
+            if (a.in_bufs == 2 && grp == ngroups - 1) issue_input(sc + 1);
         }
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
-        const float *s_in = s_in0 + (a.in_bufs == 2 ? (chunk & 1) * in_floats : 0);
-        const float *s_w = s_w0 + (stage & 1) * w_floats;
-        // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
-        TapOps<MP, MC> o0, o1;
-        load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, l31, half);
-        int t = 0;
-        for (; t + 1 < nt; t += 2) {
-            load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, l31, half);
-            mma_tap<MP, MC>(o0, acc);
-            if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, l31, half);
-            mma_tap<MP, MC>(o1, acc);
+        const int nsub = min(a.cps, chunk_hi - (chunk_lo + sc * a.cps));
+        for (int sub = 0; sub < nsub; ++sub) {
+            const float *s_in = s_in0 + (a.in_bufs == 2 ? (sc & 1) * in_floats : 0) + sub * CK * plane;
+            const float *s_w = s_w0 + (stage & 1) * w_floats + sub * a.tap_group * CK * CO_T;
+            // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
+            TapOps<MP, MC> o0, o1;
+            load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, l31, half);
+            int t = 0;
+            for (; t + 1 < nt; t += 2) {
+                load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, l31, half);
+                mma_tap<MP, MC>(o0, acc);
+                if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, l31, half);
+                mma_tap<MP, MC>(o1, acc);
+            }
+            if (t < nt) mma_tap<MP, MC>(o0, acc);
         }
-        if (t < nt) mma_tap<MP, MC>(o0, acc);
     }
 
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
@@ -463,6 +475,23 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         ksp = std::min(ksp, nchunks / 2);
         if (ksp >= 2) a.ksplit = ksp;
     }
+    // chunks per stage: a stage of one 16-channel chunk is only taps*8*MP*MC MFMAs (a few hundred ns) while the DMA
+    // of the next stage needs a memory round trip, so short layers stage several chunks (up to all of K) at once.
+    // Layers that fill the chip more than once keep their LDS footprint (two workgroups per CU) instead.
+    {
+        const int per_split = (nchunks + a.ksplit - 1) / a.ksplit;
+        const int CO_T = 32 * MC;
+        const size_t budget = bg.nwg * a.ksplit > 256 ? std::max<size_t>(lds, 80 * 1024) : 160 * 1024;
+        int cps = 1;
+        for (int cand : {2, 4, 8}) {
+            if (cand > per_split * 2 - 1 && cand > per_split) break;
+            const size_t b = ((size_t)a.in_bufs * cand * CK * a.plane_pad + 2 * (size_t)cand * a.tap_group * CK * CO_T) * 4;
+            if (b <= budget) cps = cand;
+        }
+        cps = std::min(cps, per_split);
+        a.cps = std::max(cps, 1);
+        lds = ((size_t)a.in_bufs * a.cps * CK * a.plane_pad + 2 * (size_t)a.cps * a.tap_group * CK * CO_T) * 4;
+    }
     return LAV_OK;
 }
 }  // namespace
@@ -478,7 +507,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     rc = choose_tile(*c, p, a, MP, MC, lds);
     if (rc) return rc;
     info[0] = MP; info[1] = MC; info[2] = a.rowblock; info[3] = a.Wst; info[4] = a.ROWS; info[5] = (int)lds;
-    info[6] = a.ksplit; info[7] = a.tap_group;
+    info[6] = a.ksplit; info[7] = a.tap_group; info[8] = a.cps;
     return LAV_OK;
 }
 

@@ -188,7 +188,7 @@ def test_every_layer_shape_of_the_frame_has_a_launch_plan():
                     todo.append((blk.downsample[0], tuple(x.shape)))
                 x = walk([blk.conv1, blk.conv2], x)
     assert len(todo) > 150
-    info = (C.c_int * 6)()
+    info = (C.c_int * 9)()
     for conv, shp in todo:
         tr = isinstance(conv, torch.nn.ConvTranspose2d)
         cin, cout = (conv.in_channels, conv.out_channels)

@@ -44,7 +44,7 @@ def main():
         layer = ConvLayer(w, stride=s, padding=p, dilation=d, transposed=tr, output_padding=op, relu_pre=True, device=dev)
         x = torch.randn((B, cin, H, W), device=dev)
         desc = Conv.from_buffer_copy(layer.desc); desc.batch, desc.h, desc.w = B, H, W
-        info = (ctypes.c_int * 8)()
+        info = (ctypes.c_int * 9)()
         lib.lav_conv_tile_info(ctypes.byref(desc), info)
         y = layer(x)
         reps = 30
@@ -59,7 +59,7 @@ def main():
         us = ms.value / max(n.value, 1) * 1e3
         flops = 2.0 * y.numel() * cin * k[0] * k[1] / (s * s if tr else 1)
         print(f"{name:28s} {us:8.1f} us  {flops / us / 1e6:7.1f} TF/s  tile MPxMC={info[0]}x{info[1]} rowblock={info[2]} Wst={info[3]} ROWS={info[4]} "
-              f"lds={info[5] // 1024}KB ksplit={info[6]} tapgroup={info[7]}")
+              f"lds={info[5] // 1024}KB ksplit={info[6]} tapgroup={info[7]} cps={info[8]}")
 
 
 if __name__ == "__main__":
