@@ -154,7 +154,17 @@ class GraphedFramePipeline(FramePipeline):
 
     # ---- graph A -------------------------------------------------------------------------------------------
     def _part_a(self, cmd_value):
+        """The frame graph.  Three HIP streams: the LiDAR chain (seg -> paint -> pillar -> BEV -> heads -> peaks) on
+        the capturing stream, the brake net (independent of everything else) and, once the feature map exists, the ego
+        branch (crop -> ResNet-18 -> cast -> plan) on side streams - most of these kernels are small and
+        latency-bound, so the chains overlap almost for free."""
         im = self.infer_model
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "s_bra"):
+            self.s_bra, self.s_ego = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        self.s_bra.wait_stream(main)
+        with torch.cuda.stream(self.s_bra):
+            pred_bra = self.bra_model(self.b_rgbs, self.b_tel)
         cur = torch.cat([self.b_tick, self.b_prev])
         m = ego_box_mask(cur)
         cur = torch.cat([torch.where(m, torch.full_like(cur[:, 0], float("nan")), cur[:, 0])[:, None], cur[:, 1:]], dim=1)
@@ -171,6 +181,15 @@ class GraphedFramePipeline(FramePipeline):
             self.b_features = torch.empty((1, lm.backbone.out_channels, canvas.shape[2] // 2, canvas.shape[3] // 2),
                                           dtype=torch.float32, device=canvas.device)
         features = lm.backbone(canvas, out=self.b_features)
+        up = self.infer_model.uniplanner
+        self.s_ego.wait_stream(main)
+        with torch.cuda.stream(self.s_ego):
+            ppm_f = up.pixels_per_meter / 2
+            ego_crop = up.crop_feature(features, features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, up.crop_size)
+            ego_embd = up.lidar_conv_emb(ego_crop)
+            ego_cast = up.cast(ego_embd, mode="ego")
+            ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
+                               crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
         heat, size, ori, pred_bev = lm.heads(features)
         hm = torch.sigmoid(heat[0])
         rows = []
@@ -182,14 +201,8 @@ class GraphedFramePipeline(FramePipeline):
             rows.append(torch.stack([score, xs.float(), ys.float(), size[0, 0, ys, xs], size[0, 1, ys, xs],
                                      ori[0, 0, ys, xs], ori[0, 1, ys, xs]], dim=1))
         det_raw = torch.stack(rows)                                                     # (2, 15, 7)
-        up = self.infer_model.uniplanner
-        ppm_f = up.pixels_per_meter / 2
-        ego_crop = up.crop_feature(features, features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, up.crop_size)
-        ego_embd = up.lidar_conv_emb(ego_crop)
-        ego_cast = up.cast(ego_embd, mode="ego")
-        ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
-                           crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
-        pred_bra = self.bra_model(self.b_rgbs, self.b_tel)
+        main.wait_stream(self.s_bra)
+        main.wait_stream(self.s_ego)
         return dict(features=features, det_raw=det_raw, pred_bev=pred_bev, ego_embd=ego_embd, ego_plan_locs=ego_plan,
                     ego_cast_locs=ego_cast[0, int(cmd_value)], pred_bra=pred_bra, lidar_points=lidar_points)
 

@@ -35,10 +35,13 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def _workspace(key, nbytes: int, device) -> torch.Tensor:
-    ws = _workspaces.get((key, device))
+    """Scratch buffer per (kind, device, stream): kernels enqueued on different streams may run concurrently
+    (the frame graph forks the brake net and the ego branch onto side streams), so they never share scratch."""
+    k = (key, device, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(k)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _workspaces[(key, device)] = ws
+        _workspaces[k] = ws
     return ws
 
 

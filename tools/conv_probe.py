@@ -30,6 +30,9 @@ SHAPES = [
     ("erf 128 3x1 36x32 B3", 3, 128, 128, (3, 1), 1, (1, 0), (1, 1), False, 0, 36, 32),
     ("erf 64 1x3 72x64 B3", 3, 64, 64, (1, 3), 1, (0, 1), (1, 1), False, 0, 72, 64),
     ("erf 16 3x1 144x128 B3", 3, 16, 16, (3, 1), 1, (1, 0), (1, 1), False, 0, 144, 128),
+    ("tiny 16 3x1 8x16 (1 WG)", 1, 16, 16, (3, 1), 1, (1, 0), (1, 1), False, 0, 8, 16),
+    ("tiny 64 3x3 8x16 (2 WG)", 1, 64, 64, (3, 3), 1, (1, 1), (1, 1), False, 0, 8, 16),
+    ("tiny 16 1x1 8x16 (1 WG)", 1, 16, 16, (1, 1), 1, (0, 0), (1, 1), False, 0, 8, 16),
 ]
 
 
