@@ -14,6 +14,8 @@
 //         the fly (4 FMAs).  Command branches never interact: with cmd >= 0 only that branch is evaluated.
 //
 // Gate order r, z, n as in torch.nn.GRU;  h' = (1-z)*n + z*h;  precise expf/tanhf (no fast-math).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -253,6 +255,195 @@ __global__ __launch_bounds__(64 * OUT_WAVES) void k_plan_out(PlanArgs a, int it)
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------- plan, persistent
+// All iters*T dependent steps in ONE launch.  H/8 workgroups stay resident, each keeping its 24 rows of W_hh in
+// registers; after every step the workgroups exchange the new hidden state through 8-byte {epoch, value} granules
+// written with relaxed agent-scope (write-through) atomic stores and polled with relaxed agent-scope atomic loads:
+// the data is the flag, so no fences and no separate counters (MI355X guide, guideline 16 form R2).  Two granule
+// buffers alternate; a workgroup can only be one step ahead of the slowest one, so a buffer is never overwritten while
+// still being read.  Every workgroup re-derives the waypoints (Linear(512->2) + cumsum) itself because it needs them
+// as GRU inputs in the next iteration; workgroup 0 also writes them out.  Spins are bounded: on timeout the kernel
+// raises a flag, stops waiting and the host-visible status word reports it.
+constexpr long long PLAN_SPIN_LIMIT = 1ll << 22;
+
+__global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status) {
+    const int H = a.H, T = a.T, R = a.R;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nk = H / 64;
+    __shared__ float gh_s[3 * PLAN_UNITS][PLAN_RC];
+    __shared__ float loc_s[2][PLAN_RC][64][2];
+    __shared__ float run_s[PLAN_RC][2];
+    __shared__ int abort_s;
+    const int j0 = blockIdx.x * PLAN_UNITS;
+    float w[6][PLAN_MAXK], bh[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int lr = wid * 6 + q;
+        const int row = (lr / PLAN_UNITS) * H + j0 + (lr % PLAN_UNITS);
+        const float *wr = a.w_hh + (long)row * H;
+#pragma unroll
+        for (int i = 0; i < PLAN_MAXK; ++i) w[q][i] = i < nk ? wr[lane + 64 * i] : 0.f;
+        bh[q] = a.b_hh[row];
+    }
+    float m0[PLAN_MAXK], m1[PLAN_MAXK];
+#pragma unroll
+    for (int i = 0; i < PLAN_MAXK; ++i) {
+        m0[i] = i < nk ? a.mlp_w[lane + 64 * i] : 0.f;
+        m1[i] = i < nk ? a.mlp_w[H + lane + 64 * i] : 0.f;
+    }
+    for (int e = tid; e < R * T; e += 256) {  // iteration 0 refines the cast waypoints
+        const int r = e / T, t = e - r * T;
+        int b, ci, c;
+        row_decode(a, r, b, ci, c);
+        const float *src = a.cast_locs + (((long)b * a.num_cmds + c) * T + t) * 2;
+        loc_s[0][r][t][0] = src[0];
+        loc_s[0][r][t][1] = src[1];
+    }
+    if (tid == 0) abort_s = 0;
+    // this thread's gate job (tid < 8*R): unit u of state row rr
+    const int gu = tid % PLAN_UNITS, grr = tid / PLAN_UNITS;
+    const bool gate_thread = tid < PLAN_UNITS * R;
+    int gb = 0, gci = 0, gc = 0;
+    if (gate_thread) row_decode(a, grr, gb, gci, gc);
+    float wih[3][4], bih[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int row = g * H + j0 + gu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wih[g][k] = a.w_ih[row * 4 + k];
+        bih[g] = a.b_ih[row];
+    }
+    const float u0 = gate_thread ? a.nxp[gb * 2 + 0] * a.ppm / a.crop * 2.f - 1.f : 0.f;
+    const float u1 = gate_thread ? a.nxp[gb * 2 + 1] * a.ppm / a.crop * 2.f - 1.f : 0.f;
+    float hself = 0.f;
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = 0; it < a.iters; ++it) {
+        if (tid < R * 2) run_s[tid >> 1][tid & 1] = 0.f;
+        for (int t = 0; t <= T; ++t) {  // t == T only gathers h_{T-1} to finish the iteration's waypoints
+            const unsigned epoch = (unsigned)(it * T + t);  // the state published by the previous step carries this tag
+            float hv[PLAN_RC][PLAN_MAXK];
+            if (t == 0) {
+#pragma unroll
+                for (int rr = 0; rr < PLAN_RC; ++rr) {
+                    int b, ci, c;
+                    row_decode(a, min(rr, R - 1), b, ci, c);
+#pragma unroll
+                    for (int i = 0; i < PLAN_MAXK; ++i) hv[rr][i] = i < nk ? a.embd[(long)b * H + lane + 64 * i] : 0.f;
+                }
+            } else {
+                const unsigned long long *g = gran + (long)((epoch - 1) & 1) * R * H;
+                long long spins = 0;
+                bool ok;
+                do {
+                    ok = true;
+#pragma unroll
+                    for (int rr = 0; rr < PLAN_RC; ++rr) {
+                        if (rr < R) {
+#pragma unroll
+                            for (int i = 0; i < PLAN_MAXK; ++i) {
+                                if (i < nk) {
+                                    const unsigned long long x = __hip_atomic_load(g + (long)rr * H + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = ok && (unsigned)(x >> 32) == epoch;
+                                    hv[rr][i] = __uint_as_float((unsigned)x);
+                                }
+                            }
+                        }
+                    }
+                    ok = __all(ok);
+                    if (!ok) {
+                        if (++spins > PLAN_SPIN_LIMIT || *(volatile int *)&abort_s) {
+                            abort_s = 1;
+                            if (lane == 0) atomicExch(status, 1);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                } while (!ok);
+                if (*(volatile int *)&abort_s) return;  // give up: never hang the device
+                // waypoint t-1 of this iteration from h_{t-1} (every workgroup needs it as next iteration's input)
+                if (wid == 0) {
+#pragma unroll
+                    for (int rr = 0; rr < PLAN_RC; ++rr) {
+                        if (rr < R) {
+                            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < PLAN_MAXK; ++i) {
+                                s0 = fmaf(m0[i], hv[rr][i], s0);
+                                s1 = fmaf(m1[i], hv[rr][i], s1);
+                            }
+#pragma unroll
+                            for (int d = 32; d >= 1; d >>= 1) {
+                                s0 += __shfl_xor(s0, d, 64);
+                                s1 += __shfl_xor(s1, d, 64);
+                            }
+                            if (lane == 0) {
+                                const float r0 = run_s[rr][0] + (s0 + a.mlp_b[0]), r1 = run_s[rr][1] + (s1 + a.mlp_b[1]);
+                                run_s[rr][0] = r0;
+                                run_s[rr][1] = r1;
+                                const float o0 = r0 + loc_s[cur][rr][t - 1][0], o1 = r1 + loc_s[cur][rr][t - 1][1];
+                                loc_s[cur ^ 1][rr][t - 1][0] = o0;
+                                loc_s[cur ^ 1][rr][t - 1][1] = o1;
+                                if (blockIdx.x == 0) {
+                                    int b, ci, c;
+                                    row_decode(a, rr, b, ci, c);
+                                    float *o = a.out + ((((long)b * a.iters + it) * a.NC + ci) * T + (t - 1)) * 2;
+                                    o[0] = o0;
+                                    o[1] = o1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (t == T) break;
+#pragma unroll
+            for (int rr = 0; rr < PLAN_RC; ++rr) {
+                if (rr < R) {
+                    float acc[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        acc[q] = 0.f;
+#pragma unroll
+                        for (int i = 0; i < PLAN_MAXK; ++i) acc[q] = fmaf(w[q][i], hv[rr][i], acc[q]);
+                    }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) acc[q] += __shfl_xor(acc[q], d, 64);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) gh_s[wid * 6 + q][rr] = acc[q] + bh[q];
+                    }
+                }
+            }
+            __syncthreads();
+            if (gate_thread) {
+                if (t == 0) hself = a.embd[(long)gb * H + j0 + gu];
+                const float uu[4] = {u0, u1, loc_s[cur][grr][t][0], loc_s[cur][grr][t][1]};
+                float gi[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = fmaf(wih[g][k], uu[k], acc);
+                    gi[g] = acc + bih[g];
+                }
+                const float rg = sigmoidf_(gi[0] + gh_s[0 * PLAN_UNITS + gu][grr]);
+                const float zg = sigmoidf_(gi[1] + gh_s[1 * PLAN_UNITS + gu][grr]);
+                const float ng = tanhf(gi[2] + rg * gh_s[2 * PLAN_UNITS + gu][grr]);
+                hself = (1.f - zg) * ng + zg * hself;
+                const unsigned long long x = ((unsigned long long)(epoch + 1) << 32) | __float_as_uint(hself);
+                __hip_atomic_store(gran + (long)(epoch & 1) * R * H + (long)grr * H + j0 + gu, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
 }  // namespace
 
 extern "C" size_t lav_gru_cast_workspace_bytes(int, int, int, int, int) { return 0; }
@@ -274,7 +465,10 @@ extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int n
 }
 
 extern "C" size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T) {
-    return lav::align_up((size_t)T * B * num_cmds * H * sizeof(float), 256);
+    // step-per-launch path: h sequence [T][R][H] floats; persistent path: 2 granule buffers [R][H] u64 + status word
+    const size_t seq = (size_t)T * B * num_cmds * H * sizeof(float);
+    const size_t gran = 2 * (size_t)PLAN_RC * H * sizeof(unsigned long long) + 256;
+    return lav::align_up(seq > gran ? seq : gran, 256);
 }
 
 extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds,
@@ -298,6 +492,19 @@ extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *ca
     if (!workspace || workspace_bytes < need) return lav::fail(LAV_EWORKSPACE, "lav_gru_plan: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("gru_plan", st);
+    const char *impl = getenv("LAV_PLAN_IMPL");
+    if (a.R <= PLAN_RC && !(impl && impl[0] == 's')) {
+        // persistent kernel: needs its H/8 workgroups co-resident (64 of 256 CUs) - always true on an MI355X
+        const size_t gbytes = 2 * (size_t)a.R * H * sizeof(unsigned long long);
+        LAV_REQUIRE(workspace_bytes >= gbytes + 256, "lav_gru_plan: workspace too small for the persistent kernel");
+        unsigned long long *gran = static_cast<unsigned long long *>(workspace);
+        int *status = reinterpret_cast<int *>(static_cast<char *>(workspace) + lav::align_up(gbytes, 256));
+        LAV_HIP(hipMemsetAsync(workspace, 0, lav::align_up(gbytes, 256) + 4, st));  // tags and status start at 0
+        hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status);
+        timer_end(tok, st);
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
+    }
     for (int it = 0; it < iters; ++it) {
         for (int t = 0; t < T; ++t) {
             hipLaunchKernelGGL(k_plan_step, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, it, t);

@@ -52,7 +52,11 @@ def test_paint_large_and_edge(models):
     assert empty.shape == (0, 8)
 
 
-def test_gru_cast_plan_vs_reference_golden(golden, models):
+@pytest.mark.parametrize("impl", ["persistent", "steps"])
+def test_gru_cast_plan_vs_reference_golden(golden, models, impl, monkeypatch):
+    """plan: one persistent launch with granule all-gathers (default, used when <= 6 state rows) and the
+    step-per-launch variant (LAV_PLAN_IMPL=steps, any batch)."""
+    monkeypatch.setenv("LAV_PLAN_IMPL", impl)
     g = golden["planner"]
     _, up = models
     embd = torch.from_numpy(g["gru_embd"]).to(DEV)
@@ -61,9 +65,14 @@ def test_gru_cast_plan_vs_reference_golden(golden, models):
     assert_close(cast.cpu().numpy(), g["gru_cast"], atol=2e-5, what="cast")
     plan = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192)
     assert_close(plan.cpu().numpy(), g["gru_plan"], atol=1e-4, what="plan (all commands)")
-    for cmd in (0, 3, 5):  # single-branch evaluation == that slice of the full result
+    for cmd in (0, 3, 5):  # single-branch evaluation == that slice of the full result (3 state rows: persistent kernel)
         one = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=cmd)
         assert_close(one[:, :, 0].cpu().numpy(), g["gru_plan"][:, :, cmd], atol=1e-4, what=f"plan cmd {cmd}")
+    one = up.plan(embd[:1], nxp[:1], cast_locs=cast[:1], pixels_per_meter=4, crop_size=192, cmd=-1)   # 6 rows
+    assert_close(one.cpu().numpy(), g["gru_plan"][:1], atol=1e-4, what="plan B=1 all commands")
+    for _ in range(3):  # repeated launches reuse the granule buffers (re-zeroed by the launch)
+        again = up.plan(embd[:1], nxp[:1], cast_locs=cast[:1], pixels_per_meter=4, crop_size=192, cmd=3)
+        assert_close(again[:, :, 0].cpu().numpy(), g["gru_plan"][:1, :, 3], atol=1e-4, what="plan repeat")
     with torch.no_grad():
         assert_close(up.cast_cmd_pred(embd).cpu().numpy(), g["gru_cmd"], atol=1e-6, what="cmd")
 
