@@ -161,11 +161,20 @@ class GraphedFramePipeline(FramePipeline):
         im = self.infer_model
         main = torch.cuda.current_stream()
         if not hasattr(self, "s_bra"):
-            self.s_bra, self.s_ego = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
-        self.s_bra.wait_stream(main)
-        with torch.cuda.stream(self.s_bra):
-            pred_bra = self.bra_model(self.b_rgbs, self.b_tel)
+            self.s_bra, self.s_bra2, self.s_ego = (torch.cuda.Stream(self.device) for _ in range(3))
         cur = torch.cat([self.b_tick, self.b_prev])
+        # fork AFTER a first node of the main chain (a fork from the empty capture origin was observed to serialise
+        # behind the main chain); the two brake trunks (wide image, tele image) get a stream each
+        bra = self.bra_model
+        self.s_bra.wait_stream(main)
+        self.s_bra2.wait_stream(main)
+        with torch.cuda.stream(self.s_bra):
+            x1 = bra.conv_backbone(bra.normalize(self.b_rgbs / 255.))
+        with torch.cuda.stream(self.s_bra2):
+            x2 = bra.conv_backbone(bra.normalize(self.b_tel / 255.))
+        self.s_bra.wait_stream(self.s_bra2)
+        with torch.cuda.stream(self.s_bra):
+            pred_bra = bra.classifier(torch.cat([bra.attn1(x1), bra.attn2(x2)], dim=1))[:, 0]
         m = ego_box_mask(cur)
         cur = torch.cat([torch.where(m, torch.full_like(cur[:, 0], float("nan")), cur[:, 0])[:, None], cur[:, 1:]], dim=1)
         pred_sem = torch.softmax(self.seg_model(self.b_all_rgbs), dim=1)
