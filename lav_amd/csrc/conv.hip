@@ -481,7 +481,9 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     {
         const int per_split = (nchunks + a.ksplit - 1) / a.ksplit;
         const int CO_T = 32 * MC;
-        const size_t budget = bg.nwg * a.ksplit > 256 ? std::max<size_t>(lds, 80 * 1024) : 160 * 1024;
+        // keep the footprint at <= 64 KB so that workgroups of OTHER streams (the frame graph runs the brake net, the ego
+        // branch and the LiDAR chain concurrently) can share the CU: a 160 KB workgroup monopolises its CU's LDS
+        const size_t budget = std::max<size_t>(lds, 64 * 1024);
         int cps = 1;
         for (int cand : {2, 4, 8}) {
             if (cand > per_split * 2 - 1 && cand > per_split) break;
