@@ -163,18 +163,8 @@ class GraphedFramePipeline(FramePipeline):
         if not hasattr(self, "s_bra"):
             self.s_bra, self.s_bra2, self.s_ego = (torch.cuda.Stream(self.device) for _ in range(3))
         cur = torch.cat([self.b_tick, self.b_prev])
-        # fork AFTER a first node of the main chain (a fork from the empty capture origin was observed to serialise
-        # behind the main chain); the two brake trunks (wide image, tele image) get a stream each
-        bra = self.bra_model
-        self.s_bra.wait_stream(main)
-        self.s_bra2.wait_stream(main)
-        with torch.cuda.stream(self.s_bra):
-            x1 = bra.conv_backbone(bra.normalize(self.b_rgbs / 255.))
-        with torch.cuda.stream(self.s_bra2):
-            x2 = bra.conv_backbone(bra.normalize(self.b_tel / 255.))
-        self.s_bra.wait_stream(self.s_bra2)
-        with torch.cuda.stream(self.s_bra):
-            pred_bra = bra.classifier(torch.cat([bra.attn1(x1), bra.attn2(x2)], dim=1))[:, 0]
+        fork_ev = torch.cuda.Event()
+        fork_ev.record(main)      # the brake trunks depend on nothing but this point; they are CAPTURED at the end
         m = ego_box_mask(cur)
         cur = torch.cat([torch.where(m, torch.full_like(cur[:, 0], float("nan")), cur[:, 0])[:, None], cur[:, 1:]], dim=1)
         pred_sem = torch.softmax(self.seg_model(self.b_all_rgbs), dim=1)
@@ -210,6 +200,19 @@ class GraphedFramePipeline(FramePipeline):
             rows.append(torch.stack([score, xs.float(), ys.float(), size[0, 0, ys, xs], size[0, 1, ys, xs],
                                      ori[0, 0, ys, xs], ori[0, 1, ys, xs]], dim=1))
         det_raw = torch.stack(rows)                                                     # (2, 15, 7)
+        # brake net: forked from the event recorded after the first node, one stream per trunk (wide / tele image).
+        # Captured last on purpose: hipGraph was observed to start sibling branches in capture order, one after the
+        # other, when they are captured before the main chain.
+        bra = self.bra_model
+        self.s_bra.wait_event(fork_ev)
+        self.s_bra2.wait_event(fork_ev)
+        with torch.cuda.stream(self.s_bra):
+            x1 = bra.conv_backbone(bra.normalize(self.b_rgbs / 255.))
+        with torch.cuda.stream(self.s_bra2):
+            x2 = bra.conv_backbone(bra.normalize(self.b_tel / 255.))
+        self.s_bra.wait_stream(self.s_bra2)
+        with torch.cuda.stream(self.s_bra):
+            pred_bra = bra.classifier(torch.cat([bra.attn1(x1), bra.attn2(x2)], dim=1))[:, 0]
         main.wait_stream(self.s_bra)
         main.wait_stream(self.s_ego)
         return dict(features=features, det_raw=det_raw, pred_bev=pred_bev, ego_embd=ego_embd, ego_plan_locs=ego_plan,
