@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 2
+#define LAV_ABI_VERSION 3
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -195,6 +195,35 @@ int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const f
  * ------------------------------------------------------------------------------------------ */
 int lav_crop_rotate(const float *feat, int feat_batch, int C, int H, int W, const float *locs, const float *oris, int n,
                     float pixels_per_meter, int crop, float offset_x, float offset_y, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 6. Per-frame glue of LAVAgent.run_step between the big kernels (one launch each).
+ *
+ * lav_merge_ticks: cur = cat([tick, prev]) with the ego-vehicle box removed, then prev = tick
+ *    (team_code_v2/lav_agent_fast.py:240-247 and preprocess() :450-452).  Removed points are marked x = NaN
+ *    instead of being compacted: they fail every range test downstream exactly like absent points, and the
+ *    row count stays static.  tick, prev [rows][4], cur [2*rows][4] (device).
+ *
+ * lav_stack_sweeps: get_stacked_lidar() (lav_agent_fast.py:363-383) with move_lidar_points() (:547-565).
+ *    fused [rows][8] is the newly painted sweep; ring [slots][rows][8] the history; d_slot (1 int64, device):
+ *    ring slot the new sweep is stored to; d_sweeps [num_sweeps] int64 (device): ring slots of sweeps t, t-5, t-10
+ *    (d_sweeps[0] is ignored: sweep 0 is `fused`); d_R [num_sweeps][3][3], d_t [num_sweeps][3] (device): xyz' = xyz@R + t.
+ *    out [num_sweeps*rows][8 + num_sweeps] = (xyz', features, one-hot sweep index).
+ *
+ * lav_extract_peaks: extract_peak() (team_code_v2/model_inference.py:189-202: 7x7 max-pool NMS, top-15 by
+ *    score) over `ncls` heat-map planes [ncls][h][w] (apply_sigmoid: logits in, scores out) plus the gathers of
+ *    det_inference() (:95-121) from size [size_c][h][w] and ori [ori_c][h][w].
+ *    out [ncls][max_det][3 + size_c + ori_c] = (score, x, y, size..., ori...), rows by descending score, ties by
+ *    ascending pixel index; if a plane has fewer than max_det non-suppressed pixels the remaining rows carry
+ *    score -1e5.  The last 256 bytes of the workspace are counters: zero before the first use, left zero.
+ * ------------------------------------------------------------------------------------------ */
+int lav_merge_ticks(const float *tick, float *prev, int rows, int dim, float *cur, void *stream);
+int lav_stack_sweeps(const float *fused, float *ring, const long *d_slot, const long *d_sweeps, const float *d_R,
+                     const float *d_t, int num_sweeps, int rows, int dim, float *out, void *stream);
+size_t lav_extract_peaks_workspace_bytes(int ncls, int h, int w);
+int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max_det, int apply_sigmoid,
+                      const float *size, int size_c, const float *ori, int ori_c, float *out, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblav_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_CAM = 4
 
 
@@ -60,6 +60,10 @@ SIGNATURES = {
     "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_crop_rotate": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
+    "lav_merge_ticks": (_I, [_P, _P, _I, _I, _P, _P]),
+    "lav_stack_sweeps": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "lav_extract_peaks_workspace_bytes": (_Z, [_I, _I, _I]),
+    "lav_extract_peaks": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _Z, _P]),
 }
 
 _lib = None

@@ -16,11 +16,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblav_amd.so")
-SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "conv.hip", "crop.hip"]
+SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "conv.hip", "crop.hip", "frame.hip"]
 # Parity-critical float32 arithmetic (cell ids, decoration, camera projection) must round every multiply and
 # add separately, like the oracle: these translation units are compiled with FMA contraction off (the header
 # helpers __fadd_rn/__fmul_rn are plain operators that clang would otherwise fuse after inlining).
-EXTRA_FLAGS = {"pillar.hip": ["-ffp-contract=off"], "paint.hip": ["-ffp-contract=off"], "crop.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"pillar.hip": ["-ffp-contract=off"], "paint.hip": ["-ffp-contract=off"], "crop.hip": ["-ffp-contract=off"],
+               "frame.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 

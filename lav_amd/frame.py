@@ -15,6 +15,7 @@ from collections import deque
 import numpy as np
 import torch
 
+from . import ops
 from .model_inference import InferModel
 
 GAP = 5  # NUM_REPEAT + 1 (lav_agent_fast.py:32-33)
@@ -30,12 +31,12 @@ def move_lidar_points(xyz: torch.Tensor, dloc, ori0: float, ori1: float) -> torc
     """Re-register a past sweep into the current ego frame (lav_agent_fast.py:547-565)."""
     dloc = np.asarray(dloc, np.float64) @ np.array([[math.cos(ori0), -math.sin(ori0)], [math.sin(ori0), math.cos(ori0)]])
     ori = ori1 - ori0
-    R = torch.tensor([[math.cos(ori), math.sin(ori), 0.], [-math.sin(ori), math.cos(ori), 0.], [0., 0., 1.]],
-                     dtype=torch.float32, device=xyz.device)
-    out = xyz @ R
-    out[:, 0] += float(dloc[0])
-    out[:, 1] += float(dloc[1])
-    return out
+    # xyz @ R + t written out (R[2] = R[:, 2] = e_z): products rounded separately and summed left to right, the
+    # arithmetic lav_stack_sweeps uses - a BLAS matmul leaves summation order and FMA use unspecified
+    c, s_ = float(np.float32(math.cos(ori))), float(np.float32(math.sin(ori)))
+    x, y = xyz[:, 0], xyz[:, 1]
+    return torch.stack([(x * c + y * -s_) + float(np.float32(dloc[0])), (x * s_ + y * c) + float(np.float32(dloc[1])),
+                        xyz[:, 2]], dim=1)
 
 
 class FramePipeline:
@@ -132,13 +133,10 @@ class GraphedFramePipeline(FramePipeline):
         self.b_slot = torch.zeros((1,), dtype=torch.long, device=dev)
         self.b_sweeps = torch.zeros((num_sweeps := self.num_frame_stack + 1,), dtype=torch.long, device=dev)
         self.b_R = torch.zeros((num_sweeps, 3, 3), **f)
-        self.b_t = torch.zeros((num_sweeps, 1, 3), **f)
-        onehot = torch.zeros((num_sweeps, 2 * P, num_sweeps), **f)
-        for i in range(num_sweeps):
-            onehot[i, :, i] = 1
-        self.b_onehot = onehot
+        self.b_t = torch.zeros((num_sweeps, 3), **f)
         self.b_features = None   # (1,384,160,160): shared by every frame graph, read by the others-graphs
         self.b_locs = torch.zeros((15, 2), **f)
+        self.b_zero = torch.zeros((1, 4), **f)   # the ego vehicle's own (loc, ori)
         self.b_oris = torch.zeros((15,), **f)
         self.graphs_a, self.graphs_b, self.out_a, self.out_b = {}, {}, {}, {}
         self.pool = None
@@ -162,18 +160,12 @@ class GraphedFramePipeline(FramePipeline):
         main = torch.cuda.current_stream()
         if not hasattr(self, "s_bra"):
             self.s_bra, self.s_bra2, self.s_ego = (torch.cuda.Stream(self.device) for _ in range(3))
-        cur = torch.cat([self.b_tick, self.b_prev])
+        cur = ops.merge_ticks(self.b_tick, self.b_prev)                 # concat + ego box + prev <- tick: one launch
         fork_ev = torch.cuda.Event()
         fork_ev.record(main)      # the brake trunks depend on nothing but this point; they are CAPTURED at the end
-        m = ego_box_mask(cur)
-        cur = torch.cat([torch.where(m, torch.full_like(cur[:, 0], float("nan")), cur[:, 0])[:, None], cur[:, 1:]], dim=1)
         pred_sem = torch.softmax(self.seg_model(self.b_all_rgbs), dim=1)
         fused = im.forward_paint(cur, pred_sem)
-        self.ring.index_copy_(0, self.b_slot, fused[None])
-        self.b_prev.copy_(self.b_tick)
-        sw = self.ring.index_select(0, self.b_sweeps)                                   # (3, 2P, 8)
-        xyz = torch.baddbmm(self.b_t, sw[..., :3], self.b_R)                            # xyz @ R + t  (move_lidar_points)
-        lidar_points = torch.cat([xyz, sw[..., 3:], self.b_onehot], dim=-1).view(-1, 11)
+        lidar_points = ops.stack_sweeps(fused, self.ring, self.b_slot, self.b_sweeps, self.b_R, self.b_t)
         lm = im.lidar_model
         canvas = lm.point_pillar_net([lidar_points], [lidar_points.shape[0]])
         if self.b_features is None:
@@ -184,22 +176,13 @@ class GraphedFramePipeline(FramePipeline):
         self.s_ego.wait_stream(main)
         with torch.cuda.stream(self.s_ego):
             ppm_f = up.pixels_per_meter / 2
-            ego_crop = up.crop_feature(features, features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, up.crop_size)
+            ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], ppm_f, up.crop_size)
             ego_embd = up.lidar_conv_emb(ego_crop)
             ego_cast = up.cast(ego_embd, mode="ego")
             ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
                                crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
         heat, size, ori, pred_bev = lm.heads(features)
-        hm = torch.sigmoid(heat[0])
-        rows = []
-        W = hm.size(2)
-        from .model_inference import extract_peak
-        for i in range(hm.size(0)):
-            score, loc = extract_peak(hm[i])
-            ys, xs = torch.div(loc, W, rounding_mode="floor"), loc % W
-            rows.append(torch.stack([score, xs.float(), ys.float(), size[0, 0, ys, xs], size[0, 1, ys, xs],
-                                     ori[0, 0, ys, xs], ori[0, 1, ys, xs]], dim=1))
-        det_raw = torch.stack(rows)                                                     # (2, 15, 7)
+        det_raw = ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True)       # (2, 15, 7)
         # brake net: forked from the event recorded after the first node, one stream per trunk (wide / tele image).
         # Captured last on purpose: hipGraph was observed to start sibling branches in capture order, one after the
         # other, when they are captured before the main chain.
@@ -252,10 +235,10 @@ class GraphedFramePipeline(FramePipeline):
                 dloc = (np.asarray(loc, np.float64) - loc0) @ np.array([[math.cos(ori0), -math.sin(ori0)], [math.sin(ori0), math.cos(ori0)]])
                 o = ori - ori0
                 Rs.append([[math.cos(o), math.sin(o), 0.], [-math.sin(o), math.cos(o), 0.], [0., 0., 1.]])
-                ts.append([[float(dloc[0]), float(dloc[1]), 0.]])
+                ts.append([float(dloc[0]), float(dloc[1]), 0.])
                 sweeps.append((slot - age) % self.num_frame_keep)
             else:  # history not that deep yet: point at a slot that is still all-NaN (never written) or stale-free
-                Rs.append([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]]); ts.append([[0., 0., 0.]])
+                Rs.append([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]]); ts.append([0., 0., 0.])
                 sweeps.append((slot - age) % self.num_frame_keep)
         self.b_slot.copy_(torch.tensor([slot]), non_blocking=True)
         self.b_sweeps.copy_(torch.tensor(sweeps), non_blocking=True)
@@ -314,20 +297,4 @@ class GraphedFramePipeline(FramePipeline):
                     pred_bra=oa["pred_bra"], lidar_points=oa["lidar_points"])
 
     def _decode(self, det_rows, min_score=0.2):
-        """Filters of InferModel.det_inference (model_inference.py:95-121) on the host rows."""
-        ppm = self.infer_model.pixels_per_meter
-        dets = []
-        for i, rows in enumerate(det_rows):
-            det = []
-            for s, x, y, w, h, cos, sin in rows:
-                if not s > min_score:
-                    continue
-                x, y = int(x), int(y)
-                if i == 1 and max(w, h) < 0.1 * ppm:
-                    continue
-                dist = np.linalg.norm([x - 160, y - 280])
-                if dist <= 2 or dist >= 30 * ppm:
-                    continue
-                det.append((x, y, w, h, cos, sin))
-            dets.append(det)
-        return dets
+        return self.infer_model.det_decode(det_rows, min_score)

@@ -101,20 +101,19 @@ class InferModel(nn.Module):
         canvas = lm.point_pillar_net([lidar_points], [len(lidar_points)])
         features = lm.backbone(canvas)
         heat, size, ori, pred_bev = lm.heads(features)
-        det = self.det_inference(torch.sigmoid(heat[0]), size[0], ori[0])
+        det = self.det_decode(ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True).cpu().tolist())
         ego_embd, ego_plan, ego_cast, other_cast, other_cmds = self.uniplanner.infer_all(features[0], det[1], cmd_value, nxps)
         return ego_embd, ego_plan, ego_cast, other_cast, other_cmds, pred_bev, det
 
     def det_inference(self, heatmaps, sizemaps, orimaps, min_score=0.2):
         """Peaks -> [(x, y, w, h, cos, sin)] per class with the reference's score/size/range filters
-        (model_inference.py:95-121).  One device->host copy per class instead of four per peak."""
+        (model_inference.py:95-121): one lav_extract_peaks launch and one device->host copy for all classes."""
+        return self.det_decode(ops.extract_peaks(heatmaps, sizemaps, orimaps).cpu().tolist(), min_score)
+
+    def det_decode(self, det_rows, min_score=0.2):
+        """Host half of det_inference: the score / size / range filters on (ncls, 15, 7) rows."""
         dets = []
-        W = heatmaps.size(2)
-        for i, c in enumerate(heatmaps):
-            score, loc = extract_peak(c)
-            ys, xs = torch.div(loc, W, rounding_mode="floor"), loc % W
-            rows = torch.stack([score, xs.float(), ys.float(), sizemaps[0, ys, xs], sizemaps[1, ys, xs],
-                                orimaps[0, ys, xs], orimaps[1, ys, xs]], dim=1).cpu().tolist()
+        for i, rows in enumerate(det_rows):
             det = []
             for s, x, y, w, h, cos, sin in rows:
                 if not s > min_score:

@@ -40,7 +40,8 @@ def _workspace(key, nbytes: int, device) -> torch.Tensor:
     k = (key, device, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(k)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        # zero-filled: the split-K convolution keeps arrival counters at the end of its buffer (zero between launches)
+        ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=device)
         _workspaces[k] = ws
     return ws
 
@@ -255,4 +256,49 @@ def crop_rotate(features: torch.Tensor, locs: torch.Tensor, oris: torch.Tensor, 
     out = torch.empty((n, Cc, crop, crop), dtype=torch.float32, device=features.device)
     check(lib.lav_crop_rotate(_ptr(features), fb, Cc, H, W, _ptr(locs), _ptr(oris), n, float(pixels_per_meter), int(crop),
                               float(offset_x), float(offset_y), _ptr(out), _stream()), "lav_crop_rotate")
+    return out
+
+
+def merge_ticks(tick: torch.Tensor, prev: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """cat([tick, prev]) with ego-box points marked x = NaN; then prev <- tick, in place.  tick, prev (P,4)."""
+    lib = _lib.load()
+    tick, prev = _f32c(tick, "tick"), _f32c(prev, "prev")
+    if tick.shape != prev.shape or tick.dim() != 2 or tick.shape[1] != 4:
+        raise RuntimeError(f"merge_ticks: tick {tuple(tick.shape)} / prev {tuple(prev.shape)} must both be (P, 4)")
+    P = tick.shape[0]
+    if out is None:
+        out = torch.empty((2 * P, 4), dtype=torch.float32, device=tick.device)
+    check(lib.lav_merge_ticks(_ptr(tick), _ptr(prev), P, 4, _ptr(out), _stream()), "lav_merge_ticks")
+    return out
+
+
+def stack_sweeps(fused: torch.Tensor, ring: torch.Tensor, slot: torch.Tensor, sweeps: torch.Tensor, R: torch.Tensor,
+                 t: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """History write + temporal stacking: fused (rows,8), ring (slots,rows,8), slot (1,) int64, sweeps (S,) int64,
+    R (S,3,3), t (S,3) - all in HBM -> (S*rows, 8+S)."""
+    lib = _lib.load()
+    fused, ring, R, t = _f32c(fused, "fused"), _f32c(ring, "ring"), _f32c(R, "R"), _f32c(t.reshape(-1, 3), "t")
+    S, rows, dim = sweeps.numel(), fused.shape[0], fused.shape[1]
+    if ring.shape[1:] != fused.shape or slot.dtype != torch.long or sweeps.dtype != torch.long or R.shape != (S, 3, 3):
+        raise RuntimeError("stack_sweeps: inconsistent arguments")
+    if out is None:
+        out = torch.empty((S * rows, dim + S), dtype=torch.float32, device=fused.device)
+    check(lib.lav_stack_sweeps(_ptr(fused), _ptr(ring), _ptr(slot), _ptr(sweeps), _ptr(R), _ptr(t), S, rows, dim, _ptr(out),
+                               _stream()), "lav_stack_sweeps")
+    return out
+
+
+def extract_peaks(heat: torch.Tensor, size: torch.Tensor, ori: torch.Tensor, ks: int = 7, max_det: int = 15,
+                  apply_sigmoid: bool = False) -> torch.Tensor:
+    """heat (ncls,H,W), size (cs,H,W), ori (co,H,W) -> (ncls, max_det, 3+cs+co) rows (score, x, y, size.., ori..)."""
+    lib = _lib.load()
+    heat, size, ori = _f32c(heat, "heat"), _f32c(size, "size"), _f32c(ori, "ori")
+    ncls, H, W = heat.shape
+    if size.shape[1:] != (H, W) or ori.shape[1:] != (H, W):
+        raise RuntimeError("extract_peaks: size / ori maps must match the heat map")
+    out = torch.empty((ncls, max_det, 3 + size.shape[0] + ori.shape[0]), dtype=torch.float32, device=heat.device)
+    nbytes = lib.lav_extract_peaks_workspace_bytes(ncls, H, W)
+    ws = _workspace("peaks", nbytes, heat.device)
+    check(lib.lav_extract_peaks(_ptr(heat), ncls, H, W, ks, max_det, int(apply_sigmoid), _ptr(size), size.shape[0], _ptr(ori),
+                                ori.shape[0], _ptr(out), _ptr(ws), ws.numel(), _stream()), "lav_extract_peaks")
     return out

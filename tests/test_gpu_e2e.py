@@ -135,7 +135,12 @@ def test_graphed_frame_pipeline_matches_eager(models):
         if a is None:
             assert b is None
             continue
-        assert a["det"][0] == b["det"][0] and [d[:2] for d in a["det"][1]] == [d[:2] for d in b["det"][1]], f"frame {i}"
+        # the eager path stacks sweeps with a torch matmul, the graphed one with lav_stack_sweeps: xyz may differ in the
+        # last bit, so pixel positions must agree exactly and the regressed maps within float noise
+        for c in range(2):
+            assert [d[:2] for d in a["det"][c]] == [d[:2] for d in b["det"][c]], f"frame {i} class {c}"
+            assert_close(np.array([d[2:] for d in b["det"][c]]), np.array([d[2:] for d in a["det"][c]]), atol=1e-5,
+                         what=f"frame {i} det {c}")
         for k in ("ego_plan_locs", "ego_cast_locs", "other_cast_locs", "other_cast_cmds", "pred_bra"):
-            assert_close(b[k].cpu().numpy(), a[k].cpu().numpy(), atol=2e-5, what=f"frame {i} {k}")
+            assert_close(b[k].cpu().numpy(), a[k].cpu().numpy(), atol=2e-5, rtol=2e-6, what=f"frame {i} {k}")
         assert_close(b["pred_bev"].cpu().numpy(), a["pred_bev"].cpu().numpy(), atol=1e-5, what=f"frame {i} pred_bev")
