@@ -12,6 +12,8 @@
 // All three are HBM streaming / latency work: coalesced 16-byte loads, no LDS except for the NMS halo tile and the
 // final top-k selection.  Compiled with -ffp-contract=off: the rotation below is two roundings per product-sum exactly
 // as written, like the oracle.
+#include <algorithm>
+
 #include "common.hpp"
 
 #pragma clang fp contract(off)
@@ -96,13 +98,14 @@ __device__ __forceinline__ float unordered(unsigned k) {
 
 struct PeakArgs {
     const float *heat, *size, *ori;
-    int ncls, H, W, ks, max_det, apply_sigmoid, size_c, ori_c;
+    int ncls, H, W, ks, max_det, apply_sigmoid, size_c, ori_c, lds_cand;
     float *out;                       // [ncls][max_det][3 + size_c + ori_c]
     unsigned long long *cand;         // [ncls][H*W]
     int *count;                       // [ncls] + ticket at [ncls]
 };
 
 __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
+    extern __shared__ __align__(16) unsigned char dyn_smem[];  // candidate keys of one class (last workgroup only)
     __shared__ unsigned long long s_u64[256];
     __shared__ float s_tile[(PT_H + PEAK_MAX_KS - 1) * (PT_W + PEAK_MAX_KS - 1)];
     __shared__ int s_flag;
@@ -159,9 +162,19 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
     __syncthreads();
     if (!s_flag) return;
     const int ncol = 3 + a.size_c + a.ori_c;
+    // final selection by the last workgroup: candidates of one class into LDS (when they fit), then max_det rounds of
+    // "largest key below the previous pick" - wave reduction by DPP shuffles, one barrier per round
+    unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(dyn_smem);
     for (int c = 0; c < a.ncls; ++c) {
         const int n = min(__hip_atomic_load(&a.count[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.H * a.W);
         const unsigned long long *cand = a.cand + (long)c * a.H * a.W;
+        const bool in_lds = n <= a.lds_cand;
+        __syncthreads();
+        if (in_lds) {
+            for (int j = tid; j < n; j += 256) s_cand[j] = cand[j];
+            __syncthreads();
+            cand = s_cand;
+        }
         unsigned long long bound = ~0ull;  // keys are unique (they carry the pixel index): select strictly below the last pick
         for (int d = 0; d < a.max_det; ++d) {
             unsigned long long best = 0;
@@ -169,14 +182,16 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
                 const unsigned long long k = cand[j];
                 if (k < bound && k > best) best = k;
             }
-            s_u64[tid] = best;
-            __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if (tid < w) s_u64[tid] = max(s_u64[tid], s_u64[tid + w]);
-                __syncthreads();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)best, off), hi = __shfl_xor((unsigned)(best >> 32), off);
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                best = o > best ? o : best;
             }
-            best = s_u64[0];
+            unsigned long long *slot = s_u64 + (d & 1) * 4;  // two slot sets: one barrier per round is enough
+            if ((tid & 63) == 0) slot[tid >> 6] = best;
             __syncthreads();
+            best = max(max(slot[0], slot[1]), max(slot[2], slot[3]));
             float *row = a.out + ((long)c * a.max_det + d) * ncol;
             if (tid < ncol) {
                 float v;
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
                 }
                 row[tid] = v;
             }
-            bound = best ? best : 0;
+            bound = best;
         }
     }
     if (tid <= a.ncls) __hip_atomic_store(&a.count[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
@@ -251,7 +266,10 @@ extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int 
     a.count = reinterpret_cast<int *>(static_cast<char *>(workspace) + workspace_bytes - align_up((size_t)(ncls + 1) * sizeof(int), 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("extract_peaks", st);
-    hipLaunchKernelGGL(k_extract_peaks, dim3((w + PT_W - 1) / PT_W, (h + PT_H - 1) / PT_H, ncls), dim3(256), 0, st, a);
+    const dim3 grid((w + PT_W - 1) / PT_W, (h + PT_H - 1) / PT_H, ncls);
+    // every tile contributes at most max_det candidates; keep them in LDS for the final selection when <= 48 KB
+    a.lds_cand = (int)std::min<long>((long)grid.x * grid.y * max_det, 6144);
+    hipLaunchKernelGGL(k_extract_peaks, grid, dim3(256), (size_t)a.lds_cand * sizeof(unsigned long long), st, a);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

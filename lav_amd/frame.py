@@ -105,13 +105,18 @@ class GraphedFramePipeline(FramePipeline):
     """Same frame as FramePipeline.step, replayed from HIP graphs (torch.cuda.graphs captures the torch ops and the
     liblav_amd launches alike: both are enqueued on the capturing stream).
 
-    graph A  (one per command value, captured lazily): everything that does not depend on the detections -
-             half-sweep concat, ego-box marking, ERFNet+softmax, painting, history ring update, 3-sweep stacking,
-             pillar scatter, BEV backbone+heads, peak extraction into a fixed (2,15,7) tensor, the ego crop ->
-             ResNet-18 -> cast -> plan, and the brake net.
-    host     one device->host copy of the peak tensor, the reference's score/size/range filters
-             (model_inference.py:95-144), N = number of other vehicles.
-    graph B  (one per N, captured lazily): N rotated crops -> ResNet-18 -> cast -> command scores -> ego frame.
+    Five linear graphs on three HIP streams instead of one graph with internal branches (hipGraph replays sibling
+    branches of ONE graph poorly on this stack: every cross-branch edge becomes a signal wait and branches start in
+    capture order; separate in-order streams overlap the way hardware queues do):
+
+      main   lidar      merge ticks, ERFNet + softmax, painting, history + 3-sweep stacking, pillar scatter, BEV backbone
+      main   heads      fused heads, peak extraction into a fixed (2,15,7) tensor
+      s_bra  brake      the brake net (needs only the camera images)
+      s_ego  ego[cmd]   ego crop -> ResNet-18 -> cast -> plan; starts when the feature map exists (one per command)
+      main   others[N]  after the host decoded the peaks: N rotated crops -> ResNet-18 -> cast -> command scores
+
+    host:  one device->host copy of the peak tensor, the reference's score/size/range filters
+           (model_inference.py:95-144), N = number of other vehicles.
 
     Static shapes: every LiDAR tick is padded to `points_per_tick` rows with NaN (NaN fails the pillar range test
     exactly like an absent point; all downstream results are independent of point count and order), the ego-box
@@ -134,12 +139,15 @@ class GraphedFramePipeline(FramePipeline):
         self.b_sweeps = torch.zeros((num_sweeps := self.num_frame_stack + 1,), dtype=torch.long, device=dev)
         self.b_R = torch.zeros((num_sweeps, 3, 3), **f)
         self.b_t = torch.zeros((num_sweeps, 3), **f)
-        self.b_features = None   # (1,384,160,160): shared by every frame graph, read by the others-graphs
+        self.b_features = None   # (1,384,160,160): written by the lidar graph, read by heads / ego / others
         self.b_locs = torch.zeros((15, 2), **f)
-        self.b_zero = torch.zeros((1, 4), **f)   # the ego vehicle's own (loc, ori)
         self.b_oris = torch.zeros((15,), **f)
-        self.graphs_a, self.graphs_b, self.out_a, self.out_b = {}, {}, {}, {}
-        self.pool = None
+        self.b_zero = torch.zeros((1, 4), **f)   # the ego vehicle's own (loc, ori)
+        # capture streams double as workspace keys (lav_amd.ops._workspace): graphs that run concurrently must not
+        # share split-K scratch, graphs of one stream may
+        self.s_cap, self.s_bra, self.s_ego = (torch.cuda.Stream(dev) for _ in range(3))
+        self.ev_in, self.ev_feat = torch.cuda.Event(), torch.cuda.Event()
+        self.graphs, self.outs = {}, {}
         self.frame_no = 0
         self.poses = deque()
 
@@ -150,58 +158,38 @@ class GraphedFramePipeline(FramePipeline):
             self.frame_no = 0
             self.poses = deque()
 
-    # ---- graph A -------------------------------------------------------------------------------------------
-    def _part_a(self, cmd_value):
-        """The frame graph.  Three HIP streams: the LiDAR chain (seg -> paint -> pillar -> BEV -> heads -> peaks) on
-        the capturing stream, the brake net (independent of everything else) and, once the feature map exists, the ego
-        branch (crop -> ResNet-18 -> cast -> plan) on side streams - most of these kernels are small and
-        latency-bound, so the chains overlap almost for free."""
-        im = self.infer_model
-        main = torch.cuda.current_stream()
-        if not hasattr(self, "s_bra"):
-            self.s_bra, self.s_bra2, self.s_ego = (torch.cuda.Stream(self.device) for _ in range(3))
+    # ---- the graphs' bodies --------------------------------------------------------------------------------
+    def _g_lidar(self):
+        im, lm = self.infer_model, self.infer_model.lidar_model
         cur = ops.merge_ticks(self.b_tick, self.b_prev)                 # concat + ego box + prev <- tick: one launch
-        fork_ev = torch.cuda.Event()
-        fork_ev.record(main)      # the brake trunks depend on nothing but this point; they are CAPTURED at the end
         pred_sem = torch.softmax(self.seg_model(self.b_all_rgbs), dim=1)
         fused = im.forward_paint(cur, pred_sem)
         lidar_points = ops.stack_sweeps(fused, self.ring, self.b_slot, self.b_sweeps, self.b_R, self.b_t)
-        lm = im.lidar_model
         canvas = lm.point_pillar_net([lidar_points], [lidar_points.shape[0]])
         if self.b_features is None:
             self.b_features = torch.empty((1, lm.backbone.out_channels, canvas.shape[2] // 2, canvas.shape[3] // 2),
                                           dtype=torch.float32, device=canvas.device)
-        features = lm.backbone(canvas, out=self.b_features)
-        up = self.infer_model.uniplanner
-        self.s_ego.wait_stream(main)
-        with torch.cuda.stream(self.s_ego):
-            ppm_f = up.pixels_per_meter / 2
-            ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], ppm_f, up.crop_size)
-            ego_embd = up.lidar_conv_emb(ego_crop)
-            ego_cast = up.cast(ego_embd, mode="ego")
-            ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
-                               crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
-        heat, size, ori, pred_bev = lm.heads(features)
-        det_raw = ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True)       # (2, 15, 7)
-        # brake net: forked from the event recorded after the first node, one stream per trunk (wide / tele image).
-        # Captured last on purpose: hipGraph was observed to start sibling branches in capture order, one after the
-        # other, when they are captured before the main chain.
-        bra = self.bra_model
-        self.s_bra.wait_event(fork_ev)
-        self.s_bra2.wait_event(fork_ev)
-        with torch.cuda.stream(self.s_bra):
-            x1 = bra.conv_backbone(bra.normalize(self.b_rgbs / 255.))
-        with torch.cuda.stream(self.s_bra2):
-            x2 = bra.conv_backbone(bra.normalize(self.b_tel / 255.))
-        self.s_bra.wait_stream(self.s_bra2)
-        with torch.cuda.stream(self.s_bra):
-            pred_bra = bra.classifier(torch.cat([bra.attn1(x1), bra.attn2(x2)], dim=1))[:, 0]
-        main.wait_stream(self.s_bra)
-        main.wait_stream(self.s_ego)
-        return dict(features=features, det_raw=det_raw, pred_bev=pred_bev, ego_embd=ego_embd, ego_plan_locs=ego_plan,
-                    ego_cast_locs=ego_cast[0, int(cmd_value)], pred_bra=pred_bra, lidar_points=lidar_points)
+        lm.backbone(canvas, out=self.b_features)
+        return dict(lidar_points=lidar_points)
 
-    def _part_b(self, n):
+    def _g_heads(self):
+        heat, size, ori, pred_bev = self.infer_model.lidar_model.heads(self.b_features)
+        return dict(det_raw=ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True), pred_bev=pred_bev)  # (2,15,7)
+
+    def _g_brake(self):
+        bra = self.bra_model
+        return dict(pred_bra=bra(self.b_rgbs, self.b_tel))
+
+    def _g_ego(self, cmd_value):
+        up, features = self.infer_model.uniplanner, self.b_features
+        ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], up.pixels_per_meter / 2, up.crop_size)
+        ego_embd = up.lidar_conv_emb(ego_crop)
+        ego_cast = up.cast(ego_embd, mode="ego")
+        ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
+                           crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
+        return dict(ego_embd=ego_embd, ego_plan_locs=ego_plan, ego_cast_locs=ego_cast[0, int(cmd_value)])
+
+    def _g_others(self, n):
         up = self.infer_model.uniplanner
         feats = self.b_features
         locs, oris = self.b_locs[:n], self.b_oris[:n]
@@ -213,13 +201,26 @@ class GraphedFramePipeline(FramePipeline):
         cast = transform_points(cast, oris[:, None].repeat(1, up.num_cmds)) + locs.view(n, 1, 1, 2)
         return dict(other_cast_locs=cast, other_cast_cmds=cmds)
 
-    def _capture(self, fn, *args):
-        # every graph gets a PRIVATE memory pool: graphs that share one may only be replayed in capture order, and
-        # here a later-captured frame graph (new command value) runs before earlier-captured others-graphs
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = fn(*args)
-        return g, out
+    def _replay(self, key, fn, stream, *args):
+        """Replay graph `key` on the current stream; first use: one eager run on the capture stream (builds the
+        convolution engines and the per-stream workspaces), then the capture.  Every graph has a PRIVATE memory pool:
+        graphs that share one may only be replayed in capture order."""
+        g = self.graphs.get(key)
+        if g is None:
+            torch.cuda.synchronize()
+            state = (self.ring.clone(), self.b_prev.clone())   # the lidar graph advances these: undo the two extra runs
+            with torch.cuda.stream(stream):
+                fn(*args)
+            torch.cuda.synchronize()
+            self.ring.copy_(state[0]); self.b_prev.copy_(state[1])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                out = fn(*args)
+            torch.cuda.synchronize()
+            self.ring.copy_(state[0]); self.b_prev.copy_(state[1])
+            self.graphs[key], self.outs[key] = g, out
+        g.replay()
+        return self.outs[key]
 
     def _set_pose_buffers(self):
         """History indices and the float32 rotation / translation of every stacked sweep (lav_agent_fast.py:363-383,
@@ -262,39 +263,37 @@ class GraphedFramePipeline(FramePipeline):
             self.poses.popleft()
         self._set_pose_buffers()
         cmd_value = int(cmd_value)
-        if cmd_value not in self.graphs_a:
-            # one eager run (builds engines / workspaces), restore the state it advanced, then capture
-            state = (self.ring.clone(), self.b_prev.clone())
-            self._part_a(cmd_value)
-            torch.cuda.synchronize()
-            self.ring.copy_(state[0]); self.b_prev.copy_(state[1])
-            self.graphs_a[cmd_value], self.out_a[cmd_value] = self._capture(self._part_a, cmd_value)
-            self.ring.copy_(state[0]); self.b_prev.copy_(state[1])
-        self.graphs_a[cmd_value].replay()
-        oa = self.out_a[cmd_value]
+        main = torch.cuda.current_stream()
+        self.ev_in.record(main)                                        # inputs are in their static buffers
+        o_lidar = self._replay("lidar", self._g_lidar, self.s_cap)
+        self.s_bra.wait_event(self.ev_in)
+        with torch.cuda.stream(self.s_bra):
+            o_bra = self._replay("brake", self._g_brake, self.s_bra)
+        self.ev_feat.record(main)                                      # feature map complete
+        self.s_ego.wait_event(self.ev_feat)
+        with torch.cuda.stream(self.s_ego):
+            o_ego = self._replay(("ego", cmd_value), self._g_ego, self.s_ego, cmd_value)
+        o_heads = self._replay("heads", self._g_heads, self.s_cap)
         self.frame_no += 1
-        det_rows = oa["det_raw"].cpu().tolist()           # the frame's only blocking device->host copy before the others branch
+        det_rows = o_heads["det_raw"].cpu().tolist()      # the frame's only blocking device->host copy before the others branch
         det = self._decode(det_rows)
         up = self.infer_model.uniplanner
-        H, W = oa["features"].size(2) * 2, oa["features"].size(3) * 2
+        H, W = self.b_features.size(2) * 2, self.b_features.size(3) * 2
         locs, oris = up.others_from_detections(det[1], H, W)
         N = min(len(locs), 15)
         if N > 0:
             self.b_locs[:N].copy_(torch.tensor(locs[:N], dtype=torch.float32), non_blocking=True)
             self.b_oris[:N].copy_(torch.tensor(oris[:N], dtype=torch.float32), non_blocking=True)
-            if N not in self.graphs_b:
-                self._part_b(N)
-                torch.cuda.synchronize()
-                self.graphs_b[N], self.out_b[N] = self._capture(self._part_b, N)
-            self.graphs_b[N].replay()
-            ob = self.out_b[N]
+            ob = self._replay(("others", N), self._g_others, self.s_cap, N)
             other_cast, other_cmds = ob["other_cast_locs"], ob["other_cast_cmds"]
         else:
             other_cast = torch.zeros((0, up.num_cmds, up.num_plan, 2))
             other_cmds = torch.zeros((0, up.num_cmds))
-        return dict(ego_embd=oa["ego_embd"], ego_plan_locs=oa["ego_plan_locs"], ego_cast_locs=oa["ego_cast_locs"],
-                    other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=oa["pred_bev"], det=det,
-                    pred_bra=oa["pred_bra"], lidar_points=oa["lidar_points"])
+        main.wait_stream(self.s_ego)      # also keeps the next frame's input copies behind this frame's readers
+        main.wait_stream(self.s_bra)
+        return dict(ego_embd=o_ego["ego_embd"], ego_plan_locs=o_ego["ego_plan_locs"], ego_cast_locs=o_ego["ego_cast_locs"],
+                    other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=o_heads["pred_bev"],
+                    det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])
 
     def _decode(self, det_rows, min_score=0.2):
         return self.infer_model.det_decode(det_rows, min_score)

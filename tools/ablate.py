@@ -66,6 +66,8 @@ with torch.no_grad():
     timeit("brake attn+classifier", lambda: bra.classifier(torch.cat([bra.attn1(x1), bra.attn2(x2)], dim=1)))
     for n in (1, 2, 4):
         pipe.b_locs[:n] = torch.tensor([[5.0, 1.0]] * n, device=dev)
-        timeit(f"others branch N={n}", lambda: pipe._part_b(n))
-    state = (pipe.ring.clone(), pipe.b_prev.clone())
-    timeit("frame graph A (all)", lambda: pipe._part_a(3))
+        timeit(f"others graph N={n}", lambda: pipe._g_others(n))
+    timeit("lidar graph", pipe._g_lidar)
+    timeit("heads graph", pipe._g_heads)
+    timeit("ego graph", lambda: pipe._g_ego(3))
+    timeit("brake graph", pipe._g_brake)
