@@ -199,10 +199,37 @@ def main():
         lib.lav_profile_enable(0)
         nb = 4 * (len(pts) * 11 + 64 * 320 * 320)
         ks, ps = k_ms / max(k_n, 1) * 1e-3, p_ms / max(p_n, 1) * 1e-3
+        kept = int(((pts[:, 0] >= -10) & (pts[:, 0] < 70) & (pts[:, 1] >= -40) & (pts[:, 1] < 40)).sum())
+        fl = 10240.0 * kept    # PointNet: 2*(16*64 + 64*64) flop per kept point, on the matrix cores inside the same kernel
         return dict(points=len(pts), algorithmic_bytes=nb, kernel_us=round(ks * 1e6, 2), prep_us=round(ps * 1e6, 2),
                     achieved=round(nb / ks / 1e9, 1), frac=round(nb / ks / 1e9 / HBM_PEAK_GBS, 4),
-                    pipeline_achieved=round(nb / (ks + ps) / 1e9, 1), unit="GB/s", peak=HBM_PEAK_GBS)
+                    pipeline_achieved=round(nb / (ks + ps) / 1e9, 1), unit="GB/s", peak=HBM_PEAK_GBS,
+                    pointnet_flops=fl, pointnet_tflops=round(fl / ks / 1e12, 1),
+                    mfma_bound_us=round(fl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6, 2), hbm_bound_us=round(nb / (HBM_PEAK_GBS * 1e9) * 1e6, 2))
+    def conv_micro(reps=50):
+        """The frame's largest dense kernel in isolation: the fused 384->256 3x3 convolution of the four heads on the
+        (1,384,160,160) feature map - MFMA-bound, fp32 matrix peak 157.3 TFLOP/s."""
+        lm = pipe.infer_model.lidar_model
+        feats = torch.randn((1, 384, 160, 160), device=device)
+        lm.heads(feats)
+        layer = lm._eng["conv"]
+        for _ in range(3):
+            layer(feats)
+        torch.cuda.synchronize()
+        lib.lav_profile_enable(reps + 8)
+        layer(feats); torch.cuda.synchronize(); lib.lav_profile_reset()
+        for _ in range(reps):
+            layer(feats)
+        torch.cuda.synchronize()
+        ms, n = read("conv2d")
+        lib.lav_profile_enable(0)
+        flops = 2.0 * 160 * 160 * 256 * 384 * 9
+        sec = ms / max(n, 1) * 1e-3
+        return dict(bound="mfma", kernel="k_conv<2,2> heads 384->256 3x3 @160x160", achieved=round(flops / sec / 1e12, 1),
+                    peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                    traffic=None, algorithmic_flops=flops, avg_kernel_us=round(sec * 1e6, 1), launches=reps)
     micro = {"config2_32768pts": pillar_micro(10923), "agent_196608pts": pillar_micro(65536)} if rank == 0 else None
+    conv_roof = conv_micro() if rank == 0 else None
     # roofline of the dominant pillar kernel at the frame's own size (196 608 points).  The frame loop replays HIP
     # graphs (kernels inside a graph cannot carry event pairs), so the figure comes from the back-to-back launches
     # above on the same library stream: pure kernel time, no launch gaps.
@@ -222,8 +249,8 @@ def main():
                                         f"({n_pts} pts x 11) + 3x288x256 RGB + 288x480 tele; ERFNet seg, paint, pillar 320x320x64, "
                                         "BEV backbone+heads, uniplanner (cast+plan GRUs), brake net",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1]),
-                               launch="eager" if args.eager else "hip graphs (static frame graph + per-N others graph)"),
-                   roofline=roofline, roofline_pillar_isolated=micro, hip_kernel_us_per_frame=per_frame_us)
+                               launch="eager" if args.eager else "hip graphs: lidar / heads / others[N] on the main stream, brake and ego[cmd] on side streams"),
+                   roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, hip_kernel_us_per_frame=per_frame_us)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, host)
         else:

@@ -19,6 +19,8 @@
 // Epilogue (fused): +bias -> ReLU -> *scale+shift (eval BatchNorm; the reference puts BN AFTER the ReLU,
 // lidar.py:58-60, so it cannot be folded into the weights) -> +residual -> ReLU -> sigmoid, then a channel-
 // offset store (fused torch.cat of lidar.py:143).
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -35,6 +37,7 @@ constexpr int NPOS_MAX = 40;  // bound on staged input positions per thread (LDS
 
 struct ConvArgs {
     const float *x, *w, *bias, *scale, *shift, *res, *zero_page;
+    unsigned long long *trace;  // debug (LAV_CONV_TRACE): [workgroup][8] wall-clock stamps
     float *y;
     int in_c_total, in_c_offset, cin, H, W;
     int cout, out_c_total, out_c_offset, OH, OW;
@@ -83,8 +86,10 @@ __device__ __forceinline__ void mma_tap(const TapOps<MP, MC> &o, f32x16 (&acc)[M
                 acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[cp][mc], o.b[cp][mp], acc[mc][mp], 0, 0, 0);
 }
 
-template <int MP, int MC>
+template <int MP, int MC, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
+#define CONV_STAMP(i) do { if constexpr (TRACE) { if (threadIdx.x == 0) a.trace[(((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } } while (0)
+    CONV_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_T = 32 * MC, PIXW = 128 * MP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         issue_weights(0);
         if (a.in_bufs == 2) issue_input(0);
     }
+    CONV_STAMP(1);
     for (int stage = 0; stage < nstages; ++stage) {
         const int sc = stage / ngroups, grp = stage % ngroups;
         if (a.in_bufs == 1 && grp == 0) {  // single input buffer: everyone must be done with the previous chunks first
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
         // stage's DMA has landed for every wave, and every wave is done computing stage-1 (whose buffers stage+1 reuses)
         __syncthreads();  // hipcc drains vmcnt(0) ahead of the barrier because LDS-DMA is in flight
+        if (stage == 0) CONV_STAMP(2);
         if (stage + 1 < nstages) {
             issue_weights(stage + 1);
             if (a.in_bufs == 2 && grp == ngroups - 1) issue_input(sc + 1);
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
     }
 
+    CONV_STAMP(3);
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
     if (a.ksplit > 1) {  // raw partial sums [ks][n][cout][OH][OW]; k_conv_reduce adds them up and applies the epilogue
         const long plane_o = (long)a.OH * a.OW;
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                     if (pix_ok && co < a.cout) pbase[co * plane_o + (long)oy * a.OW + ox] = acc[mc][mp][r];
                 }
             }
+        CONV_STAMP(4);
         return;
     }
     const bool has_bias = a.bias != nullptr, has_aff = a.scale != nullptr, has_res = a.res != nullptr;
@@ -293,6 +302,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
             }
         }
     }
+    CONV_STAMP(4);
+#undef CONV_STAMP
 }
 
 // Split-K second pass: y = epilogue( sum_ks partial[ks] ), fixed summation order (deterministic).
@@ -483,7 +494,11 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         const int CO_T = 32 * MC;
         // keep the footprint at <= 64 KB so that workgroups of OTHER streams (the frame graph runs the brake net, the ego
         // branch and the LiDAR chain concurrently) can share the CU: a 160 KB workgroup monopolises its CU's LDS
-        const size_t budget = std::max<size_t>(lds, 64 * 1024);
+        // ... unless the whole layer is at most one workgroup per CU: then nothing of this layer queues behind the
+        // footprint, and staging more of K up front saves a barrier + DMA round trip per stage (small gain, measured)
+        static const size_t small_budget = [] { const char *e = getenv("LAV_CONV_SMALL_LDS_KB"); return (size_t)(e ? atoi(e) : 96) * 1024; }();
+        const bool one_wave = bg.nwg * a.ksplit <= 256;
+        const size_t budget = std::max<size_t>(lds, one_wave ? small_budget : 64 * 1024);
         int cps = 1;
         for (int cand : {2, 4, 8}) {
             if (cand > per_split * 2 - 1 && cand > per_split) break;
@@ -524,6 +539,40 @@ int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t 
     const int Q = p.QH * p.QW;
     dim3 grid(a.rowblock ? p.QH * a.xblocks : (Q + 128 * MP - 1) / (128 * MP), (a.cout + 32 * MC - 1) / (32 * MC), batch * p.nclasses * a.ksplit);
     const int tok = timer_begin("conv2d", st);
+    static const bool want_trace = getenv("LAV_CONV_TRACE") != nullptr;
+    if (want_trace) {  // debug: per-workgroup phase stamps of every 10th launch
+        static unsigned long long *d_trace = nullptr;
+        static int runs = 0;
+        static bool attr2 = false;
+        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)65536 * 8 * sizeof(unsigned long long)));
+        if (!attr2) {
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv<MP, MC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        if (nwg <= 65536) {
+            ConvArgs at = a;
+            at.trace = d_trace;
+            hipLaunchKernelGGL((k_conv<MP, MC, true>), grid, dim3(256), lds, st, at);
+            if (++runs % 10 == 0) {
+                std::vector<unsigned long long> h(nwg * 8);
+                if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (size_t i = 0; i < nwg; ++i) { t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 4]); }
+                    double ph[4] = {0, 0, 0, 0}, last_start = 0;
+                    for (size_t i = 0; i < nwg; ++i) {
+                        for (int k = 0; k < 4; ++k) ph[k] += (double)(h[i * 8 + k + 1] - h[i * 8 + k]) / 100.0;
+                        last_start = std::max(last_start, (double)(h[i * 8] - t0) / 100.0);
+                    }
+                    fprintf(stderr, "[conv trace] %zu wgs (%ux%ux%u) lds %zu KB ksplit %d cps %d: span %.2f us, last start %.2f | mean us: setup+issue %.2f | first stage wait %.2f | main loop %.2f | epilogue %.2f\n",
+                            nwg, grid.x, grid.y, grid.z, lds / 1024, a.ksplit, a.cps, (double)(t1 - t0) / 100.0, last_start, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg);
+                }
+            }
+            timer_end(tok, st);
+            LAV_LAUNCH_CHECK();
+            return LAV_OK;
+        }
+    }
     hipLaunchKernelGGL((k_conv<MP, MC>), grid, dim3(256), lds, st, a);
     if (a.ksplit > 1) {
         const long total = (long)batch * a.cout * p.OH * p.OW;
@@ -618,6 +667,7 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
             LAV_HIP(hipMemset(zero_page, 0, 256));
         }
         a.zero_page = zero_page;
+        a.trace = nullptr;
     }
     for (int i = 0; i < MAX_CLASSES; ++i) {
         const bool live = i < p.nclasses;

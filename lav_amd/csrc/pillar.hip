@@ -36,7 +36,9 @@
 // round up to exactly nx (resp. ny) - y = nextafter(40,0) with min_y=-40 gives yi = 320 - the key space has one
 // extra row and column; the canvas write clamps them like the reference (:89) and lets the LATER pillar in unique
 // order win, by processing such "overflow" cells as extra layers after the regular ones.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -63,6 +65,7 @@ struct PillarArgs {
     int nx, ny;  // nx = number of xi cells = canvas columns; ny = number of yi cells = canvas rows
     int KX, KY;  // key space (nx+1) x (ny+1)
     int T, TW;   // column tiles per canvas row, columns per tile
+    unsigned long long *trace;  // debug (LAV_PILLAR_TRACE): [ntiles][8] wall-clock stamps of thread 0, else null
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -203,7 +206,7 @@ __device__ __forceinline__ void decorate(const PillarArgs &a, const float *pt, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int D, bool USE_MFMA>
+template <int D, bool USE_MFMA, bool TRACE = false>
 __global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const float *__restrict__ rec,
                                                           const int *__restrict__ tile_offset,
                                                           const float *__restrict__ w1, const float *__restrict__ b1,
@@ -228,15 +231,20 @@ __global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const fl
     const int c1 = min(a.nx, c0 + TW);
     const int tw = c1 - c0;  // live columns in this tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+#define LAV_STAMP(i) do { if constexpr (TRACE) { if (tid == 0) a.trace[(long)wg * 8 + (i)] = wall_clock64(); } } while (0)
+    LAV_STAMP(0);
     const int p0 = tile_offset[wg * NSUB], p1 = tile_offset[(wg + 1) * NSUB];
+    if constexpr (TRACE) { if (tid == 0) a.trace[(long)wg * 8 + 7] = (unsigned long long)(p1 - p0); }
     float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
     const long cstride = (long)a.ny * a.nx;
 
     if (p0 == p1) {  // empty tile: stream zeros (workgroup-uniform)
         for (int ch = wid; ch < C; ch += 4)
             for (int j = lane; j < tw; j += 64) dst[ch * cstride + j] = 0.f;
+        LAV_STAMP(6);
         return;
     }
+    LAV_STAMP(1);
     // Issue every global load that depends only on (p0, p1) before touching LDS, so the workgroup pays ONE memory
     // round trip here instead of one per phase: layer-2 weights, layer-1 weights, this thread's record for the
     // sums sweep and this lane's record for the wave's first PointNet pass.
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const fl
         for (int j = tid; j < TW * 3; j += 256) sums[j] = 0ull;
         for (int j = tid; j < TW; j += 256) cnt[j] = 0;
         __syncthreads();
+        if (L == 0) LAV_STAMP(2);
         // (a) per-cell coordinate sums and counts of this layer (first 256 records were prefetched)
         for (int j = p0 + tid; j < p1; j += 256) {
             float x, y, z;
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const fl
             }
         }
         __syncthreads();
+        if (L == 0) LAV_STAMP(3);
 
         if constexpr (!USE_MFMA) {
             // cross-check path: one point per thread, plain fp32 FMAs (slow; selected by LAV_PILLAR_IMPL=valu)
@@ -428,7 +438,9 @@ __global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const fl
             }
         }
     }
+    LAV_STAMP(4);
     __syncthreads();
+    LAV_STAMP(5);
     // (d) stream the tile out; canvas [B][C][ny][nx]
 #pragma unroll 4
     for (int ch = wid; ch < C; ch += 4) {
@@ -436,6 +448,8 @@ __global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const fl
         float *d = dst + ch * cstride;
         for (int j = lane; j < tw; j += 64) d[j] = src[j];
     }
+    LAV_STAMP(6);
+#undef LAV_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -567,7 +581,12 @@ __global__ void k_counts(const int *p_total, const int *kept_total, int *counts)
 }
 
 void tile_geometry(int nx, int &T, int &TW) {
-    T = (nx + TILE_MAX_W - 1) / TILE_MAX_W;
+    static const int max_w = [] {  // experiment knob: LAV_PILLAR_TW=<columns per tile>
+        const char *e = getenv("LAV_PILLAR_TW");
+        const int v = e ? atoi(e) : 0;
+        return v >= 4 && v <= 320 ? v : TILE_MAX_W;
+    }();
+    T = (nx + max_w - 1) / max_w;
     const int tw = (nx + T - 1) / T;
     TW = (tw + 3) / 4 * 4;
 }
@@ -603,6 +622,40 @@ bool use_valu_impl() {
     return e && e[0] == 'v';
 }
 
+// debug: per-workgroup phase times of one k_tile_pointnet launch (100 MHz wall clock -> us)
+void dump_trace(const unsigned long long *d_trace, int ntiles, hipStream_t st) {
+    std::vector<unsigned long long> h((size_t)ntiles * 8);
+    if (hipStreamSynchronize(st) != hipSuccess) return;
+    if (hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long t0 = ~0ull, tend = 0;
+    for (int i = 0; i < ntiles; ++i) { t0 = std::min(t0, h[i * 8]); tend = std::max(tend, h[i * 8 + 6]); }
+    auto us = [&](unsigned long long t) { return (double)(t - t0) / 100.0; };
+    fprintf(stderr, "[pillar trace] %d tiles, span %.1f us\n", ntiles, us(tend));
+    int nempty = 0; double e_start = 0, e_dur = 0, e_last = 0;
+    double ph[6] = {0, 0, 0, 0, 0, 0}, n_start_max = 0, n_end_max = 0; int nn = 0;
+    struct Row { double start, end; unsigned long long n; double p[6]; };
+    std::vector<Row> rows;
+    for (int i = 0; i < ntiles; ++i) {
+        const unsigned long long *r = &h[i * 8];
+        if (r[7] == 0) { ++nempty; e_start += us(r[0]); e_dur += (double)(r[6] - r[0]) / 100.0; e_last = std::max(e_last, us(r[6])); continue; }
+        Row w; w.start = us(r[0]); w.end = us(r[6]); w.n = r[7];
+        for (int k = 0; k < 6; ++k) { w.p[k] = (double)(r[k + 1] - r[k]) / 100.0; ph[k] += w.p[k]; }
+        n_start_max = std::max(n_start_max, w.start); n_end_max = std::max(n_end_max, w.end); ++nn; rows.push_back(w);
+    }
+    fprintf(stderr, "  empty tiles %d: mean start %.1f us, mean duration %.2f us, last end %.1f us\n", nempty, nempty ? e_start / nempty : 0, nempty ? e_dur / nempty : 0, e_last);
+    fprintf(stderr, "  tiles with points %d: last start %.1f us, last end %.1f us; mean phase us: offsets %.2f | prefetch+init %.2f | sums+means %.2f | pointnet %.2f | barrier %.2f | stream-out issue %.2f\n",
+            nn, n_start_max, n_end_max, ph[0] / std::max(nn, 1), ph[1] / std::max(nn, 1), ph[2] / std::max(nn, 1), ph[3] / std::max(nn, 1), ph[4] / std::max(nn, 1), ph[5] / std::max(nn, 1));
+    std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.end > y.end; });
+    for (size_t i = 0; i < std::min<size_t>(rows.size(), 8); ++i)
+        fprintf(stderr, "  late tile: n=%llu start %.1f end %.1f | %.2f %.2f %.2f %.2f %.2f %.2f\n", rows[i].n, rows[i].start, rows[i].end, rows[i].p[0], rows[i].p[1], rows[i].p[2], rows[i].p[3], rows[i].p[4], rows[i].p[5]);
+    // start-time histogram (2 us bins)
+    std::vector<int> hist(40, 0);
+    for (int i = 0; i < ntiles; ++i) hist[std::min<size_t>(39, (size_t)(us(h[i * 8]) / 2.0))]++;
+    fprintf(stderr, "  starts per 2 us:");
+    for (int i = 0; i < 40; ++i) if (hist[i]) fprintf(stderr, " [%d]=%d", i * 2, hist[i]);
+    fprintf(stderr, "\n");
+}
+
 template <int D>
 int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, hipStream_t st) {
     const long total = (long)a.batch * a.max_points;
@@ -628,9 +681,26 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     if (!attr_set) {
         LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
+    static const bool want_trace = getenv("LAV_PILLAR_TRACE") != nullptr;
+    static unsigned long long *d_trace = nullptr;
+    static int trace_runs = 0;
+    PillarArgs at = a;
+    if (want_trace) {
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)ntiles * 8 * sizeof(unsigned long long)));
+        LAV_HIP(hipMemsetAsync(d_trace, 0, (size_t)ntiles * 8 * sizeof(unsigned long long), st));
+        at.trace = d_trace;
+    }
     const int tok = timer_begin("pointnet_scatter", st);
+    if (want_trace) {
+        hipLaunchKernelGGL((k_tile_pointnet<D, true, true>), dim3(ntiles), dim3(256), lds, st, at, w.rec, w.tile_offset, net->w1, net->b1, net->w2, net->b2, canvas);
+        timer_end(tok, st);
+        LAV_LAUNCH_CHECK();
+        if (++trace_runs == 20) dump_trace(d_trace, ntiles, st);
+        return LAV_OK;
+    }
     if (use_valu_impl())
         hipLaunchKernelGGL((k_tile_pointnet<D, false>), dim3(ntiles), dim3(256), lds, st, a, w.rec, w.tile_offset, net->w1, net->b1, net->w2, net->b2, canvas);
     else
@@ -669,6 +739,7 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
     if (!workspace || !ar.ok()) return fail(LAV_EWORKSPACE, "lav_pillar_scatter: workspace %zu < %zu bytes", workspace_bytes, ar.used);
 
     PillarArgs a;
+    a.trace = nullptr;
     a.points = points;
     a.batch = batch;
     a.max_points = max_points;
