@@ -248,7 +248,9 @@ class GraphedFramePipeline(FramePipeline):
 
     @torch.no_grad()
     def step(self, lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value):
-        n = min(int(lidar.shape[0]), self.P)
+        n = int(lidar.shape[0])
+        if n > self.P:
+            raise RuntimeError(f"LiDAR tick of {n} points exceeds the static graph buffers (points_per_tick={self.P})")
         self.b_tick[:n].copy_(lidar[:n], non_blocking=True)
         if n < self.P:
             self.b_tick[n:].fill_(float("nan"))

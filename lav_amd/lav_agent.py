@@ -1,0 +1,262 @@
+"""LAVAgent - the leaderboard entry point of team_code_v2/lav_agent_fast.py on the MI355X path.
+
+Same surface (SURVEY.md 8b level B1): module-level get_entry_point(), class LAVAgent(AutonomousAgent) with sensors(),
+setup(path_to_conf_file), run_step(input_data, timestamp) -> VehicleControl, destroy().  Everything the reference does
+on the GPU in run_step (:233-323) is one call of lav_amd.frame.GraphedFramePipeline.step; the host side (EKF pose,
+route/command tracking, PID, the brake / collision / creep overrides) is restated in lav_amd/agent/.
+
+Differences, all deliberate: no wandb / OpenCV video logging (flush_data and visualize are no-ops); the two camera
+networks are loaded from state_dicts (`seg_model_dir`, `bra_model_dir`) instead of TorchScript traces, because the HIP
+convolution engines are built from the modules' parameters; `synthetic_weights: true` in the config replaces missing
+checkpoint files by seeded random weights (tests, benchmarks - the released checkpoints are git-LFS objects).
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from . import synth
+from .agent import EKF, AutonomousAgent, PIDController, RoutePlanner, Track, VehicleControl, Waypointer
+from .bev_planner import BEVPlanner
+from .frame import GAP, FramePipeline, GraphedFramePipeline
+from .lidar import LiDARModel
+from .rgb import RGBBrakePredictionModel, RGBSegmentationModel
+from .uniplanner import UniPlanner
+
+CAMERA_YAWS = [-60, 0, 60]
+
+# team_code_v2/config.yaml - the keys the agent reads
+DEFAULT_CONFIG = dict(
+    num_plan=20, num_cmds=6, camera_x=1.5, camera_z=2.4, seg_channels=[4, 6, 7, 10], crop_size=96, num_plan_iter=5,
+    cmd_thresh=0.2, backbone="cnn", min_x=-10, max_x=70, min_y=-40, max_y=40, pixels_per_meter=4, num_frame_stack=2,
+    feature_x_jitter=1.5, feature_angle_jitter=20, crop_tel_bottom=96, point_painting=True, num_features=[64, 64],
+    aim_point=[4, 4, 4, 3, 6, 6], turn_KP=0.8, turn_KI=0.5, turn_KD=0.2, turn_n=40, speed_KP=5.0, speed_KI=0.5,
+    speed_KD=1.0, speed_n=40, brake_speed=0.2, brake_ratio=1.1, clip_delta=0.25, max_throttle=0.8, max_speed=35,
+    speed_ratio=[0.8, 0.8, 0.8, 0.6, 0.8, 0.8], lidar_model_dir="weights/lidar_v2_7.th",
+    uniplanner_dir="weights/uniplanner_v2_7.th", bra_model_dir="weights/bra_v2_9.th", seg_model_dir="weights/seg_1.th",
+    synthetic_weights=False, hip_graphs=True, points_per_tick=32768, log_wandb=False)
+
+
+def get_entry_point():
+    return "LAVAgent"
+
+
+def _rotate(x, y, theta):
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, -s], [s, c]]) @ [x, y]
+
+
+class LAVAgent(AutonomousAgent):
+    # ---------------------------------------------------------------------------------------------- leaderboard API
+    def sensors(self):
+        pose = dict(x=0.0, y=0.0, z=self.camera_z)
+        cam = dict(x=self.camera_x, y=0.0, z=self.camera_z, roll=0.0, pitch=0.0, height=288)
+        out = [{"type": "sensor.speedometer", "id": "EGO"},
+               {"type": "sensor.other.gnss", **pose, "id": "GPS"},
+               {"type": "sensor.other.imu", **pose, "roll": 0.0, "pitch": 0.0, "yaw": 0.0, "sensor_tick": 0.05, "id": "IMU"},
+               {"type": "sensor.lidar.ray_cast", **pose, "yaw": 0.0, "pitch": 0.0, "roll": 0.0, "id": "LIDAR"}]
+        out += [{"type": "sensor.camera.rgb", **cam, "yaw": yaw, "width": 256, "fov": 64, "id": f"RGB_{i}"}
+                for i, yaw in enumerate(CAMERA_YAWS)]
+        out.append({"type": "sensor.camera.rgb", **cam, "yaw": 0.0, "width": 480, "fov": 40, "id": "TEL_RGB"})
+        return out
+
+    def setup(self, path_to_conf_file):
+        self.track = Track.SENSORS
+        config = dict(DEFAULT_CONFIG)
+        if path_to_conf_file:
+            with open(path_to_conf_file, "r") as f:
+                config.update(yaml.safe_load(f) or {})
+        for key, value in config.items():
+            setattr(self, key, value)
+        if not torch.cuda.is_available():
+            raise RuntimeError("LAVAgent: no HIP device - the lav_amd path has no CPU fallback")
+        self.device = torch.device("cuda")
+        self.waypointer = self.planner = None
+
+        y_off = 1 + self.min_x / ((self.max_x - self.min_x) / 2)
+        self.lidar_model = LiDARModel(
+            num_input=len(self.seg_channels) + 10 + self.num_frame_stack if self.point_painting else 10,
+            backbone=self.backbone, num_features=self.num_features, min_x=self.min_x, max_x=self.max_x,
+            min_y=self.min_y, max_y=self.max_y, pixels_per_meter=self.pixels_per_meter)
+        planner_args = dict(pixels_per_meter=self.pixels_per_meter, crop_size=self.crop_size,
+                            feature_x_jitter=self.feature_x_jitter, feature_angle_jitter=self.feature_angle_jitter,
+                            x_offset=0, y_offset=y_off, num_cmds=self.num_cmds, num_plan=self.num_plan,
+                            num_plan_iter=self.num_plan_iter)
+        bev_planner = BEVPlanner(num_frame_stack=self.num_frame_stack, **planner_args)
+        self.uniplanner = UniPlanner(bev_planner, num_input_feature=self.num_features[-1] * 6, **planner_args)
+        self.seg_model = RGBSegmentationModel(self.seg_channels)
+        self.bra_model = RGBBrakePredictionModel(self.seg_channels)
+        for module, path, prefix in ((self.lidar_model, self.lidar_model_dir, "lidar."),
+                                     (self.uniplanner, self.uniplanner_dir, "uni."),
+                                     (self.seg_model, self.seg_model_dir, "seg."),
+                                     (self.bra_model, self.bra_model_dir, "bra.")):
+            module.load_state_dict(self._checkpoint(module, path, prefix))
+            module.eval().to(self.device)
+
+        extra = dict(points_per_tick=self.points_per_tick) if self.hip_graphs else {}
+        cls = GraphedFramePipeline if self.hip_graphs else FramePipeline
+        self.pipeline = cls(self.lidar_model, self.uniplanner, self.seg_model, self.bra_model, self.camera_x,
+                            self.camera_z, num_frame_stack=self.num_frame_stack, device=self.device, **extra)
+        self.infer_model = self.pipeline.infer_model
+        self.coord_converters = self.infer_model.coord_converters
+
+        self.ekf = EKF(1, 1.477531, 1.393600)      # cos0 = 1 rad (sic), lf, lr (lav_agent_fast.py:141)
+        self.ekf_initialized = False
+        self.vizs = []
+        self.num_frames = 0
+        self.num_frame_keep = (self.num_frame_stack + 1) * GAP
+        self.turn_controller = PIDController(K_P=self.turn_KP, K_I=self.turn_KI, K_D=self.turn_KD, n=self.turn_n)
+        self.speed_controller = PIDController(K_P=self.speed_KP, K_I=self.speed_KI, K_D=self.speed_KD, n=self.speed_n)
+        self.lane_change_counter = 0
+        self.stop_counter = 0
+        self.force_move = 0
+        self.lane_changed = None
+        self.last_outputs = None
+
+    def _checkpoint(self, module, path, prefix):
+        if path and os.path.exists(path):
+            return torch.load(path, map_location="cpu")
+        if self.synthetic_weights:
+            return synth.seeded_state_dict(module, prefix=prefix)
+        raise FileNotFoundError(f"LAVAgent: checkpoint {path!r} not found (set synthetic_weights: true for seeded random weights)")
+
+    def flush_data(self):
+        self.vizs.clear()
+
+    def destroy(self):
+        self.waypointer = self.planner = None
+        self.turn_controller = self.speed_controller = None
+        self.num_frames = 0
+        self.lane_change_counter = self.stop_counter = self.force_move = 0
+        self.lane_changed = None
+        self.ekf = None
+        self.ekf_initialized = False
+        self.pipeline = self.infer_model = self.coord_converters = None
+        for name in ("lidar_model", "uniplanner", "bra_model", "seg_model"):
+            if hasattr(self, name):
+                delattr(self, name)
+        torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------------------------------------- one 20 Hz tick
+    @torch.no_grad()
+    def run_step(self, input_data, timestamp):
+        self.num_frames += 1
+        _, lidar = input_data.get("LIDAR")
+        _, gps = input_data.get("GPS")
+        _, imu = input_data.get("IMU")
+        _, ego = input_data.get("EGO")
+        spd = ego.get("speed")
+        compass = imu[-1]
+        if np.isnan(compass):          # CARLA reports NaN for a heading of exactly 0 / 2 pi
+            compass = 0.0
+        if not self.ekf_initialized:
+            self.ekf.init(*gps[:2], compass - math.pi / 2)
+            self.ekf_initialized = True
+        loc, ori = self.ekf.x[:2].copy(), float(self.ekf.x[2])
+        self.stop_counter = self.stop_counter + 1 if spd < 0.1 else 0
+
+        lidar = torch.from_numpy(np.ascontiguousarray(lidar, dtype=np.float32)).to(self.device)
+        if self.num_frames <= 1:       # first tick: only half a sweep exists (:235-237)
+            self.pipeline.step(lidar, None, None, None, loc, ori, None, 3)
+            return VehicleControl()
+
+        # camera images: BGRA uint8 -> RGB float, three views side by side for the brake net, stacked for ERFNet
+        bgr = [torch.from_numpy(np.ascontiguousarray(input_data.get(f"RGB_{i}")[1][..., :3])) for i in range(len(CAMERA_YAWS))]
+        views = torch.stack(bgr).to(self.device).flip(-1)                             # (3,288,256,3) RGB
+        all_rgbs = views.permute(0, 3, 1, 2).float()
+        rgbs = torch.cat(list(views), dim=1)[None].permute(0, 3, 1, 2).float()        # (1,3,288,768)
+        tel = torch.from_numpy(np.ascontiguousarray(input_data.get("TEL_RGB")[1][..., :3])).to(self.device).flip(-1)
+        tel_rgbs = tel[:-self.crop_tel_bottom][None].permute(0, 3, 1, 2).float()      # (1,3,192,480)
+
+        # high-level command and next route point (:280-307)
+        if self.waypointer is None:
+            self.waypointer = Waypointer(self._global_plan, gps, pop_lane_change=True)
+            self.planner = RoutePlanner(self._global_plan)
+        _, _, cmd = self.waypointer.tick(gps)
+        wx, wy = self.planner.run_step(gps)
+        cmd_value = cmd.value - 1
+        cmd_value = 3 if cmd_value < 0 else cmd_value
+        if cmd_value in (4, 5):
+            if self.lane_changed is not None and cmd_value != self.lane_changed:
+                self.lane_change_counter = 0
+            self.lane_change_counter += 1
+            self.lane_changed = cmd_value if self.lane_change_counter > 300 else None
+        else:
+            self.lane_change_counter = 0
+            self.lane_changed = None
+        if cmd_value == self.lane_changed:
+            cmd_value = 3
+        wx, wy = _rotate(wx, wy, -imu[-1] + np.pi / 2)
+        nxps = torch.tensor([-wx, -wy], dtype=torch.float32, device=self.device)
+
+        out = self.pipeline.step(lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value)
+        self.last_outputs = out
+        ego_plan_locs = out["ego_plan_locs"].cpu().numpy()
+        ego_cast_locs = out["ego_cast_locs"].cpu().numpy()
+        other_cast_locs = out["other_cast_locs"].cpu().numpy()
+        other_cast_cmds = out["other_cast_cmds"].cpu().numpy()
+        pred_bra = float(out["pred_bra"])
+
+        if cmd_value in (4, 5):
+            ego_plan_locs = ego_cast_locs
+        if not np.isnan(ego_plan_locs).any():
+            steer, throt, brake = self.pid_control(ego_plan_locs, spd, cmd_value)
+            steer, throt, brake = self.pid_control(ego_plan_locs, spd, cmd_value)   # sic: the reference steps its PIDs twice (:318-326)
+        else:
+            steer, throt, brake = 0, 0, 0
+        self.ekf.step(spd, steer, *gps[:2], compass - math.pi / 2)
+
+        if pred_bra > 0.1:
+            throt, brake = 0, 1
+        elif self.plan_collide(ego_plan_locs, other_cast_locs, other_cast_cmds):
+            throt, brake = 0, 1
+        if spd * 3.6 > self.max_speed:
+            throt = 0
+        if self.stop_counter >= 600:   # stuck for 30 s: creep forward
+            self.force_move = 20
+        if self.force_move > 0:
+            throt, brake = max(0.4, throt), 0
+            self.force_move -= 1
+        return VehicleControl(steer=steer, throttle=throt, brake=brake)
+
+    # ---------------------------------------------------------------------------------------------- host-side rules
+    def plan_collide(self, ego_plan_locs, other_cast_locs, other_cast_cmds, dist_threshold_static=1.0,
+                     dist_threshold_moving=2.5):
+        """Brake if any sufficiently likely forecast of a vehicle ahead comes close to the ego plan (:366-384)."""
+        for other_trajs, other_cmds in zip(other_cast_locs, other_cast_cmds):
+            if other_trajs[0, 0][1] > 0.5 * self.pixels_per_meter:     # behind the ego vehicle
+                continue
+            for traj, score in zip(other_trajs, other_cmds):
+                if score < self.cmd_thresh:
+                    continue
+                speed = np.linalg.norm(traj[1:] - traj[:-1], axis=-1).mean()
+                limit = dist_threshold_static if speed < self.brake_speed else dist_threshold_moving
+                if np.linalg.norm(traj - ego_plan_locs, axis=-1).min() < limit:
+                    return True
+        return False
+
+    def pid_control(self, waypoints, speed, cmd):
+        """Waypoints (metres, ego frame) -> steer / throttle / brake (:387-410)."""
+        wp = np.copy(waypoints) * self.pixels_per_meter
+        wp[:, 1] *= -1
+        desired_speed = np.linalg.norm(wp[1:] - wp[:-1], axis=1).mean()
+        aim = wp[self.aim_point[cmd]]
+        angle = np.degrees(np.pi / 2 - np.arctan2(aim[1], aim[0])) / 90
+        steer = np.clip(self.turn_controller.step(angle), -1.0, 1.0)
+        brake = desired_speed < self.brake_speed * self.pixels_per_meter
+        delta = np.clip(desired_speed * self.speed_ratio[cmd] - speed, 0.0, self.clip_delta)
+        throttle = np.clip(self.speed_controller.step(delta), 0.0, self.max_throttle)
+        throttle = throttle if not brake else 0.0
+        return float(steer), float(throttle), float(brake)
+
+    def preprocess(self, lidar_xyzr):
+        """Ego-box removal with the reference's compaction semantics (:450-452)."""
+        from .frame import ego_box_mask
+        return lidar_xyzr[~ego_box_mask(lidar_xyzr)]
+
+    def visualize(self, *a, **k):
+        return None

@@ -169,3 +169,42 @@ def _owner(module: torch.nn.Module, key: str):
     for part in key.split(".")[:-1]:
         m = getattr(m, part) if not part.isdigit() else m[int(part)]
     return m
+
+
+def agent_scenario():
+    """Seeded inputs of the host-glue fixtures (shared with tests/test_agent_host.py): a GNSS route with commands,
+    a noisy drive along it, EKF / PID input streams."""
+    rng = np.random.default_rng(2021)
+    n = 48
+    lat0, lon0 = 0.0012, -0.0007
+    step = 6.0 / 6371e3 * 180 / np.pi                     # ~6 m between plan nodes
+    heading = np.cumsum(rng.normal(0, 0.08, n))
+    lat = lat0 + np.cumsum(np.cos(heading)) * step
+    lon = lon0 + np.cumsum(np.sin(heading)) * step
+    cmds = np.full(n, 4)                                  # LANEFOLLOW
+    cmds[8:11] = 1; cmds[18:20] = 5; cmds[27:30] = 2; cmds[36:38] = 6; cmds[42:44] = 3
+    # the drive: 12 ticks per plan segment, GNSS noise of ~0.3 m
+    t = np.linspace(0, n - 1.001, 12 * n)
+    i0 = t.astype(int); f = t - i0
+    gps = np.stack([lat[i0] * (1 - f) + lat[i0 + 1] * f, lon[i0] * (1 - f) + lon[i0 + 1] * f, np.zeros_like(t)], 1)
+    gps[:, :2] += rng.normal(0, 0.3 / 6371e3 * 180 / np.pi, (len(t), 2))
+    ekf_in = np.stack([rng.uniform(0, 8, 300), rng.uniform(-0.6, 0.6, 300)], 1)      # speed, steer
+    ekf_gps = gps[:300, :2].copy()
+    ekf_compass = 0.3 + np.cumsum(rng.normal(0, 0.01, 300))
+    pid_err = rng.normal(0, 0.4, 120)
+    return dict(lat=lat, lon=lon, cmds=cmds, gps=gps, ekf_in=ekf_in, ekf_gps=ekf_gps, ekf_compass=ekf_compass, pid_err=pid_err)
+
+
+def agent_inputs(i, scenario=None, n_points=8192):
+    """input_data of leaderboard tick i (sensor id -> (frame, payload)) along agent_scenario()'s drive."""
+    sc = scenario if scenario is not None else agent_scenario()
+    cams, tel = rgb_frames()
+    g = sc["gps"][i]
+    g_next = sc["gps"][min(i + 1, len(sc["gps"]) - 1)]
+    compass = float(np.arctan2(g_next[1] - g[1], g_next[0] - g[0]) + np.pi / 2)
+    imu = np.array([0.0, 0.0, 9.8, 0.0, 0.0, 0.0, compass])
+    data = {"LIDAR": (i, lidar_sweep(n_points, name=f"agent{i}")), "GPS": (i, g.copy()), "IMU": (i, imu),
+            "EGO": (i, {"speed": 3.0 + 2.0 * np.sin(0.1 * i)}), "TEL_RGB": (i, np.roll(tel, 7 * i, axis=1))}
+    for k, c in enumerate(cams):
+        data[f"RGB_{k}"] = (i, np.roll(c, 5 * i, axis=1))
+    return data

@@ -235,6 +235,37 @@ def gold_rgb():
          logits_sum=t2n(logits.double().sum((2, 3))), pred_bra=t2n(pred_bra))
 
 
+def gold_agent():
+    """Host glue of the agent: the reference's own ekf.py / pid.py / planner.py / waypointer.py on the seeded scenario."""
+    from ekf import EKF  # noqa: E402  (reference)
+    from pid import PIDController  # noqa: E402  (reference)
+    from planner import RoutePlanner  # noqa: E402  (reference)
+    from waypointer import Waypointer  # noqa: E402  (reference)
+    from agents.navigation.local_planner import RoadOption
+    sc = synth.agent_scenario()
+    ekf = EKF(1, 1.477531, 1.393600)
+    ekf.init(*sc["ekf_gps"][0], sc["ekf_compass"][0] - np.pi / 2)
+    xs = []
+    for (spd, steer), (la, lo), comp in zip(sc["ekf_in"], sc["ekf_gps"], sc["ekf_compass"]):
+        ekf.step(spd, steer, la, lo, comp - np.pi / 2)
+        xs.append(ekf.x.copy())
+    pid_a = PIDController(K_P=0.8, K_I=0.5, K_D=0.2, n=40)
+    pid_b = PIDController(K_P=5.0, K_I=0.5, K_D=1.0, n=3)
+    pa = [pid_a.step(e) for e in sc["pid_err"]]
+    pb = [pid_b.step(e) for e in sc["pid_err"]]
+    plan = [({"lat": la, "lon": lo, "z": 0.0}, RoadOption(int(c))) for la, lo, c in zip(sc["lat"], sc["lon"], sc["cmds"])]
+    rp = RoutePlanner(plan)
+    wp = Waypointer(plan, sc["gps"][0], pop_lane_change=True)
+    wp2 = Waypointer(plan, sc["gps"][0], pop_lane_change=False, pop_turning=True)
+    r_out, w_out, w2_out = [], [], []
+    for g in sc["gps"]:
+        r_out.append(rp.run_step(g))
+        dx, dy, c = wp.tick(g); w_out.append([dx, dy, c.value])
+        dx, dy, c = wp2.tick(g); w2_out.append([dx, dy, c.value])
+    save("agent", ekf_x=np.array(xs), pid_a=np.array(pa), pid_b=np.array(pb), route=np.array(r_out),
+         waypointer=np.array(w_out), waypointer_turn=np.array(w2_out), gps_crc=np.array([crc(sc["gps"])]))
+
+
 def gold_keys(lm, up):
     import json
     seg = RGBSegmentationModel([4, 6, 7, 10]); bra = RGBBrakePredictionModel([4, 6, 7, 10])
@@ -245,6 +276,9 @@ def gold_keys(lm, up):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["agent"]:     # only the host-glue fixture
+        gold_agent()
+        sys.exit(0)
     lm, up = build_reference()
     gold_keys(lm, up)
     gold_pillar(lm)
@@ -253,3 +287,4 @@ if __name__ == "__main__":
     gold_planner(lm, up, feat)
     gold_e2e(lm, up)
     gold_rgb()
+    gold_agent()
