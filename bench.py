@@ -112,6 +112,32 @@ def cpu_baseline(sds, host, budget_s=20.0):
                 sample=f"{len(times)} full frames of the oracle (numpy pillar/paint + torch-CPU conv/GRU), median of all but the first; 32k-pt ticks, 3 cams")
 
 
+def train_bench(args):
+    """BASELINE.json metric (ii): samples/s of train_full_v2 (global batch 32 at 8 GPUs = 4 per GPU) / train_bev_v2
+    (64 at 8 GPUs = 8 per GPU) on synthetic batches; weak scaling - the per-GPU batch is fixed, one process per GPU,
+    gradient all-reduce over RCCL.  One step = forward + backward + Adam (+ the reference's per-step eval inference for
+    train_full).  Dense layers run on torch autograd (MIOpen/rocBLAS) in this round: a measured baseline for the
+    training row, not a hand-kernel number."""
+    from lav_amd.train.run import train_loop
+    what = "lidar" if args.mode == "train_full" else "bev"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    per = args.batch or (4 if what == "lidar" else 8)
+    steps = args.steps if args.steps != 100 else 10
+    warmup = min(args.warmup, 3)
+    dt, info, (rank, world) = train_loop(what, per * world, steps, warmup)
+    if rank == 0:
+        print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
+                              unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
+                                          + (", 120000-point clouds, 320x320 maps" if what == "lidar" else ", (9,320,320) BEV"),
+                                          parallelism=f"dp{world}", loss=round(info["loss"], 4)),
+                              roofline=None, cpu_baseline=None)))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +145,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train_full", "train_bev"],
+                    help="infer: BASELINE metric (i) frames/s; train_full / train_bev: metric (ii) samples/s, data parallel")
+    ap.add_argument("--batch", type=int, default=None, help="training modes: per-GPU batch (default 4 for train_full, 8 for train_bev)")
     args = ap.parse_args()
+    if args.mode != "infer":
+        return train_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

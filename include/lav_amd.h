@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 3
+#define LAV_ABI_VERSION 4
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -224,6 +224,32 @@ size_t lav_extract_peaks_workspace_bytes(int ncls, int h, int w);
 int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max_det, int apply_sigmoid,
                       const float *size, int size_c, const float *ori, int ori_c, float *out, void *workspace,
                       size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 7. Training-side pillar ops: what PointPillarNet needs in train mode, where BatchNorm1d uses batch
+ *    statistics and therefore cannot be folded into the fused inference kernel.  They replace the two
+ *    torch_scatter calls and coords.unique(dim=0) of lav/models/point_pillar.py:55-68, 81-85, 33 and give
+ *    autograd what it needs (arg-max for the backward of scatter_max).
+ *
+ * lav_pillar_decorate: grid_locations + pillar_generation + decorate (point_pillar.py:55-85).
+ *    points [batch][max_points][D]; outputs sized for the worst case (batch*max_points rows):
+ *    unique_coords [P][3] = (cloud, xi, yi) sorted like torch.unique(dim=0); inverse [N_kept] pillar of each kept
+ *    point; kept_src [N_kept] flat index (cloud*max_points + row) of each kept point - kept points stay in input
+ *    order; decorated [N_kept][D+5] = (point, xyz - pillar mean, x - cell_x, y - cell_y) with the reference's swapped
+ *    cell origin; counts [2] (device) = {P, N_kept}.  Pillar means are the same order-independent fixed-point sums as
+ *    in lav_pillar_scatter.  Workspace: lav_pillar_workspace_bytes.  Any output except decorated/counts may be NULL.
+ *
+ * lav_scatter_max: out[s][c] = max over rows i with index[i] == s of src[i][c]; argmax[s][c] = the lowest such row
+ *    (n for an empty segment, whose out is 0 - torch_scatter's convention).  src [n][channels], index [n] int32.
+ * lav_scatter_max_backward: grad_src[argmax[s][c]][c] = grad_out[s][c], zero elsewhere.
+ * ------------------------------------------------------------------------------------------ */
+int lav_pillar_decorate(const float *points, const int *h_num_points, int batch, int max_points, int D,
+                        const lav_grid *grid, int *unique_coords, int *inverse, int *kept_src, float *decorated,
+                        int *counts, void *workspace, size_t workspace_bytes, void *stream);
+int lav_scatter_max(const float *src, const int *index, int n, int channels, int num_segments, float *out, int *argmax,
+                    void *stream);
+int lav_scatter_max_backward(const float *grad_out, const int *argmax, int n, int channels, int num_segments,
+                             float *grad_src, void *stream);
 
 #ifdef __cplusplus
 }

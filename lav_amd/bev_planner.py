@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .lidar import _Engine
-from .planner_common import DecoderMixin, crop_feature
+from .planner_common import DecoderMixin, crop_feature, crop_feature_torch, sample_others
 from .resnet import resnet18
 
 
@@ -51,6 +51,8 @@ class BEVPlanner(DecoderMixin, _Engine):
 
     def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
         ox, oy = self.offsets()
+        if self.training:   # autograd path (affine_grid + grid_sample)
+            return crop_feature_torch(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
         return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
 
     @torch.no_grad()
@@ -61,3 +63,25 @@ class BEVPlanner(DecoderMixin, _Engine):
         cast = self.cast(embd)
         plan = self.plan(embd, nxps, cast_locs=cast, pixels_per_meter=self.pixels_per_meter, crop_size=self.crop_size * 2)
         return plan, cast, self.cast_cmd_pred(embd)
+
+    def forward(self, bev, ego_locs, locs, oris, nxps, typs):
+        """Training forward of the privileged planner (bev_planner_v2.py:72-174): forecasts for up to `max_num_cars`
+        jittered crops around other vehicles and the ego plan from the un-jittered ego crop.
+        bev (B,9,320,320), ego_locs (B,T+1,2), locs (B,N+1,T+1,2), oris (B,N+1), nxps (B,2), typs (B,N+1)."""
+        pick, N = sample_others(self, ego_locs, locs, oris, typs)
+        ppm, crop = self.pixels_per_meter, self.crop_size * 2
+        if pick is not None:
+            flat_bev = bev[:, None].expand(-1, N, -1, -1, -1)[pick["typs"]]
+            other_embd = self.bev_conv_emb(self.crop_feature(flat_bev, pick["crop_locs"], pick["crop_oris"], ppm, crop))
+            other_locs = pick["other_locs"]
+            other_cast_locs, other_cast_cmds = self.cast(other_embd), self.cast_cmd_pred(other_embd)
+        else:
+            z = dict(dtype=bev.dtype, device=bev.device)
+            other_locs = torch.zeros((N, self.num_plan, 2), **z)
+            other_cast_locs = torch.zeros((N, self.num_cmds, self.num_plan, 2), **z)
+            other_cast_cmds = torch.zeros((N, self.num_cmds), **z)
+        B = bev.size(0)
+        ego_embd = self.bev_conv_emb(self.crop_feature(bev, bev.new_zeros((B, 2)), bev.new_zeros((B,)), ppm, crop))
+        ego_cast_locs = self.cast(ego_embd)
+        ego_plan_locs = self.plan(ego_embd, nxps, cast_locs=ego_cast_locs, pixels_per_meter=ppm, crop_size=crop)
+        return other_locs, other_cast_locs, other_cast_cmds, ego_plan_locs, ego_cast_locs, self.cast_cmd_pred(ego_embd)

@@ -595,6 +595,7 @@ struct Workspace {
     int *tile_count, *tile_offset, *key, *slot;
     float *rec;
     int *cell_count, *cell_rank, *kept_rank, *block_sums, *totals;
+    unsigned long long *cell_sums;  // [min(ncells, points)][3] fixed-point coordinate sums (training entry lav_pillar_decorate)
 };
 
 size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid *g) {
@@ -614,6 +615,7 @@ size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid 
     w.kept_rank = ar.take<int>(total + 1);
     w.block_sums = ar.take<int>((nmax + SCAN_TILE - 1) / SCAN_TILE + 1);
     w.totals = ar.take<int>(4);
+    w.cell_sums = ar.take<unsigned long long>((ncells < total ? ncells : total) * 3 + 3);
     return align_up(ar.used, 256);
 }
 
@@ -796,5 +798,190 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
             LAV_LAUNCH_CHECK();
         }
     }
+    return LAV_OK;
+}
+
+// =========================================================================================================
+// Training-side entry points: the torch_scatter ABI the reference's PointPillarNet uses in train mode
+// (lav/models/point_pillar.py:55-68 decorate + scatter_mean, :33 scatter_max), with what autograd needs.
+// =========================================================================================================
+namespace {
+__global__ __launch_bounds__(256) void k_keys(PillarArgs a, int *__restrict__ key) {
+    const long total = (long)a.batch * a.max_points;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int b = (int)(gid / a.max_points);
+    const int i = (int)(gid - (long)b * a.max_points);
+    int k = -1;
+    if (i < a.n[b]) {
+        const float *pt = a.points + gid * a.D;
+        k = cell_key(a, b, pt[0], pt[1]);
+    }
+    key[gid] = k;
+}
+
+__global__ __launch_bounds__(256) void k_dec_sums(PillarArgs a, const int *__restrict__ key, const int *__restrict__ cell_rank,
+                                                  const int *__restrict__ kept_rank, unsigned long long *__restrict__ sums,
+                                                  int *__restrict__ inverse, int *__restrict__ kept_src) {
+    const long total = (long)a.batch * a.max_points;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int k = key[gid];
+    if (k < 0) return;
+    const int p = cell_rank[k], j = kept_rank[gid];
+    if (inverse) inverse[j] = p;
+    if (kept_src) kept_src[j] = (int)gid;
+    const float *pt = a.points + gid * a.D;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        atomicAdd(&sums[(long)p * 3 + d], (unsigned long long)__double2ll_rn((double)pt[d] * FIX_SCALE));
+}
+
+__global__ __launch_bounds__(256) void k_dec_write(PillarArgs a, const int *__restrict__ key, const int *__restrict__ cell_rank,
+                                                   const int *__restrict__ cell_count, const int *__restrict__ kept_rank,
+                                                   const unsigned long long *__restrict__ sums, float *__restrict__ out) {
+    const long total = (long)a.batch * a.max_points;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int k = key[gid];
+    if (k < 0) return;
+    const int b = (int)(gid / a.max_points);
+    const int cellk = k - b * a.KX * a.KY;
+    const int xi = cellk / a.KY, yi = cellk - xi * a.KY;
+    const int p = cell_rank[k], n = cell_count[k];
+    const float *pt = a.points + gid * a.D;
+    float *o = out + (long)kept_rank[gid] * (a.D + 5);
+    for (int d = 0; d < a.D; ++d) o[d] = pt[d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float mean = (float)((double)(long long)sums[(long)p * 3 + d] / ((double)n * FIX_SCALE));
+        o[a.D + d] = pt[d] - mean;
+    }
+    o[a.D + 3] = pt[0] - ((float)yi / a.ppm + a.min_x);  // sic: swapped, un-centred (point_pillar.py:57-58)
+    o[a.D + 4] = pt[1] - ((float)xi / a.ppm + a.min_y);
+}
+
+__device__ __forceinline__ unsigned ord_f(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__global__ __launch_bounds__(256) void k_smax_init(unsigned *__restrict__ out_u, int *__restrict__ argmax, long pc, int n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < pc) { out_u[i] = 0u; argmax[i] = n; }
+}
+__global__ __launch_bounds__(256) void k_smax_max(const float *__restrict__ src, const int *__restrict__ index, long nc, int C,
+                                                  unsigned *__restrict__ out_u) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nc) return;
+    const long i = e / C;
+    const int c = (int)(e - i * C);
+    atomicMax(&out_u[(long)index[i] * C + c], ord_f(src[e]));
+}
+__global__ __launch_bounds__(256) void k_smax_arg(const float *__restrict__ src, const int *__restrict__ index, long nc, int C,
+                                                  const unsigned *__restrict__ out_u, int *__restrict__ argmax) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nc) return;
+    const long i = e / C;
+    const int c = (int)(e - i * C);
+    const long o = (long)index[i] * C + c;
+    if (ord_f(src[e]) == out_u[o]) atomicMin(&argmax[o], (int)i);  // ties: lowest source row (deterministic)
+}
+__global__ __launch_bounds__(256) void k_smax_fin(unsigned *__restrict__ out_u, const int *__restrict__ argmax, long pc, int n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pc) return;
+    const float v = argmax[i] < n ? unord_f(out_u[i]) : 0.f;  // empty segment: 0, argmax = n (torch_scatter's convention)
+    out_u[i] = __float_as_uint(v);
+}
+__global__ __launch_bounds__(256) void k_smax_bwd(const float *__restrict__ grad_out, const int *__restrict__ argmax, long pc, int C,
+                                                  int n, float *__restrict__ grad_src) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pc) return;
+    const int a = argmax[i];
+    if (a < n) grad_src[(long)a * C + (i % C)] = grad_out[i];  // every source element is the arg-max of at most one output
+}
+}  // namespace
+
+extern "C" int lav_pillar_decorate(const float *points, const int *h_num_points, int batch, int max_points, int D,
+                                   const lav_grid *grid, int *unique_coords, int *inverse, int *kept_src, float *decorated,
+                                   int *counts, void *workspace, size_t workspace_bytes, void *stream) {
+    LAV_REQUIRE(grid && h_num_points && counts && decorated, "lav_pillar_decorate: null argument");
+    LAV_REQUIRE(batch >= 1 && batch <= MAX_BATCH, "lav_pillar_decorate: batch %d outside [1,%d]", batch, MAX_BATCH);
+    LAV_REQUIRE(max_points >= 0 && (points || max_points == 0) && D >= 3 && D < REC_MAX, "lav_pillar_decorate: bad points");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Arena ar(workspace, workspace_bytes);
+    Workspace w;
+    carve(ar, w, batch, max_points, grid);
+    if (!workspace || !ar.ok()) return fail(LAV_EWORKSPACE, "lav_pillar_decorate: workspace %zu < %zu bytes", workspace_bytes, ar.used);
+    PillarArgs a;
+    a.trace = nullptr;
+    a.points = points; a.batch = batch; a.max_points = max_points; a.D = D;
+    for (int b = 0; b < MAX_BATCH; ++b) a.n[b] = b < batch ? (h_num_points[b] < max_points ? h_num_points[b] : max_points) : 0;
+    for (int b = 0; b < batch; ++b) LAV_REQUIRE(h_num_points[b] >= 0, "lav_pillar_decorate: negative num_points");
+    a.min_x = grid->min_x; a.max_x = grid->max_x; a.min_y = grid->min_y; a.max_y = grid->max_y; a.ppm = grid->ppm;
+    a.nx = grid->nx; a.ny = grid->ny; a.KX = grid->nx + 1; a.KY = grid->ny + 1;
+    a.T = a.TW = 0;
+    const long ncells = (long)batch * a.KX * a.KY;
+    const long total = (long)batch * max_points;
+    const unsigned gp = (unsigned)((total + 255) / 256);
+    LAV_HIP(hipMemsetAsync(w.cell_count, 0, ncells * sizeof(int), st));
+    LAV_HIP(hipMemsetAsync(w.totals, 0, 4 * sizeof(int), st));
+    if (total > 0) {
+        hipLaunchKernelGGL(k_keys, dim3(gp), dim3(256), 0, st, a, w.key);
+        hipLaunchKernelGGL(k_cell_count, dim3(gp), dim3(256), 0, st, total, w.key, w.cell_count);
+        LAV_LAUNCH_CHECK();
+    }
+    int rc = exclusive_scan(w.cell_count, ncells, 1, w.cell_rank, w.block_sums, w.totals + 0, st);
+    if (rc) return rc;
+    if (total > 0) {
+        rc = exclusive_scan(w.key, total, 2, w.kept_rank, w.block_sums, w.totals + 1, st);
+        if (rc) return rc;
+        const long nsum = (ncells < total ? ncells : total) * 3;
+        LAV_HIP(hipMemsetAsync(w.cell_sums, 0, nsum * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_dec_sums, dim3(gp), dim3(256), 0, st, a, w.key, w.cell_rank, w.kept_rank, w.cell_sums, inverse, kept_src);
+        hipLaunchKernelGGL(k_dec_write, dim3(gp), dim3(256), 0, st, a, w.key, w.cell_rank, w.cell_count, w.kept_rank, w.cell_sums, decorated);
+        LAV_LAUNCH_CHECK();
+    }
+    if (unique_coords) {
+        hipLaunchKernelGGL(k_unique_coords, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, a, w.cell_count, w.cell_rank, ncells, unique_coords);
+        LAV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_counts, dim3(1), dim3(1), 0, st, w.totals + 0, w.totals + 1, counts);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_scatter_max(const float *src, const int *index, int n, int channels, int num_segments, float *out, int *argmax,
+                               void *stream) {
+    LAV_REQUIRE(n >= 0 && channels > 0 && num_segments >= 0, "lav_scatter_max: bad sizes");
+    LAV_REQUIRE(out && argmax && (n == 0 || (src && index)), "lav_scatter_max: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long pc = (long)num_segments * channels, nc = (long)n * channels;
+    unsigned *out_u = reinterpret_cast<unsigned *>(out);
+    if (pc == 0) return LAV_OK;
+    const int tok = timer_begin("scatter_max", st);
+    hipLaunchKernelGGL(k_smax_init, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, st, out_u, argmax, pc, n);
+    if (nc > 0) {
+        hipLaunchKernelGGL(k_smax_max, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, src, index, nc, channels, out_u);
+        hipLaunchKernelGGL(k_smax_arg, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, src, index, nc, channels, out_u, argmax);
+    }
+    hipLaunchKernelGGL(k_smax_fin, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, st, out_u, argmax, pc, n);
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_scatter_max_backward(const float *grad_out, const int *argmax, int n, int channels, int num_segments,
+                                        float *grad_src, void *stream) {
+    LAV_REQUIRE(n >= 0 && channels > 0 && num_segments >= 0, "lav_scatter_max_backward: bad sizes");
+    LAV_REQUIRE(grad_src || n == 0, "lav_scatter_max_backward: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long pc = (long)num_segments * channels;
+    if (n > 0) LAV_HIP(hipMemsetAsync(grad_src, 0, (size_t)n * channels * sizeof(float), st));
+    if (pc == 0 || n == 0) return LAV_OK;
+    LAV_REQUIRE(grad_out && argmax, "lav_scatter_max_backward: null argument");
+    hipLaunchKernelGGL(k_smax_bwd, dim3((unsigned)((pc + 255) / 256)), dim3(256), 0, st, grad_out, argmax, pc, channels, n, grad_src);
+    LAV_LAUNCH_CHECK();
     return LAV_OK;
 }

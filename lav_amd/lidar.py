@@ -37,7 +37,7 @@ class _Engine(nn.Module):
 
     def _need_eval(self):
         if self.training:
-            raise NotImplementedError(f"{type(self).__name__}: the HIP path is inference-only in this round (eval() first)")
+            raise NotImplementedError(f"{type(self).__name__}: the fused HIP path is eval-only; train mode runs forward_train")
 
 
 def _bn_tuple(bn: nn.BatchNorm2d):
@@ -93,8 +93,17 @@ class ConvBackbone(_Engine):
         object.__setattr__(self, "_eng", eng)
         return eng
 
+    def forward_train(self, x):
+        """Train mode (autograd, BatchNorm on batch statistics): the nn modules themselves (lidar.py:110-143)."""
+        f1 = self.conv1(x)
+        f2 = self.conv2(f1)
+        f3 = self.conv3(f2)
+        return torch.cat([self.upconv1(f1), self.upconv2(f2), self.upconv3(f3)], dim=1)
+
     def forward(self, x, out=None):
         """`out`: optional preallocated (B, 6*num_feature, H/2, W/2) buffer the three up-convolutions write into."""
+        if self.training:
+            return self.forward_train(x)
         self._need_eval()
         e = self._engine(x.device)
         feats = []
@@ -134,7 +143,8 @@ class Head(_Engine):
                          sigmoid=self._sigmoid, in_c_total=in_c_total, in_c_offset=in_c_offset, device=device)
 
     def forward(self, x):
-        self._need_eval()
+        if self.training:
+            return self.output_activation(self.net(x))
         if self._eng is None or self._eng["device"] != x.device:
             conv, bn = self.net[0], self.net[2]
             eng = dict(device=x.device,
@@ -163,8 +173,9 @@ class LiDARModel(_Engine):
     def heads(self, features):
         """(center, box, ori, seg) from the shared feature map: one fused 384->256 convolution, then four
         ConvTranspose2d(64->n) over their channel windows of the hidden tensor (lidar.py:30-33,159-161)."""
-        self._need_eval()
         hs = (self.center_head, self.box_head, self.ori_head, self.seg_head)
+        if self.training:
+            return tuple(h(features) for h in hs)
         if self._eng is None or self._eng["device"] != features.device:
             dev = features.device
             w = torch.cat([h.net[0].weight.detach() for h in hs], dim=0)

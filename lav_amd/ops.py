@@ -86,6 +86,66 @@ def pillar_scatter(points: torch.Tensor, num_points: Sequence[int], grid: Grid, 
     return canvas
 
 
+def pillar_decorate(points: torch.Tensor, num_points: Sequence[int], grid: Grid):
+    """Training-side front end of PointPillarNet: points (B, Nmax, D) -> decorated (N_kept, D+5), unique_coords (P,3),
+    inverse (N_kept,), kept_src (N_kept,) (int32, all in HBM).  One device->host copy (the two counts)."""
+    lib = _lib.load()
+    if points.dim() == 2:
+        points = points[None]
+    points = _f32c(points.detach(), "points")
+    B, nmax, D = points.shape
+    dev = points.device
+    total = max(B * nmax, 1)
+    uc = torch.empty((total, 3), dtype=torch.int32, device=dev)
+    inv = torch.empty((total,), dtype=torch.int32, device=dev)
+    src = torch.empty((total,), dtype=torch.int32, device=dev)
+    dec = torch.empty((total, D + 5), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+    nbytes = lib.lav_pillar_workspace_bytes(B, nmax, C.byref(grid))
+    ws = _workspace("pillar", nbytes, dev)
+    h_num = (C.c_int * B)(*[int(n) for n in num_points])
+    check(lib.lav_pillar_decorate(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), _ptr(uc), _ptr(inv),
+                                  _ptr(src), _ptr(dec), _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "lav_pillar_decorate")
+    p, k = [int(v) for v in cnt.tolist()]
+    return dec[:k], uc[:p], inv[:k], src[:k]
+
+
+class _ScatterMax(torch.autograd.Function):
+    """torch_scatter.scatter_max(src, index, dim=0) on liblav_amd, differentiable in src."""
+
+    @staticmethod
+    def forward(ctx, src, index, num_segments):
+        lib = _lib.load()
+        src = _f32c(src, "src")
+        if index.dtype != torch.int32 or not index.is_cuda:
+            raise RuntimeError("scatter_max: index must be an int32 tensor in HBM")
+        n, ch = src.shape
+        out = torch.empty((num_segments, ch), dtype=torch.float32, device=src.device)
+        arg = torch.empty((num_segments, ch), dtype=torch.int32, device=src.device)
+        check(lib.lav_scatter_max(_ptr(src), _ptr(index.contiguous()), n, ch, num_segments, _ptr(out), _ptr(arg), _stream()),
+              "lav_scatter_max")
+        ctx.save_for_backward(arg)
+        ctx.n = n
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        (arg,) = ctx.saved_tensors
+        lib = _lib.load()
+        grad_out = _f32c(grad_out, "grad_out")
+        num_segments, ch = grad_out.shape
+        grad_src = torch.empty((ctx.n, ch), dtype=torch.float32, device=grad_out.device)
+        check(lib.lav_scatter_max_backward(_ptr(grad_out), _ptr(arg), ctx.n, ch, num_segments, _ptr(grad_src), _stream()),
+              "lav_scatter_max_backward")
+        return grad_src, None, None
+
+
+def scatter_max(src: torch.Tensor, index: torch.Tensor, num_segments: int):
+    """(out (S, C), argmax (S, C) int32) - torch_scatter.scatter_max(src, index, dim=0) semantics."""
+    return _ScatterMax.apply(src, index, int(num_segments))
+
+
 # ------------------------------------------------------------------------------------------ paint
 def make_cameras(mats) -> C.Array:
     """mats: sequence of (K 3x3, lidar_to_world 4x4, world_to_cam 4x4) float32 arrays."""

@@ -54,6 +54,44 @@ def transform_points(locs, oris):
     return locs @ R
 
 
+def filter_cars(ego_locs, locs, typs):
+    """Vehicles ahead of the ego vehicle only (bev_planner_v2.py:279-283; -y is forward)."""
+    return typs & ((locs[:, :, 0] - ego_locs[:, 0:1])[..., 1] < 0)
+
+
+def random_sample(binaries, size):
+    """Keep at most `size` set entries per row, chosen uniformly (bev_planner_v2.py:286-299; same RNG calls)."""
+    cut = torch.zeros_like(binaries)
+    for i in range(binaries.size(0)):
+        if binaries[i].sum() <= size:
+            cut[i] = binaries[i]
+        else:
+            nz = torch.nonzero(binaries[i]).squeeze(1)
+            nz = nz[torch.multinomial(torch.ones_like(nz).float(), size)]
+            cut[i, nz] = binaries[i, nz]
+    return cut
+
+
+def sample_others(self, ego_locs, locs, oris, typs):
+    """Shared front half of BEVPlanner.forward / UniPlanner.forward (bev_planner_v2.py:74-101, uniplanner.py:58-86):
+    pick the vehicles to train on and draw their crop jitter.  Returns None when no vehicle qualifies."""
+    ego_oris = oris[:, :1]
+    locs, oris = locs[:, 1:], oris[:, 1:]
+    typs = filter_cars(ego_locs, locs, typs[:, 1:] == 1)          # 1 = vehicle
+    if int(typs.float().sum()) == 0:
+        return None, locs.size(1)
+    typs = random_sample(typs, size=self.max_num_cars)
+    flat_locs = (locs[:, :, 1:] - locs[:, :, :1])[typs]
+    rel_loc0 = (locs[:, :, 0] - ego_locs[:, None, 0])[typs]
+    rel_ori0 = (oris - ego_oris)[typs]
+    K = flat_locs.size(0)
+    locs_jitter = (torch.rand((K, 2)) * 2 - 1).float().to(locs.device) * self.feature_x_jitter
+    locs_jitter[:, 1] = 0
+    oris_jitter = (torch.rand((K,)) * 2 - 1).float().to(oris.device) * self.feature_angle_jitter
+    other_locs = transform_points(flat_locs - locs_jitter[:, None], -rel_ori0 - oris_jitter)
+    return dict(typs=typs, crop_locs=rel_loc0 + locs_jitter, crop_oris=rel_ori0 + oris_jitter, other_locs=other_locs), locs.size(1)
+
+
 class DecoderMixin:
     """cast()/plan() on the HIP GRU kernels.  Expects self.num_plan, self.num_plan_iter, self.num_cmds,
     self.plan_gru, self.plan_mlp and a _cast_modules() -> (grus, mlps) hook."""
@@ -72,6 +110,8 @@ class DecoderMixin:
     def cast(self, embd, mode="ego"):
         """(B,512) -> (B, num_cmds, num_plan, 2).  Both modes use the *_ego GRUs, as the reference does
         (uniplanner.py:296-300)."""
+        if self.training:
+            return self._cast_torch(embd)
         w = self._dec(embd.device)["cast"]
         return ops.gru_cast(embd, w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"], w["mlp_b"], self.num_plan)
 
@@ -80,6 +120,27 @@ class DecoderMixin:
         cmd >= 0 evaluates only that command branch and returns (B, iters, 1, T, 2)."""
         if cast_locs is None:
             cast_locs = self.cast(embd)
+        if self.training:
+            return self._plan_torch(embd, nxp, cast_locs.detach(), pixels_per_meter, crop_size, cmd)
         w = self._dec(embd.device)["plan"]
         return ops.gru_plan(embd, nxp, cast_locs.detach(), w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"],
                             w["mlp_b"], self.num_plan_iter, cmd, pixels_per_meter, crop_size)
+
+    # ---- train mode: the same decoders as differentiable torch ops (uniplanner.py:255-308) ----------------------
+    def _cast_torch(self, embd):
+        grus, mlps = self._cast_modules()
+        u = embd[:, None].expand(-1, self.num_plan, -1)
+        return torch.stack([torch.cumsum(mlp(gru(u)[0]), dim=1) for gru, mlp in zip(grus, mlps)], dim=1)
+
+    def _plan_torch(self, embd, nxp, plan_loc, pixels_per_meter, crop_size, cmd=-1):
+        u0 = (nxp * pixels_per_meter / crop_size * 2 - 1)[:, None].expand(-1, self.num_plan, -1)
+        branches = range(self.num_cmds) if cmd < 0 else [cmd]
+        if cmd >= 0:
+            plan_loc = plan_loc[:, cmd:cmd + 1]
+        outs = []
+        for _ in range(self.num_plan_iter):
+            locs = [torch.cumsum(self.plan_mlp(self.plan_gru(torch.cat([u0, plan_loc[:, j]], dim=2), embd[None].contiguous())[0]), dim=1)
+                    for j, _b in enumerate(branches)]
+            plan_loc = torch.stack(locs, dim=1) + plan_loc
+            outs.append(plan_loc)
+        return torch.stack(outs, dim=1)

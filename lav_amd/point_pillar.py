@@ -91,9 +91,23 @@ class PointPillarNet(nn.Module):
         num_points = [min(n, int(pts.shape[1])) for n in num_points]
         return pts, num_points
 
+    def forward_train(self, lidar_list, num_points):
+        """Train-mode forward (BatchNorm1d on batch statistics, autograd): liblav_amd does the index work and the two
+        torch_scatter ops - lav_pillar_decorate (grid_locations + unique + scatter_mean + decorate, no_grad in the
+        reference too, point_pillar.py:95-112) and lav_scatter_max with its arg-max backward; the two Linear + BatchNorm
+        layers and the dense index_put are torch ops on the same stream."""
+        pts, n = self._pack(lidar_list, num_points)
+        decorated, unique_coords, inverse, _ = ops.pillar_decorate(pts, n, self._grid)
+        feat = self.point_net.net(decorated)
+        feat_max, _ = ops.scatter_max(feat, inverse, unique_coords.shape[0])
+        uc = unique_coords.long()
+        canvas = torch.zeros((pts.shape[0], feat_max.shape[1], self.ny, self.nx), dtype=feat_max.dtype, device=feat_max.device)
+        canvas[uc[:, 0], :, torch.clamp(self.ny - 1 - uc[:, 1], 0, self.ny - 1), torch.clamp(uc[:, 2], 0, self.nx - 1)] = feat_max
+        return canvas
+
     def forward(self, lidar_list, num_points, return_indices: bool = False):
         if self.training:
-            raise NotImplementedError("PointPillarNet: the HIP path is inference-only in this round (eval() first)")
+            return self.forward_train(lidar_list, num_points)
         pts, n = self._pack(lidar_list, num_points)
         if pts.shape[2] + 5 != self.num_input:
             raise RuntimeError(f"points have {pts.shape[2]} columns, PointNet expects {self.num_input - 5}")

@@ -61,8 +61,18 @@ class ResNet(_Engine):
         object.__setattr__(self, "_eng", eng)
         return eng
 
+    def forward_train(self, x):
+        """Train mode (autograd, BatchNorm on batch statistics): plain torch ops over the same modules."""
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        for i in range(1, 5):
+            for blk in getattr(self, f"layer{i}"):
+                identity = x if blk.downsample is None else blk.downsample(x)
+                x = F.relu(blk.bn2(blk.conv2(F.relu(blk.bn1(blk.conv1(x))))) + identity)
+        return x
+
     def forward(self, x):
-        self._need_eval()
+        if self.training:
+            return self.forward_train(x)
         e = self._engine(x.device)
         x = F.max_pool2d(e["stem"](x), 3, 2, 1)
         for b in e["blocks"]:

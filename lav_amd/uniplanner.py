@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .lidar import _Engine
-from .planner_common import DecoderMixin, crop_feature, transform_points
+from .planner_common import DecoderMixin, crop_feature, crop_feature_torch, sample_others, transform_points
 from .resnet import resnet18
 
 
@@ -56,6 +56,8 @@ class UniPlanner(DecoderMixin, _Engine):
 
     def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
         ox, oy = self.offsets()
+        if self.training:   # autograd path (affine_grid + grid_sample)
+            return crop_feature_torch(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
         return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
 
     def others_from_detections(self, det, H, W):
@@ -71,6 +73,48 @@ class UniPlanner(DecoderMixin, _Engine):
             locs.append([(X - cx) / self.pixels_per_meter, (Y - cy) / self.pixels_per_meter])
             oris.append(float(np.arctan2(sin, cos)))
         return locs, oris
+
+    def forward(self, features, bev, ego_locs, locs, oris, nxps, typs):
+        """Training forward (uniplanner.py:56-150): the student decodes from jittered crops of the LiDAR feature map,
+        the frozen privileged BEVPlanner (eval mode, no_grad - it runs on the HIP inference kernels) from the same crops
+        of the ground-truth BEV.  features (B,384,160,160), bev (B,9,320,320), ego_locs (B,T+1,2), locs (B,N+1,T+1,2),
+        oris (B,N+1), nxps (B,2), typs (B,N+1)."""
+        self.bev_planner.eval()
+        teacher = self.bev_planner
+        ppm, crop = self.pixels_per_meter, self.crop_size
+        pick, N = sample_others(self, ego_locs, locs, oris, typs)
+        if pick is not None:
+            sel = pick["typs"]
+            flat_features = features[:, None].expand(-1, N, -1, -1, -1)[sel]
+            flat_bev = bev[:, None].expand(-1, N, -1, -1, -1)[sel]
+            other_embd = self.lidar_conv_emb(self.crop_feature(flat_features, pick["crop_locs"], pick["crop_oris"], ppm / 2, crop))
+            other_locs = pick["other_locs"]
+            other_cast_locs = self.cast(other_embd, mode="other")
+            other_cast_cmds = self.cast_cmd_pred(other_embd)
+            with torch.no_grad():
+                t_embd = teacher.bev_conv_emb(teacher.crop_feature(flat_bev.contiguous(), pick["crop_locs"], pick["crop_oris"], ppm, crop * 2))
+                other_cast_locs_expert, other_cast_cmds_expert = teacher.cast(t_embd), teacher.cast_cmd_pred(t_embd)
+        else:
+            z = dict(dtype=features.dtype, device=features.device)
+            other_locs = torch.zeros((N, self.num_plan, 2), **z)
+            other_cast_locs = torch.zeros((N, self.num_cmds, self.num_plan, 2), **z)
+            other_cast_cmds = torch.zeros((N, self.num_cmds), **z)
+            other_cast_locs_expert, other_cast_cmds_expert = torch.zeros_like(other_cast_locs), torch.zeros_like(other_cast_cmds)
+        B = features.size(0)
+        locs_jitter = (torch.rand((B, 2)) * 2 - 1).float().to(locs.device) * self.feature_x_jitter
+        locs_jitter[:, 1] = 0
+        oris_jitter = (torch.rand((B,)) * 2 - 1).float().to(oris.device) * self.feature_angle_jitter
+        ego_locs = transform_points(ego_locs[:, 1:] - locs_jitter[:, None], -oris_jitter)
+        nxps = transform_points(nxps[:, None] - locs_jitter[:, None], -oris_jitter)[:, 0]
+        ego_embd = self.lidar_conv_emb(self.crop_feature(features, locs_jitter, oris_jitter, ppm / 2, crop))
+        with torch.no_grad():
+            t_embd = teacher.bev_conv_emb(teacher.crop_feature(bev, locs_jitter, oris_jitter, ppm, crop * 2))
+            ego_cast_locs_expert = teacher.cast(t_embd)
+            ego_plan_locs_expert = teacher.plan(t_embd, nxps, cast_locs=ego_cast_locs_expert, pixels_per_meter=ppm, crop_size=crop * 2)
+        ego_cast_locs = self.cast(ego_embd, mode="ego")
+        ego_plan_locs = self.plan(ego_embd, nxps, cast_locs=ego_cast_locs, pixels_per_meter=ppm, crop_size=crop * 2)
+        return (other_locs, other_cast_locs, other_cast_cmds, other_cast_locs_expert, other_cast_cmds_expert,
+                ego_locs, ego_plan_locs, ego_cast_locs, self.cast_cmd_pred(ego_embd), ego_cast_locs_expert, ego_plan_locs_expert)
 
     @torch.no_grad()
     def infer(self, features, det, cmd, nxp):

@@ -266,6 +266,69 @@ def gold_agent():
          waypointer=np.array(w_out), waypointer_turn=np.array(w2_out), gps_crc=np.array([crc(sc["gps"])]))
 
 
+def gold_train():
+    """Two optimisation steps of the REFERENCE trainers (lav/lav_privileged_v2.py `train_bev`, lav/lav_final_v2.py
+    `train_lidar`) on CPU, on lav_amd.train.synthetic batches with seeded weights: their loss terms are the fixture
+    tests/test_gpu_train.py holds the MI355X training step to.  torch.load is patched to hand the constructors seeded
+    state_dicts (the released checkpoints are LFS pointers)."""
+    import types
+    sys.path.insert(0, REF)
+    import lav.lav_privileged_v2 as ref_priv  # noqa: E402  (reference)
+    import lav.lav_final_v2 as ref_final  # noqa: E402  (reference)
+    import lav_amd
+    from lav_amd.train import TrainConfig, synthetic_bev_batch, synthetic_lidar_batch
+    from lav_amd.train.lav import LAV as OurLAV
+    torch.set_grad_enabled(True)
+    ours = OurLAV(TrainConfig(), "cpu", what="bev")          # only to obtain the seeded state_dicts by key
+    bev_sd = {k: v.clone() for k, v in ours.bev_planner.state_dict().items()}
+    lm = lav_amd.LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **CFG)
+    lidar_sd = synth.seeded_state_dict(lm, prefix="lidar.")
+    y_off = 1 + CFG["min_x"] / ((CFG["max_x"] - CFG["min_x"]) / 2)
+    up = lav_amd.UniPlanner(ours.bev_planner, pixels_per_meter=4, crop_size=96, feature_x_jitter=1.5, feature_angle_jitter=20,
+                            x_offset=0, y_offset=y_off, num_cmds=6, num_plan=20, num_input_feature=384, num_plan_iter=5)
+    uni_sd = synth.seeded_state_dict(up, prefix="uni.")
+    uni_sd.update({"bev_planner." + k: v for k, v in bev_sd.items()})
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        path = str(path)
+        return {k2: v.clone() for k2, v in (bev_sd if "bev" in path else lidar_sd if "lidar" in path else uni_sd).items()}
+
+    args = types.SimpleNamespace(config_path=os.path.join(REF, "config_v2.yaml"), device="cpu", lr=3e-4, perceive_only=False,
+                                 motion_only=False)
+    torch.load = fake_load
+    try:
+        out = {}
+        # the privileged trainer also builds the camera nets (ImageNet download): not part of train_bev, stubbed out
+        ref_priv.RGBBrakePredictionModel = lambda *a, **k: torch.nn.Linear(1, 1)
+        ref_priv.RGBSegmentationModel = lambda *a, **k: torch.nn.Linear(1, 1)
+        trainer = ref_priv.LAV(args)
+        trainer.bev_planner.load_state_dict(bev_sd)
+        batch = synthetic_bev_batch(2, seed=11, num_objs=3)
+        keys = ("plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
+        rows = []
+        for step in range(2):
+            torch.manual_seed(100 + step)
+            info = trainer.train_bev(*batch, other_weight=0.5)
+            rows.append([info[k] for k in keys])
+        out["bev_terms"] = np.array(rows)
+        trainer = ref_final.LAV(args)
+        trainer.distill = True     # read by train_lidar but absent from config_v2.yaml; team_code_v2/config.yaml:11 says True
+        batch = synthetic_lidar_batch(2, seed=12, max_points=20000, num_objs=3)
+        keys = ("hm_loss", "box_loss", "ori_loss", "seg_loss", "plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
+        rows = []
+        for step in range(2):
+            torch.manual_seed(200 + step)
+            info = trainer.train_lidar(*batch)
+            rows.append([info[k] for k in keys])
+            print("train_lidar step", step, rows[-1], flush=True)
+        out["lidar_terms"] = np.array(rows)
+        save("train", **out)
+    finally:
+        torch.load = real_load
+        torch.set_grad_enabled(False)
+
+
 def gold_keys(lm, up):
     import json
     seg = RGBSegmentationModel([4, 6, 7, 10]); bra = RGBBrakePredictionModel([4, 6, 7, 10])
@@ -278,6 +341,9 @@ def gold_keys(lm, up):
 if __name__ == "__main__":
     if sys.argv[1:] == ["agent"]:     # only the host-glue fixture
         gold_agent()
+        sys.exit(0)
+    if sys.argv[1:] == ["train"]:     # only the training fixture
+        gold_train()
         sys.exit(0)
     lm, up = build_reference()
     gold_keys(lm, up)

@@ -1,0 +1,125 @@
+"""Training path on the GPU: the liblav_amd training ops (lav_pillar_decorate, lav_scatter_max + backward; through the
+C ABI) against the reference goldens / a torch restatement, train-mode PointPillarNet gradients, and two optimisation
+steps of train_lidar / train_bev against the REFERENCE trainers' loss terms (tests/golden/train.npz)."""
+import numpy as np
+import pytest
+import torch
+
+import lav_amd
+from lav_amd import ops
+from lav_amd.train import LAV, TrainConfig, synthetic_bev_batch, synthetic_lidar_batch
+from tests.test_oracle_golden import pillar_cases
+from tests.util import CFG, state_dicts, sub_sd
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+@pytest.mark.parametrize("name", ["lidar", "uniform", "edge", "one_cell", "batch2"])
+def test_pillar_decorate_vs_reference_golden(golden, name):
+    g = golden["pillar"]
+    clouds, n = pillar_cases(g)[name]
+    n = n or [len(c) for c in clouds]
+    ppn = lav_amd.PointPillarNet(16, [64, 64], **CFG)
+    pts, n = ppn._pack([torch.from_numpy(c).to(DEV) for c in clouds], n)
+    dec, uc, inv, src = ops.pillar_decorate(pts, n, ppn._grid)
+    np.testing.assert_array_equal(uc.cpu().numpy(), g[f"{name}/unique_coords"])       # bit-exact indices
+    np.testing.assert_array_equal(inv.cpu().numpy(), g[f"{name}/inverse"])
+    ref = g[f"{name}/decorated"]
+    got = dec.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :11], ref[:, :11])
+    np.testing.assert_array_equal(got[:, 14:], ref[:, 14:])                            # cell-origin offsets: exact
+    np.testing.assert_allclose(got[:, 11:14], ref[:, 11:14], rtol=0, atol=2e-5)        # float32 running mean vs fixed point
+    flat = pts.reshape(-1, pts.shape[-1])[src.long()]
+    assert torch.equal(flat, dec[:, :11]) and bool((src[1:] > src[:-1]).all())          # kept points stay in input order
+
+
+def _ref_scatter_max(src, index, S):
+    out = torch.full((S, src.shape[1]), float("-inf"), dtype=src.dtype, device=src.device)
+    out = out.index_reduce(0, index, src, "amax", include_self=True)
+    return out
+
+
+@pytest.mark.parametrize("n,ch,S,seed", [(5000, 64, 700, 0), (333, 7, 50, 1), (64, 64, 1, 2)])
+def test_scatter_max_forward_backward(n, ch, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn((n, ch), generator=g)
+    src[::7] = src[::7].abs().floor()                      # ties inside segments
+    index = torch.randint(0, S, (n,), generator=g)
+    index[:S] = torch.arange(S)                            # every segment non-empty
+    x = src.to(DEV).requires_grad_(True)
+    idx = index.to(DEV).int()
+    out, arg = ops.scatter_max(x, idx, S)
+    xr = src.clone().requires_grad_(True)
+    ref = _ref_scatter_max(xr, index, S)
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    a = arg.cpu().long()
+    assert torch.equal(src[a, torch.arange(ch)[None].expand(S, -1)], ref.detach()) and bool((index[a] == torch.arange(S)[:, None]).all())
+    w = torch.randn((S, ch), generator=g)
+    (out * w.to(DEV)).sum().backward()
+    # reference gradient: all of grad_out goes to the arg-max row (ties: lowest row - torch's amax would split them)
+    expect = torch.zeros_like(src)
+    expect[a, torch.arange(ch)[None].expand(S, -1)] = w
+    assert torch.equal(x.grad.cpu(), expect)
+
+
+def test_scatter_max_empty_segment_convention():
+    src = torch.tensor([[1.0, -2.0], [3.0, -5.0]], device=DEV)
+    out, arg = ops.scatter_max(src, torch.tensor([2, 2], device=DEV, dtype=torch.int32), 4)
+    assert out.cpu().tolist() == [[0, 0], [0, 0], [3, -2], [0, 0]] and arg.cpu().tolist() == [[2, 2], [2, 2], [1, 0], [2, 2]]
+
+
+def test_pointpillar_train_mode_forward_and_gradients_vs_torch_restatement(golden):
+    """Train-mode PointPillarNet (BatchNorm1d on batch statistics) on the HIP training ops == the reference's forward
+    (point_pillar.py:92-116) restated with torch ops on the golden's decorated points, values and weight gradients."""
+    g = golden["pillar"]
+    clouds, n = pillar_cases(g)["batch2"]
+    lsd, _ = state_dicts()
+    ppn = lav_amd.PointPillarNet(16, [64, 64], **CFG)
+    ppn.load_state_dict(sub_sd(lsd, "point_pillar_net."))
+    ppn.train().to(DEV)
+    canvas = ppn([torch.from_numpy(c).to(DEV) for c in clouds], n or [len(c) for c in clouds])
+    wgt = torch.randn(canvas.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    (canvas * wgt).sum().backward()
+    ref_net = lav_amd.PointPillarNet(16, [64, 64], **CFG)
+    ref_net.load_state_dict(sub_sd(lsd, "point_pillar_net."))
+    ref_net.train()
+    dec = torch.from_numpy(g["batch2/decorated"])
+    inv = torch.from_numpy(g["batch2/inverse"]).long()
+    uc = torch.from_numpy(g["batch2/unique_coords"]).long()
+    feat = ref_net.point_net.net(dec)
+    fmax = _ref_scatter_max(feat, inv, len(uc))
+    ref = torch.zeros((2, 64, 320, 320))
+    ref[uc[:, 0], :, torch.clamp(319 - uc[:, 1], 0, 319), torch.clamp(uc[:, 2], 0, 319)] = fmax
+    (ref * wgt.cpu()).sum().backward()
+    np.testing.assert_allclose(canvas.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+    for (k, p), (_, q) in zip(ppn.named_parameters(), ref_net.named_parameters()):
+        # (a Linear bias in front of a train-mode BatchNorm has a mathematically zero gradient: both sides are noise)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), rtol=2e-3, atol=max(2e-3 * float(q.grad.abs().max()), 2e-4), err_msg=k)
+    # BatchNorm running statistics moved identically
+    np.testing.assert_allclose(ppn.point_net.net[1].running_mean.cpu().numpy(), ref_net.point_net.net[1].running_mean.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_train_bev_on_gpu_matches_reference_trainer(golden):
+    ref = golden["train"]["bev_terms"]
+    lav = LAV(TrainConfig(), DEV, what="bev")
+    batch = synthetic_bev_batch(2, seed=11, num_objs=3)
+    keys = ("plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
+    for step in range(2):
+        torch.manual_seed(100 + step)
+        info = lav.train_bev(*batch, other_weight=0.5)
+        np.testing.assert_allclose([info[k] for k in keys], ref[step], rtol=1e-3 if step == 0 else 3e-2, atol=1e-4, err_msg=f"step {step}")
+
+
+def test_train_lidar_on_gpu_matches_reference_trainer(golden):
+    """Full train_full_v2 step (LiDARModel + UniPlanner distilled from the frozen BEVPlanner, detection + segmentation +
+    motion losses, Adam) vs the reference's own LAV.train_lidar run on CPU with the same seeded weights and batch."""
+    ref = golden["train"]["lidar_terms"]
+    lav = LAV(TrainConfig(), DEV, what="lidar")
+    batch = synthetic_lidar_batch(2, seed=12, max_points=20000, num_objs=3)
+    keys = ("hm_loss", "box_loss", "ori_loss", "seg_loss", "plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
+    for step in range(2):
+        torch.manual_seed(200 + step)
+        info = lav.train_lidar(*batch)
+        np.testing.assert_allclose([info[k] for k in keys], ref[step], rtol=2e-3 if step == 0 else 5e-2, atol=1e-4, err_msg=f"step {step}")
+        assert info["ego_plan_locs"].shape == (20, 2) and np.isfinite(info["ego_plan_locs"]).all()
