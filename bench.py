@@ -267,8 +267,16 @@ def main():
     roofline = None
     if rank == 0:
         m = micro["agent_196608pts"]
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC pass of this very kernel (counters cannot be read from inside a run)
+            with open(os.path.join(REPO, "profiles", "r01_c_pmc_pillar.json")) as f:
+                pm = json.load(f)
+            traffic = pm["k_tile_pointnet"][str(m["points"])]["traffic_bytes"]
+            traffic_src = "profiles/r01_c_pmc_pillar.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         roofline = dict(bound="hbm", kernel="k_tile_pointnet", achieved=m["achieved"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=m["frac"], traffic=None, points=m["points"], algorithmic_bytes=m["algorithmic_bytes"],
+                        frac=m["frac"], traffic=traffic, traffic_source=traffic_src, points=m["points"], algorithmic_bytes=m["algorithmic_bytes"],
                         avg_kernel_us=m["kernel_us"], launches=100)
 
     if rank == 0:
