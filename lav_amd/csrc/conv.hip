@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int in_floats = a.cps * CK * plane, w_floats = a.cps * a.tap_group * CK * CO_T;
     float *s_in0 = smem;                               // [2][CK][plane]   double-buffered input tile
     float *s_w0 = smem + a.in_bufs * in_floats;        // [2][tap_group][CK][CO_T]   double-buffered weight slab
+    // all scalar arguments the prologue needs, fetched in ONE batch of kernarg loads with a single wait (instead of a
+    // dependent s_load + s_waitcnt round trip at each first use)
+    asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.zero_page), "s"(a.in_c_total), "s"(a.in_c_offset), "s"(a.cin), "s"(a.H), "s"(a.W),
+                 "s"(a.cin_pad), "s"(a.cout_pad), "s"(a.QH), "s"(a.QW), "s"(a.in_s), "s"(a.Wst), "s"(a.ROWS), "s"(a.plane_pad),
+                 "s"(a.taps_per_class), "s"(a.tap_group), "s"(a.cps), "s"(a.in_bufs), "s"(a.rowblock), "s"(a.xblocks));
     const int ntaps = a.cls_ntaps[cls];
     // tile origin: first output-grid row, first staged input column (relative to in_ox)
     const int xb = a.rowblock ? (int)(blockIdx.x % a.xblocks) : 0;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_stack_sweeps(const float *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------ peaks
 constexpr int PT_W = 32, PT_H = 8;  // pixels per workgroup
-constexpr int PEAK_MAX_KS = 15, PEAK_MAX_DET = 64;
+constexpr int PEAK_MAX_KS = 15, PEAK_MAX_DET = 64, PEAK_MAX_CLS = 8;
 
 __device__ __forceinline__ unsigned ordered(float f) {  // monotone float -> uint
     const unsigned u = __float_as_uint(f);
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
     extern __shared__ __align__(16) unsigned char dyn_smem[];  // candidate keys of one class (last workgroup only)
     __shared__ unsigned long long s_u64[256];
     __shared__ float s_tile[(PT_H + PEAK_MAX_KS - 1) * (PT_W + PEAK_MAX_KS - 1)];
-    __shared__ int s_flag;
+    __shared__ int s_flag, s_cnt, s_base;
+    __shared__ unsigned long long s_win[PEAK_MAX_CLS * PEAK_MAX_DET];
     const int tid = threadIdx.x, cls = blockIdx.z;
     const int r = a.ks / 2, TW = PT_W + 2 * r, TH = PT_H + 2 * r;
     const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
@@ -138,22 +139,27 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
         if (!(m > c)) key = ((unsigned long long)ordered(c) << 32) | (0xffffffffu - (unsigned)(y * a.W + x));
     }
     s_u64[tid] = key;
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
+    int local = -1;
     if (key) {
         int rank = 0;
         for (int j = 0; j < 256; ++j) rank += s_u64[j] > key;
-        if (rank < a.max_det) {
-            const int pos = atomicAdd(&a.count[cls], 1);
-            a.cand[(long)cls * a.H * a.W + pos] = key;
-        }
+        if (rank < a.max_det) local = atomicAdd(&s_cnt, 1);   // LDS atomic: order inside the tile is irrelevant
     }
-    // ---- hand-off to the last workgroup (agent-scope release -> ticket -> acquire; MI355X guide G16)
+    __syncthreads();
+    // ONE global atomic per workgroup reserves the tile's slots (12 000 same-address atomics cost ~100 us otherwise)
+    if (tid == 0) s_base = s_cnt ? atomicAdd(&a.count[cls], s_cnt) : 0;
+    __syncthreads();
+    if (local >= 0)  // write-through (sc1) store: visible device-wide once it has left this wave, no L2 write-back fence needed
+        __hip_atomic_store(&a.cand[(long)cls * a.H * a.W + s_base + local], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- hand-off to the last workgroup (MI355X guide G16, write-through form: sc1 payload stores, every wave drains
+    // its stores, barrier, one relaxed agent-scope ticket; the last arriver takes ONE acquire before plain loads).
+    // A release fence per workgroup (buffer_wbl2 from 800 workgroups) made this kernel 107 us instead of ~15.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int total = gridDim.x * gridDim.y * gridDim.z;
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int ticket = __hip_atomic_fetch_add(&a.count[a.ncls], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = ticket == total - 1;
         if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -192,24 +198,27 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
             if ((tid & 63) == 0) slot[tid >> 6] = best;
             __syncthreads();
             best = max(max(slot[0], slot[1]), max(slot[2], slot[3]));
-            float *row = a.out + ((long)c * a.max_det + d) * ncol;
-            if (tid < ncol) {
-                float v;
-                if (best == 0) {  // fewer candidates than max_det: a suppressed pixel's score, never above any threshold
-                    v = tid == 0 ? -1e5f : 0.f;
-                } else {
-                    const unsigned idx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
-                    const int py = idx / a.W, px = idx - py * a.W;
-                    if (tid == 0) v = unordered((unsigned)(best >> 32));
-                    else if (tid == 1) v = (float)px;
-                    else if (tid == 2) v = (float)py;
-                    else if (tid < 3 + a.size_c) v = a.size[((long)(tid - 3) * a.H + py) * a.W + px];
-                    else v = a.ori[((long)(tid - 3 - a.size_c) * a.H + py) * a.W + px];
-                }
-                row[tid] = v;
-            }
+            if (tid == 0) s_win[c * PEAK_MAX_DET + d] = best;   // gathers happen once, after all rounds (no memory latency per round)
             bound = best;
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < a.ncls * a.max_det * ncol; e += 256) {
+        const int col = e % ncol, d = (e / ncol) % a.max_det, c = e / (ncol * a.max_det);
+        const unsigned long long best = s_win[c * PEAK_MAX_DET + d];
+        float v;
+        if (best == 0) {  // fewer candidates than max_det: a suppressed pixel's score, never above any threshold
+            v = col == 0 ? -1e5f : 0.f;
+        } else {
+            const unsigned idx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
+            const int py = idx / a.W, px = idx - py * a.W;
+            if (col == 0) v = unordered((unsigned)(best >> 32));
+            else if (col == 1) v = (float)px;
+            else if (col == 2) v = (float)py;
+            else if (col < 3 + a.size_c) v = a.size[((long)(col - 3) * a.H + py) * a.W + px];
+            else v = a.ori[((long)(col - 3 - a.size_c) * a.H + py) * a.W + px];
+        }
+        a.out[e] = v;
     }
     if (tid <= a.ncls) __hip_atomic_store(&a.count[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
 }
@@ -250,7 +259,7 @@ extern "C" size_t lav_extract_peaks_workspace_bytes(int ncls, int h, int w) {
 extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max_det, int apply_sigmoid,
                                  const float *size, int size_c, const float *ori, int ori_c, float *out, void *workspace,
                                  size_t workspace_bytes, void *stream) {
-    LAV_REQUIRE(ncls > 0 && h > 0 && w > 0 && (long)h * w < (1l << 31), "lav_extract_peaks: bad sizes");
+    LAV_REQUIRE(ncls > 0 && ncls <= PEAK_MAX_CLS && h > 0 && w > 0 && (long)h * w < (1l << 31), "lav_extract_peaks: bad sizes (at most %d planes)", PEAK_MAX_CLS);
     LAV_REQUIRE(ks >= 1 && (ks & 1) && ks <= PEAK_MAX_KS, "lav_extract_peaks: odd kernel size <= %d expected", PEAK_MAX_KS);
     LAV_REQUIRE(max_det >= 1 && max_det <= PEAK_MAX_DET, "lav_extract_peaks: max_det in [1, %d]", PEAK_MAX_DET);
     LAV_REQUIRE(size_c >= 0 && ori_c >= 0 && 3 + size_c + ori_c <= 256, "lav_extract_peaks: too many gathered channels");
