@@ -406,91 +406,73 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
     const long Q = (long)p.QH * p.QW;
     struct Geo { int rowblock, xblocks, Wst, ROWS, plane_pad, tap_group, in_bufs; size_t lds; long nwg; bool ok; };
-    auto geo = [&](int mp, int mc) {
+    auto geo = [&](int mp, int mc, int rowblock, int in_bufs) {
         Geo g;
         const int PIXW = 128 * mp, CO_T = 32 * mc;
-        g.rowblock = 0; g.xblocks = 1;
-        g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
+        g.rowblock = rowblock; g.in_bufs = in_bufs; g.xblocks = 1;
         const int span_rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
+        g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
         g.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
+        if (rowblock) {
+            g.xblocks = (p.QW + PIXW - 1) / PIXW;
+            g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
+            g.ROWS = p.max_dy + 1;
+        }
         const size_t LDS_MAX = 160 * 1024;
-        auto pad = [&]() { return ((long)g.ROWS * g.Wst + 63) / 64 * 64; };
-        auto bytes_with = [&](int tg) { return (size_t)(g.in_bufs * (size_t)CK * pad() + 2 * (size_t)tg * CK * CO_T) * 4; };
+        const long pad = ((long)g.ROWS * g.Wst + 63) / 64 * 64;
+        auto bytes_with = [&](int tg) { return (size_t)(g.in_bufs * (size_t)CK * pad + 2 * (size_t)tg * CK * CO_T) * 4; };
         // weight slab: all taps when they fit, else one kernel row, else a single tap
-        auto pick_group = [&]() {
-            const int opts[3] = {p.taps_per_class, p.nclasses == 1 ? c.kw : 1, 1};
-            for (int tg : opts)
-                if (tg >= 1 && tg <= TAP_GROUP && bytes_with(tg) <= LDS_MAX) return tg;
-            return 0;
-        };
-        // try: linearised tile with a double- then single-buffered input, then row-blocked tiles likewise
-        bool placed = false;
-        // (rowblock, in_bufs) in order of preference; row blocks only come first when rows are at least a tile wide
-        const int wide[4][2] = {{0, 2}, {1, 2}, {0, 1}, {1, 1}}, narrow[4][2] = {{0, 2}, {0, 1}, {1, 2}, {1, 1}};
-        const int (*order)[2] = p.QW >= PIXW ? wide : narrow;
-        for (int mode = 0; mode < 4 && !placed; ++mode) {
-            g.rowblock = order[mode][0];
-            g.in_bufs = order[mode][1];
-            g.xblocks = 1; g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
-            g.ROWS = (span_rows - 1) * p.in_s + p.max_dy + 1;
-            if (g.rowblock) {
-                g.xblocks = (p.QW + PIXW - 1) / PIXW;
-                g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
-                g.ROWS = p.max_dy + 1;
-            }
-            if (pad() > 256 * NPOS_MAX) continue;
-            g.tap_group = pick_group();
-            // a one-tap slab means a barrier every 8*MP*MC MFMAs: only accept it when nothing better exists
-            if (g.tap_group >= std::min(p.taps_per_class, p.nclasses == 1 ? c.kw : 1)) placed = true;
-        }
-        if (!placed) {  // last resort: whatever fits, single tap
-            for (int mode = 0; mode < 4 && !placed; ++mode) {
-                g.rowblock = mode >> 1;
-                g.in_bufs = (mode & 1) ? 1 : 2;
-                g.xblocks = 1; g.Wst = (p.QW - 1) * p.in_s + p.max_dx + 1;
-                g.ROWS = ((int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH) - 1) * p.in_s + p.max_dy + 1;
-                if (g.rowblock) {
-                    g.xblocks = (p.QW + PIXW - 1) / PIXW;
-                    g.Wst = (std::min(PIXW, p.QW) - 1) * p.in_s + p.max_dx + 1;
-                    g.ROWS = p.max_dy + 1;
-                }
-                if (pad() > 256 * NPOS_MAX) continue;
-                g.tap_group = pick_group();
-                placed = g.tap_group >= 1;
-            }
-        }
-        auto bytes = [&]() { return bytes_with(std::max(g.tap_group, 1)); };
-        g.plane_pad = (int)pad();
-        g.lds = bytes();
-        g.ok = placed && (long)g.plane_pad <= 256 * NPOS_MAX && g.lds <= LDS_MAX;
+        g.tap_group = 0;
+        const int opts[3] = {p.taps_per_class, p.nclasses == 1 ? c.kw : 1, 1};
+        for (int tg : opts)
+            if (tg >= 1 && tg <= TAP_GROUP && bytes_with(tg) <= LDS_MAX) { g.tap_group = tg; break; }
+        g.plane_pad = (int)pad;
+        g.lds = bytes_with(std::max(g.tap_group, 1));
+        g.ok = g.tap_group >= 1 && pad <= 256 * NPOS_MAX && g.lds <= LDS_MAX;
         const long xt = g.rowblock ? (long)p.QH * g.xblocks : (Q + PIXW - 1) / PIXW;
         g.nwg = xt * ((c.cout + CO_T - 1) / CO_T) * c.batch * p.nclasses;
         return g;
     };
+    // Cost of a candidate in microseconds, calibrated on MI355X traces (LAV_CONV_TRACE): one (16-channel chunk x tap) of
+    // a tile costs 0.45 + 0.3*MP*MC us on the matrix pipes (a single-buffered input cannot overlap its DMA: x1.2; a
+    // one-tap weight slab pays a barrier per tap: x1.3); a workgroup costs ~5 us of set-up + epilogue; a split-K reduce
+    // launch ~6 us.  Matrix work is conserved per CU (rounds = workgroups / 256), fixed costs overlap between the
+    // workgroups that share a CU's LDS; staging a chunk costs ~1 ns per staged position (instruction issue).  Wasted pixels (a 160-pixel row cut into 128 + 32, a 48-pixel row in a 128-pixel
+    // row block) show up as extra workgroups.  Split-K (ks workgroups per tile, each a slice of the channel loop) is
+    // part of the search whenever a layer has fewer tiles than CUs, so a layer never lands a few workgroups above a
+    // multiple of 256.
+    const int nchunks = (c.cin + CK - 1) / CK;
     double best = 1e30;
     Geo bg{};
     bool found = false;
+    a.ksplit = 1;
     const int cand[3][2] = {{1, 1}, {1, 2}, {2, 2}};
+    const int full_group = std::min(p.taps_per_class, p.nclasses == 1 ? c.kw : 1);
     for (auto &cd : cand) {
         if (cd[1] == 2 && c.cout <= 32) continue;
-        const Geo g = geo(cd[0], cd[1]);
-        if (!g.ok) continue;
-        const double t = (double)((g.nwg + 255) / 256) * (cd[0] * cd[1] + 0.5);
-        if (t < best - 1e-9) { best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; }
+        for (int mode = 0; mode < 4; ++mode) {   // preference on ties: linearised before row-blocked, double before single buffer
+            const Geo g = geo(cd[0], cd[1], mode >> 1, (mode & 1) ? 1 : 2);
+            if (!g.ok) continue;
+            double unit = (0.45 + 0.3 * cd[0] * cd[1]) * p.taps_per_class;
+            if (g.in_bufs == 1) unit *= 1.2;
+            if (g.tap_group < full_group) unit *= 1.3;
+            unit += 0.001 * g.plane_pad;   // issuing the chunk's DMA: ~9 instructions per 64 staged positions and channel, same waves
+            const long per_cu = std::max<long>(1, std::min<long>(2, (long)(160 * 1024 / g.lds)));
+            const int ks_max = g.nwg < 256 && nchunks >= 4 ? std::min(16, nchunks / 2) : 1;
+            for (int ks = 1; ks <= ks_max; ++ks) {
+                const long wgs = g.nwg * ks;
+                const double t = (double)((wgs + 255) / 256) * ((nchunks + ks - 1) / ks) * unit +
+                                 (double)((wgs + 256 * per_cu - 1) / (256 * per_cu)) * 5.0 + (ks > 1 ? 6.0 : 0.0);
+                if (t < best * (ks > 1 ? 0.97 : 1.0) - 1e-9) {   // a larger split must pay for its partial-sum traffic
+                    best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; a.ksplit = ks;
+                }
+            }
+        }
     }
     LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
     a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
     a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group; a.in_bufs = bg.in_bufs;
     lds = bg.lds;
-    // split-K: layers with few output tiles and a long channel loop (deep ResNet stages, 40x40 BEV stage) leave most
-    // CUs idle while a handful of waves walk K serially; spread the cin chunks over up to 16 workgroups per tile
-    const int nchunks = (c.cin + CK - 1) / CK;
-    a.ksplit = 1;
-    if (bg.nwg < 160 && nchunks >= 4) {
-        int ksp = (int)std::min<long>(16, (256 + bg.nwg - 1) / bg.nwg);
-        ksp = std::min(ksp, nchunks / 2);
-        if (ksp >= 2) a.ksplit = ksp;
-    }
     // chunks per stage: a stage of one 16-channel chunk is only taps*8*MP*MC MFMAs (a few hundred ns) while the DMA
     // of the next stage needs a memory round trip, so short layers stage several chunks (up to all of K) at once.
     // Layers that fill the chip more than once keep their LDS footprint (two workgroups per CU) instead.

@@ -34,13 +34,20 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_retired = []
+
+
 def _workspace(key, nbytes: int, device) -> torch.Tensor:
     """Scratch buffer per (kind, device, stream): kernels enqueued on different streams may run concurrently
     (the frame graph forks the brake net and the ego branch onto side streams), so they never share scratch."""
     k = (key, device, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(k)
     if ws is None or ws.numel() < nbytes:
-        # zero-filled: the split-K convolution keeps arrival counters at the end of its buffer (zero between launches)
+        if ws is not None:
+            # a captured HIP graph may have baked the old buffer's address into its kernel nodes: keep it alive (it stays
+            # large enough for the launches that were captured with it) instead of returning it to the allocator
+            _retired.append(ws)
+        # zero-filled: kernels with arrival counters (lav_extract_peaks) expect zeros before their first launch
         ws = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=device)
         _workspaces[k] = ws
     return ws
