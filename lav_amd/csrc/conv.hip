@@ -458,11 +458,13 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
             if (g.tap_group < full_group) unit *= 1.3;
             unit += 0.001 * g.plane_pad;   // issuing the chunk's DMA: ~9 instructions per 64 staged positions and channel, same waves
             const long per_cu = std::max<long>(1, std::min<long>(2, (long)(160 * 1024 / g.lds)));
-            const int ks_max = g.nwg < 256 && nchunks >= 4 ? std::min(16, nchunks / 2) : 1;
+            const int ks_max = nchunks >= 4 ? std::min(16, nchunks / 2) : 1;
+            // partial sums: ks slabs of the output written by the tiles and read back by the reduce launch (~4 TB/s)
+            const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
             for (int ks = 1; ks <= ks_max; ++ks) {
                 const long wgs = g.nwg * ks;
                 const double t = (double)((wgs + 255) / 256) * ((nchunks + ks - 1) / ks) * unit +
-                                 (double)((wgs + 256 * per_cu - 1) / (256 * per_cu)) * 5.0 + (ks > 1 ? 6.0 : 0.0);
+                                 (double)((wgs + 256 * per_cu - 1) / (256 * per_cu)) * 5.0 + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
                 if (t < best * (ks > 1 ? 0.97 : 1.0) - 1e-9) {   // a larger split must pay for its partial-sum traffic
                     best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; a.ksplit = ks;
                 }
@@ -483,7 +485,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         // branch and the LiDAR chain concurrently) can share the CU: a 160 KB workgroup monopolises its CU's LDS
         // ... unless the whole layer is at most one workgroup per CU: then nothing of this layer queues behind the
         // footprint, and staging more of K up front saves a barrier + DMA round trip per stage (small gain, measured)
-        static const size_t small_budget = [] { const char *e = getenv("LAV_CONV_SMALL_LDS_KB"); return (size_t)(e ? atoi(e) : 96) * 1024; }();
+        static const size_t small_budget = [] { const char *e = getenv("LAV_CONV_SMALL_LDS_KB"); return (size_t)(e ? atoi(e) : 64) * 1024; }();
         const bool one_wave = bg.nwg * a.ksplit <= 256;
         const size_t budget = std::max<size_t>(lds, one_wave ? small_budget : 64 * 1024);
         int cps = 1;

@@ -120,3 +120,25 @@ def test_crop_rotate_matches_torch_grid_sample():
     ref = crop_feature_torch(fb, locs, oris, 1.0, 24, 0.1, 0.5)
     out = ops.crop_rotate(fb.to(DEV), locs.to(DEV), oris.to(DEV), 1.0, 24, 0.1, 0.5).cpu()
     assert_close(out.numpy(), ref.numpy(), atol=2e-4, what="rotated crop (per-sample maps)")
+
+
+def test_workspace_growth_does_not_invalidate_captured_graphs():
+    """A split-K layer captured in a HIP graph keeps working after a later, larger layer made the per-stream workspace
+    grow: the old buffer (whose address is baked into the graph's kernel nodes) is retired, not freed."""
+    from lav_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    small = ops.ConvLayer(torch.randn((256, 256, 3, 3), generator=g) * 0.02, padding=(1, 1), device=dev)
+    x = torch.randn((1, 256, 6, 6), generator=g).to(dev)
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        ref = small(x).clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            y = small(x)
+        big = ops.ConvLayer(torch.randn((512, 512, 3, 3), generator=g) * 0.02, padding=(1, 1), device=dev)
+        junk = [big(torch.randn((8, 512, 6, 6), generator=g).to(dev)) for _ in range(3)]      # grows the "conv" workspace on this stream
+        hog = [torch.randn((1 << 20,), device=dev) for _ in range(8)]                            # would land in a freed buffer
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and len(junk) == 3 and len(hog) == 8
