@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 4
+#define LAV_ABI_VERSION 5
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -250,6 +250,22 @@ int lav_scatter_max(const float *src, const int *index, int n, int channels, int
                     void *stream);
 int lav_scatter_max_backward(const float *grad_out, const int *argmax, int n, int channels, int num_segments,
                              float *grad_src, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 8. Two stacked 1-D convolutions in one launch - one half of ERFNet's non_bottleneck_1d block
+ *    (lav/models/erfnet.py:45-56):  y = relu?( (conv1x3_dB( relu( conv3x1_dA(x) + bias_a ) ) + bias_b) * scale + shift
+ *    + residual ).  x, y, residual [batch][channels][h][w] (same shape), stride 1, "same" padding (pad = dilation).
+ *    One workgroup per image row; the intermediate stays in LDS.  Supported: w in {32, 64, 128},
+ *    channels a multiple of 16 with ceil(channels/32) <= 128/w (ERFNet: 16@128, 64@64, 128@32).
+ *    Weights: lav_conv1d_pair_pack_weights repacks a PyTorch [cout][cin][3] tensor (the unit kernel dimension
+ *    squeezed) on the host; scale/shift/residual may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+size_t lav_conv1d_pair_packed_weight_floats(int channels);
+int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_packed);
+size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b);
+int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,
+                    const float *bias_a, const float *wb_packed, const float *bias_b, const float *scale, const float *shift,
+                    const float *residual, int relu_post, float *y, void *stream);
 
 #ifdef __cplusplus
 }

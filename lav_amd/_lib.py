@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblav_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_CAM = 4
 
 
@@ -63,6 +63,10 @@ SIGNATURES = {
     "lav_pillar_decorate": (_I, [_P, C.POINTER(_I), _I, _I, _I, C.POINTER(Grid), _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_scatter_max": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "lav_scatter_max_backward": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "lav_conv1d_pair_packed_weight_floats": (_Z, [_I]),
+    "lav_conv1d_pair_pack_weights": (_I, [_I, _P, _P]),
+    "lav_conv1d_pair_lds_bytes": (_Z, [_I, _I, _I]),
+    "lav_conv1d_pair": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "lav_merge_ticks": (_I, [_P, _P, _I, _I, _P, _P]),
     "lav_stack_sweeps": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "lav_extract_peaks_workspace_bytes": (_Z, [_I, _I, _I]),

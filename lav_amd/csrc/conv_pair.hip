@@ -1,0 +1,229 @@
+// Two stacked 1-D convolutions in one launch:  y = epilogue( conv1x3_d( relu( conv3x1_d(x) + bA ) ) + bB )
+//
+// This is one half of ERFNet's non_bottleneck_1d block (lav/models/erfnet.py:45-56: conv3x1 -> ReLU -> conv1x3 -> BN
+// (-> + input) -> ReLU), which makes up 66 of the 74 convolutions of the segmentation network.  As separate
+// lav_conv2d launches each of them costs ~20 us, almost all of it per-launch fixed cost (scalar set-up, staging,
+// epilogue, launch gap) - the matrix work is 1-3 us.  Fusing the pair removes a launch, a round trip of the
+// intermediate through HBM and one staging pass.
+//
+// Decomposition: one workgroup = ONE image row (all W pixels) x ALL output channels.  The horizontal convolution only
+// needs the intermediate of its own row, so the intermediate never leaves the CU: it is written to LDS in the layout
+// the second convolution reads it from ([channel][W + 2 dB], zero halo).  The 4 waves split the row's 32-pixel groups
+// and the 32-channel groups of the output (W/32 x 128/W = 4 for W in {32, 64, 128}).
+//
+//   stage   all C input channels of the three rows y-dA, y, y+dA: one asynchronous global->LDS DMA batch (16 B per
+//           lane), one barrier - there is no staged pipeline to drain
+//   phase A per 16-channel chunk and tap: 8 v_mfma_f32_32x32x2_f32 (exact fp32); the weight fragments come straight
+//           from L2 in an MFMA-ready packing (8 consecutive k per lane = two 16-byte loads per tap and chunk,
+//           prefetched one chunk ahead in registers), so the loops have no barriers at all
+//   mid     relu(acc + bA) -> LDS; one barrier
+//   phase B same loop over the intermediate's channels, taps = horizontal offsets 0, dB, 2dB into the padded row
+//   epilogue +bB -> x scale + shift (eval BatchNorm) -> + residual -> ReLU -> NCHW store
+//
+// Bound: launch/latency (a pair is 0.06-0.45 GFLOP); the design target is the fixed cost, not the matrix pipes.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace {
+using namespace lav;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct PairArgs {
+    const float *x, *wA, *bA, *wB, *bB, *scale, *shift, *res, *zero_page;
+    float *y;
+    int B, C, H, W, dA, dB, relu_post;
+    int CP;  // output channels padded to a multiple of 32 (packed-weight stride)
+};
+
+// packed weights: [tap 3][chunk C/16][half 2][co CP][cp 8]  with k = chunk*16 + 2*cp + half
+__device__ __forceinline__ void load_w(const float *__restrict__ wp, int tap, int chunk, int nchunk, int half, int co, int CP, float (&a)[8]) {
+    const float4 *p = reinterpret_cast<const float4 *>(wp + ((((long)tap * nchunk + chunk) * 2 + half) * CP + co) * 8);
+    const float4 lo = p[0], hi = p[1];
+    a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+}
+
+__global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int C = a.C, W = a.W, H = a.H, CP = a.CP;
+    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    const int NPG = W >> 5;                       // 32-pixel groups per row: 1, 2 or 4
+    const int pg = wid % NPG, cg = wid / NPG;     // this wave's pixel group / 32-channel output group
+    const int px = pg * 32 + l31;
+    const int co_lane = cg * 32 + l31;            // A-operand row (output channel) of this lane
+    const bool co_ok = cg * 32 < CP;              // wave has output channels at all (C = 16 -> one group)
+    const int WM = W + 2 * a.dB;                  // padded intermediate row
+    float *s_in = smem;                           // [C][3][W]
+    float *s_mid = smem + C * 3 * W;              // [C][WM]
+    const int nchunk = C >> 4;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+
+    // ---- stage the three input rows of every channel (16 B per lane; rows outside the image read the zero page)
+    {
+        const int W4 = W >> 2, F4 = C * 3 * W4;
+        const float *xn = a.x + (long)n * C * H * W;
+        for (int f0 = 64 * wid; f0 < F4; f0 += 256) {   // wave-uniform: this wave's 64 float4 slots f0 .. f0+63
+            const int f = f0 + lane;
+            const int q = f / W4, x4 = f - q * W4;
+            const int c = q / 3, t = q - 3 * c;
+            const int yy = y + (t - 1) * a.dA;
+            const bool ok = f < F4 && yy >= 0 && yy < H;
+            const float *src = ok ? xn + ((long)c * H + yy) * W + 4 * x4 : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + 4 * f0), 16, 0, 0);
+        }
+    }
+    // first weight fragments and the epilogue vectors travel while the DMA is in flight
+    float wa[3][8], wn[3][8];
+    if (co_ok) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) load_w(a.wA, t, 0, nchunk, half, co_lane, CP, wa[t]);
+    }
+    float bAv[16], bBv[16], sv[16], tv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
+        bAv[r] = a.bA[co];
+        bBv[r] = a.bB[co];
+        sv[r] = a.scale ? a.scale[co] : 1.f;
+        tv[r] = a.scale ? a.shift[co] : 0.f;
+    }
+    // zero halo of the intermediate row
+    for (int i = tid; i < C * 2 * a.dB; i += 256) {
+        const int c = i / (2 * a.dB), j = i - c * 2 * a.dB;
+        s_mid[c * WM + (j < a.dB ? j : W + j)] = 0.f;
+    }
+    __syncthreads();  // DMA landed (hipcc drains vmcnt before the barrier), halo written
+
+    // ---- phase A: vertical taps
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (co_ok) {
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (ch + 1 < nchunk) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch + 1, nchunk, half, co_lane, CP, wn[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float *b = s_in + ((ch * 16 + half) * 3 + t) * W + px;
+#pragma unroll
+                for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][cp], b[cp * 2 * 3 * W], acc, 0, 0, 0);
+            }
+            if (ch + 1 < nchunk) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int cp = 0; cp < 8; ++cp) wa[t][cp] = wn[t][cp];
+            }
+        }
+        // first fragments of phase B travel while the intermediate is written
+#pragma unroll
+        for (int t = 0; t < 3; ++t) load_w(a.wB, t, 0, nchunk, half, co_lane, CP, wa[t]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = acc[r] + bAv[r];
+            if (co < C) s_mid[co * WM + a.dB + px] = v > 0.f ? v : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: horizontal taps over the intermediate
+    if (!co_ok) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch + 1, nchunk, half, co_lane, CP, wn[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float *b = s_mid + (ch * 16 + half) * WM + px + t * a.dB;
+#pragma unroll
+            for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][cp], b[cp * 2 * WM], acc, 0, 0, 0);
+        }
+        if (ch + 1 < nchunk) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int cp = 0; cp < 8; ++cp) wa[t][cp] = wn[t][cp];
+        }
+    }
+    // ---- epilogue
+    const long plane = (long)H * W;
+    const long base = (long)n * C * plane + (long)y * W + px;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= C) continue;
+        float v = fmaf(acc[r] + bBv[r], sv[r], tv[r]);
+        if (a.res) v += a.res[base + co * plane];
+        if (a.relu_post) v = v > 0.f ? v : 0.f;
+        a.y[base + co * plane] = v;
+    }
+}
+}  // namespace
+
+extern "C" size_t lav_conv1d_pair_packed_weight_floats(int channels) {
+    if (channels < 16 || channels % 16) return 0;
+    const int CP = (channels + 31) / 32 * 32;
+    return (size_t)3 * (channels / 16) * 2 * CP * 8;
+}
+
+extern "C" int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_packed) {
+    LAV_REQUIRE(h_weight && h_packed, "lav_conv1d_pair_pack_weights: null");
+    LAV_REQUIRE(channels >= 16 && channels % 16 == 0, "lav_conv1d_pair_pack_weights: channels must be a multiple of 16");
+    const int C = channels, CP = (C + 31) / 32 * 32, nchunk = C / 16;
+    // h_weight: PyTorch layout [cout][cin][3] (the singleton kernel dimension squeezed out)
+    for (int t = 0; t < 3; ++t)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int half = 0; half < 2; ++half)
+                for (int co = 0; co < CP; ++co)
+                    for (int cp = 0; cp < 8; ++cp) {
+                        const int k = ch * 16 + 2 * cp + half;
+                        h_packed[((((size_t)t * nchunk + ch) * 2 + half) * CP + co) * 8 + cp] = co < C ? h_weight[((size_t)co * C + k) * 3 + t] : 0.f;
+                    }
+    return LAV_OK;
+}
+
+extern "C" size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b) {
+    return ((size_t)channels * 3 * w + (size_t)channels * (w + 2 * d_b)) * sizeof(float);
+}
+
+extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,
+                               const float *bias_a, const float *wb_packed, const float *bias_b, const float *scale,
+                               const float *shift, const float *residual, int relu_post, float *y, void *stream) {
+    LAV_REQUIRE(batch >= 1 && h >= 1 && d_a >= 1 && d_b >= 1, "lav_conv1d_pair: bad sizes");
+    LAV_REQUIRE(w == 32 || w == 64 || w == 128, "lav_conv1d_pair: row width %d not in {32, 64, 128}", w);
+    LAV_REQUIRE(channels >= 16 && channels % 16 == 0 && (channels + 31) / 32 <= 128 / w,
+                "lav_conv1d_pair: %d channels do not fit a %d-pixel row tile (at most %d)", channels, w, 32 * (128 / w));
+    LAV_REQUIRE(x && wa_packed && bias_a && wb_packed && bias_b && y, "lav_conv1d_pair: null argument");
+    LAV_REQUIRE((scale == nullptr) == (shift == nullptr), "lav_conv1d_pair: scale and shift come together");
+    const size_t lds = lav_conv1d_pair_lds_bytes(channels, w, d_b);
+    LAV_REQUIRE(lds <= 160 * 1024, "lav_conv1d_pair: %zu bytes of LDS needed", lds);
+    static float *zero_page = nullptr;
+    if (!zero_page) {
+        LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
+        LAV_HIP(hipMemset(zero_page, 0, 256));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    PairArgs a;
+    a.x = x; a.wA = wa_packed; a.bA = bias_a; a.wB = wb_packed; a.bB = bias_b; a.scale = scale; a.shift = shift; a.res = residual;
+    a.zero_page = zero_page; a.y = y;
+    a.B = batch; a.C = channels; a.H = h; a.W = w; a.dA = d_a; a.dB = d_b; a.relu_post = relu_post;
+    a.CP = (channels + 31) / 32 * 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tok = timer_begin("conv1d_pair", st);
+    hipLaunchKernelGGL(k_conv1d_pair, dim3(batch * h), dim3(256), lds, st, a);
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}

@@ -7,11 +7,15 @@ The torch forward below is kept for training mode.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import ConvLayer
+from .ops import Conv1dPair, ConvLayer
+
+_USE_PAIRS = os.environ.get("LAV_ERFNET_PAIRS", "1") != "0"   # A/B switch: 0 = four lav_conv2d launches per block
 
 
 def _affine(bn, sl):
@@ -68,7 +72,15 @@ class non_bottleneck_1d(nn.Module):  # name kept: it is part of pickled/traced c
         b = ConvLayer.from_module(self.conv1x3_1, self.bn1, relu_post=True, device=device)
         c = ConvLayer.from_module(self.conv3x1_2, relu_post=True, device=device)
         d = ConvLayer.from_module(self.conv1x3_2, self.bn2, relu_post=True, device=device)   # (+x) then ReLU
-        return lambda x: d(c(b(a(x))), residual=x)
+        # each 3x1 -> 1x3 pair as ONE launch (row-tile kernel, intermediate in LDS) where the shape allows it
+        p1 = Conv1dPair(self.conv3x1_1, self.conv1x3_1, self.bn1, device=device)
+        p2 = Conv1dPair(self.conv3x1_2, self.conv1x3_2, self.bn2, device=device)
+
+        def run(x):
+            if _USE_PAIRS and p1.supported(x) and p2.supported(x):
+                return p2(p1(x), residual=x)
+            return d(c(b(a(x))), residual=x)
+        return run
 
 
 class UpsamplerBlock(nn.Module):

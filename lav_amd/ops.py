@@ -309,6 +309,57 @@ class ConvLayer:
         return out
 
 
+class Conv1dPair:
+    """conv(3,1) -> ReLU -> conv(1,3) (+ eval BatchNorm, + residual, ReLU) as ONE lav_conv1d_pair launch: half of ERFNet's
+    non_bottleneck_1d block.  `supported(x)` tells whether the row-tile kernel takes this shape."""
+
+    def __init__(self, conv_a, conv_b, bn=None, relu_post=True, device=None):
+        lib = _lib.load()
+        ch = conv_a.in_channels
+        if not (conv_a.kernel_size == (3, 1) and conv_b.kernel_size == (1, 3) and conv_a.out_channels == ch == conv_b.in_channels ==
+                conv_b.out_channels and conv_a.stride == (1, 1) and conv_b.stride == (1, 1)
+                and conv_a.padding == (conv_a.dilation[0], 0) and conv_b.padding == (0, conv_b.dilation[1])):
+            raise RuntimeError("Conv1dPair: expects conv(3,1) then conv(1,3), same channels, stride 1, 'same' padding")
+        self.ch, self.da, self.db = ch, conv_a.dilation[0], conv_b.dilation[1]
+        dev = device if device is not None else conv_a.weight.device
+        nfl = lib.lav_conv1d_pair_packed_weight_floats(ch)
+        packed = []
+        for conv in (conv_a, conv_b):
+            w = conv.weight.detach().to("cpu", torch.float32).reshape(ch, ch, 3).contiguous()
+            out = torch.empty(nfl, dtype=torch.float32)
+            check(lib.lav_conv1d_pair_pack_weights(ch, w.data_ptr(), out.data_ptr()), "lav_conv1d_pair_pack_weights")
+            packed.append(out.to(dev))
+        self.wa, self.wb = packed
+        self.ba = conv_a.bias.detach().to(dev, torch.float32).contiguous()
+        self.bb = conv_b.bias.detach().to(dev, torch.float32).contiguous()
+        self.scale = self.shift = None
+        if bn is not None:
+            s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+            self.scale = s.float().to(dev)
+            self.shift = (bn.bias.detach().double() - bn.running_mean.detach().double() * s).float().to(dev)
+        self.relu_post = bool(relu_post)
+
+    def supported(self, x: torch.Tensor) -> bool:
+        w = x.shape[3]
+        return (w in (32, 64, 128) and self.ch % 16 == 0 and (self.ch + 31) // 32 <= 128 // w
+                and _lib.load().lav_conv1d_pair_lds_bytes(self.ch, w, self.db) <= 160 * 1024)
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = _f32c(x, "x")
+        B, ch, h, w = x.shape
+        if ch != self.ch:
+            raise RuntimeError(f"Conv1dPair: input has {ch} channels, layer expects {self.ch}")
+        if residual is not None:
+            residual = _f32c(residual, "residual")
+            if residual.shape != x.shape:
+                raise RuntimeError("residual shape mismatch")
+        y = torch.empty_like(x)
+        check(_lib.load().lav_conv1d_pair(B, ch, h, w, self.da, self.db, _ptr(x), _ptr(self.wa), _ptr(self.ba), _ptr(self.wb),
+                                          _ptr(self.bb), _ptr(self.scale), _ptr(self.shift), _ptr(residual), int(self.relu_post),
+                                          _ptr(y), _stream()), "lav_conv1d_pair")
+        return y
+
+
 def crop_rotate(features: torch.Tensor, locs: torch.Tensor, oris: torch.Tensor, pixels_per_meter: float, crop: int,
                 offset_x: float, offset_y: float) -> torch.Tensor:
     """features (1 or N, C, H, W), locs (N,2), oris (N,) in HBM -> (N, C, crop, crop)."""

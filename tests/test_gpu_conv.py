@@ -142,3 +142,41 @@ def test_workspace_growth_does_not_invalidate_captured_graphs():
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, ref) and len(junk) == 3 and len(hog) == 8
+
+
+@pytest.mark.parametrize("ch,h,w,d,batch,with_res", [(128, 36, 32, 1, 3, True), (128, 36, 32, 2, 3, False), (128, 36, 32, 16, 2, True),
+                                                        (64, 72, 64, 1, 3, True), (16, 144, 128, 1, 2, True), (128, 5, 32, 8, 1, True),
+                                                        (32, 7, 128, 4, 1, False), (48, 9, 64, 3, 2, True)])
+def test_conv1d_pair_matches_torch(ch, h, w, d, batch, with_res):
+    """lav_conv1d_pair (conv3x1 -> ReLU -> conv1x3 -> BN -> +x -> ReLU in one launch) vs torch CPU fp32
+    (lav/models/erfnet.py:45-62), incl. dilation 16 on a 36-row image (taps fall outside: zero padding) and odd heights."""
+    from lav_amd import ops
+    g = torch.Generator().manual_seed(ch * 1000 + w + d)
+    ca = torch.nn.Conv2d(ch, ch, (3, 1), padding=(d, 0), dilation=(d, 1))
+    cb = torch.nn.Conv2d(ch, ch, (1, 3), padding=(0, d), dilation=(1, d))
+    bn = torch.nn.BatchNorm2d(ch, eps=1e-3).eval()
+    with torch.no_grad():
+        for p in list(ca.parameters()) + list(cb.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 / (3 * ch) ** 0.5 if p.dim() > 1 else 0.1))
+        bn.weight.copy_(torch.rand(ch, generator=g) + 0.5); bn.bias.copy_(torch.randn(ch, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(ch, generator=g) * 0.1); bn.running_var.copy_(torch.rand(ch, generator=g) + 0.5)
+        x = torch.randn((batch, ch, h, w), generator=g)
+        ref = bn(cb(torch.relu(ca(x))))
+        ref = torch.relu(ref + x) if with_res else torch.relu(ref)
+    dev = torch.device("cuda")
+    pair = ops.Conv1dPair(ca, cb, bn, device=dev)
+    xd = x.to(dev)
+    assert pair.supported(xd)
+    y = pair(xd, residual=xd if with_res else None)
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), f"max err {err}"
+
+
+def test_conv1d_pair_rejects_unsupported_rows():
+    from lav_amd import ops
+    ca, cb = torch.nn.Conv2d(64, 64, (3, 1), padding=(1, 0)), torch.nn.Conv2d(64, 64, (1, 3), padding=(0, 1))
+    pair = ops.Conv1dPair(ca, cb, None, device=torch.device("cuda"))
+    assert not pair.supported(torch.zeros((1, 64, 8, 48))) and not pair.supported(torch.zeros((1, 64, 8, 128)))
+    with pytest.raises(RuntimeError, match="row width"):
+        pair(torch.zeros((1, 64, 8, 48), device="cuda"))
