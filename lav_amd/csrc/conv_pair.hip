@@ -22,6 +22,7 @@
 //
 // Bound: launch/latency (a pair is 0.06-0.45 GFLOP); the design target is the fixed cost, not the matrix pipes.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -43,9 +44,11 @@ __device__ __forceinline__ void load_w(const float *__restrict__ wp, int tap, in
     a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
 }
 
-__global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
+template <int KS>  // KS = 2: 8 waves, the two halves of the channel loop on different waves, partial sums combined through LDS
+__global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wid8 = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wid = wid8 & 3, kpart = wid8 >> 2;   // kpart: which half of the channel loop this wave walks (KS = 2)
     const int C = a.C, W = a.W, H = a.H, CP = a.CP;
     const int n = blockIdx.x / H, y = blockIdx.x - n * H;
     const int NPG = W >> 5;                       // 32-pixel groups per row: 1, 2 or 4
@@ -57,6 +60,8 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
     float *s_in = smem;                           // [C][3][W]
     float *s_mid = smem + C * 3 * W;              // [C][WM]
     const int nchunk = C >> 4;
+    const int ch_lo = kpart * (nchunk / KS), ch_hi = kpart == KS - 1 ? nchunk : ch_lo + nchunk / KS;
+    float *s_red = smem;                          // [4 waves][16][64] partial accumulators (aliases s_in once it is consumed)
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
     {
         const int W4 = W >> 2, F4 = C * 3 * W4;
         const float *xn = a.x + (long)n * C * H * W;
-        for (int f0 = 64 * wid; f0 < F4; f0 += 256) {   // wave-uniform: this wave's 64 float4 slots f0 .. f0+63
+        for (int f0 = 64 * wid8; f0 < F4; f0 += 256 * KS) {   // wave-uniform: this wave's 64 float4 slots f0 .. f0+63
             const int f = f0 + lane;
             const int q = f / W4, x4 = f - q * W4;
             const int c = q / 3, t = q - 3 * c;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
     float wa[3][8], wn[3][8];
     if (co_ok) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) load_w(a.wA, t, 0, nchunk, half, co_lane, CP, wa[t]);
+        for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch_lo, nchunk, half, co_lane, CP, wa[t]);
     }
     float bAv[16], bBv[16], sv[16], tv[16];
 #pragma unroll
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
         tv[r] = a.scale ? a.shift[co] : 0.f;
     }
     // zero halo of the intermediate row
-    for (int i = tid; i < C * 2 * a.dB; i += 256) {
+    for (int i = tid; i < C * 2 * a.dB; i += 256 * KS) {
         const int c = i / (2 * a.dB), j = i - c * 2 * a.dB;
         s_mid[c * WM + (j < a.dB ? j : W + j)] = 0.f;
     }
@@ -101,8 +106,8 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (co_ok) {
-        for (int ch = 0; ch < nchunk; ++ch) {
-            if (ch + 1 < nchunk) {
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            if (ch + 1 < ch_hi) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch + 1, nchunk, half, co_lane, CP, wn[t]);
             }
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
 #pragma unroll
                 for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][cp], b[cp * 2 * 3 * W], acc, 0, 0, 0);
             }
-            if (ch + 1 < nchunk) {
+            if (ch + 1 < ch_hi) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -121,7 +126,21 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
         }
         // first fragments of phase B travel while the intermediate is written
 #pragma unroll
-        for (int t = 0; t < 3; ++t) load_w(a.wB, t, 0, nchunk, half, co_lane, CP, wa[t]);
+        for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch_lo, nchunk, half, co_lane, CP, wa[t]);
+    }
+    if constexpr (KS == 2) {   // combine the two halves of K: upper waves park their accumulators in LDS (s_in is consumed)
+        __syncthreads();
+        if (kpart == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kpart == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+        }
+    }
+    if (co_ok && kpart == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -132,11 +151,10 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
     __syncthreads();
 
     // ---- phase B: horizontal taps over the intermediate
-    if (!co_ok) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        if (ch + 1 < nchunk) {
+    for (int ch = ch_lo; ch < ch_hi && co_ok; ++ch) {
+        if (ch + 1 < ch_hi) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch + 1, nchunk, half, co_lane, CP, wn[t]);
         }
@@ -146,13 +164,24 @@ __global__ __launch_bounds__(256) void k_conv1d_pair(PairArgs a) {
 #pragma unroll
             for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][cp], b[cp * 2 * WM], acc, 0, 0, 0);
         }
-        if (ch + 1 < nchunk) {
+        if (ch + 1 < ch_hi) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int cp = 0; cp < 8; ++cp) wa[t][cp] = wn[t][cp];
         }
     }
+    if constexpr (KS == 2) {
+        if (kpart == 1) {   // s_red aliases s_in, which nobody reads in phase B
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kpart == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+    }
+    if (!co_ok) return;
     // ---- epilogue
     const long plane = (long)H * W;
     const long base = (long)n * C * plane + (long)y * W + px;
@@ -212,7 +241,8 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
     }
     static bool attr_set = false;
     if (!attr_set) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     PairArgs a;
@@ -222,7 +252,13 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
     a.CP = (channels + 31) / 32 * 32;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("conv1d_pair", st);
-    hipLaunchKernelGGL(k_conv1d_pair, dim3(batch * h), dim3(256), lds, st, a);
+    // rows are few (one workgroup each, at most one per CU for ERFNet's shapes): put 8 waves on the channel loop when it
+    // is long enough to halve (the partial sums need 16 KB of the staging area)
+    static const bool no_split = getenv("LAV_PAIR_KSPLIT") && getenv("LAV_PAIR_KSPLIT")[0] == '0';
+    if (channels >= 64 && !no_split && (size_t)channels * 3 * w * sizeof(float) >= 16 * 1024)
+        hipLaunchKernelGGL(k_conv1d_pair<2>, dim3(batch * h), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL(k_conv1d_pair<1>, dim3(batch * h), dim3(256), lds, st, a);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

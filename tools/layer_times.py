@@ -33,6 +33,20 @@ def hooked(self, x, out=None, residual=None):
 
 
 ops.ConvLayer.__call__ = hooked
+pair_orig = ops.Conv1dPair.__call__
+
+
+def pair_hooked(self, x, residual=None):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y = pair_orig(self, x, residual=residual)
+    e1.record()
+    pairs.append((self, tuple(x.shape), e0, e1))
+    return y
+
+
+pairs = []
+ops.Conv1dPair.__call__ = pair_hooked
 with torch.no_grad():
     if which == "seg":
         x = torch.rand((3, 3, 288, 256), device=dev) * 255
@@ -47,12 +61,15 @@ with torch.no_grad():
         x = torch.randn((1, 64, 320, 320), device=dev)
         fn = lambda: lm.heads(lm.backbone(x))
     best = None
+    pbest = None
     for it in range(6):
-        records.clear()
+        records.clear(); pairs.clear()
         fn()
         torch.cuda.synchronize()
         t = [r[2].elapsed_time(r[3]) * 1e3 for r in records]
         best = t if best is None else [min(a, b) for a, b in zip(best, t)]
+        pt = [r[2].elapsed_time(r[3]) * 1e3 for r in pairs]
+        pbest = pt if pbest is None else [min(a, b) for a, b in zip(pbest, pt)]
     tot = 0
     for (layer, shp, _, _), us in zip(records, best):
         d = Conv.from_buffer_copy(layer.desc); d.batch, d.h, d.w = shp[0], shp[2], shp[3]
@@ -66,3 +83,7 @@ with torch.no_grad():
               f"stages={-(-(-(-nch // info[6])) // info[8])}")
         tot += us
     print(f"total {tot:.0f} us over {len(records)} conv launches")
+    if pairs:
+        for (layer, shp, _, _), us in zip(pairs, pbest):
+            print(f"P {layer.ch:4d} d{layer.da:2d} in {shp[0]}x{shp[2]}x{shp[3]:4d} {us:7.1f} us")
+        print(f"pairs total {sum(pbest):.0f} us over {len(pairs)} launches")
