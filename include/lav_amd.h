@@ -163,7 +163,8 @@ typedef struct lav_conv {
     int transposed, out_pad;             /* 1: ConvTranspose2d(stride, padding=pad_h/pad_w, output_padding) */
     int out_c_total, out_c_offset;       /* y is [batch][out_c_total][oh][ow]; channels [out_c_offset, +cout)
                                             are written (fused torch.cat, lidar.py:143) */
-    int relu_pre, relu_post, sigmoid;
+    int relu_pre, relu_post;
+    int sigmoid;       /* 0: none; k > 0: sigmoid on output channels >= k-1 of this convolution (1 = all of them) */
 } lav_conv;
 
 /* output spatial size of the convolution */

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                 v = fmaf(v, sv[r], tv[r]);
                 v += rv[r];
                 if (a.relu_post) v = v > 0.f ? v : 0.f;
-                if (a.sigmoid) v = 1.f / (1.f + expf(-v));
+                if (a.sigmoid && cov[r] >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
                 if (pix_ok && cov[r] < a.cout) a.y[cbase + (long)cov[r] * a.OH * a.OW + pix] = v;
             }
         }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_conv_reduce(ConvArgs a, int batch) {
     const long idx = ((long)n * a.out_c_total + a.out_c_offset + co) * plane_o + pix;
     if (a.res) v += a.res[idx];
     if (a.relu_post) v = v > 0.f ? v : 0.f;
-    if (a.sigmoid) v = 1.f / (1.f + expf(-v));
+    if (a.sigmoid && co >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
     a.y[idx] = v;
 }
 

@@ -135,13 +135,25 @@ class GraphedFramePipeline(FramePipeline):
         self.b_tel = torch.zeros((1, 3, 192, 480), **f)
         self.b_nxp = torch.zeros((2,), **f)
         self.ring = torch.full((self.num_frame_keep, 2 * P, 8), float("nan"), **f)
-        self.b_slot = torch.zeros((1,), dtype=torch.long, device=dev)
-        self.b_sweeps = torch.zeros((num_sweeps := self.num_frame_stack + 1,), dtype=torch.long, device=dev)
-        self.b_R = torch.zeros((num_sweeps, 3, 3), **f)
-        self.b_t = torch.zeros((num_sweeps, 3), **f)
+        # per-frame host values travel in ONE pinned staging buffer each way (pageable copies cost ~10 us apiece on the
+        # critical path): [slot i64 | sweeps 3 x i64 | R 3x3x3 f32 | t 3x3 f32] down, the peak rows up, (loc, ori) rows down
+        num_sweeps = self.num_frame_stack + 1
+        if num_sweeps != 3:
+            raise NotImplementedError("GraphedFramePipeline is laid out for 3 stacked sweeps (num_frame_stack = 2)")
+        self.h_pose = torch.zeros((176,), dtype=torch.uint8).pin_memory()
+        self.d_pose = torch.zeros((176,), dtype=torch.uint8, device=dev)
+        self.b_slot, self.b_sweeps = self.d_pose[0:8].view(torch.long), self.d_pose[8:32].view(torch.long)
+        self.b_R, self.b_t = self.d_pose[32:140].view(torch.float32).view(3, 3, 3), self.d_pose[140:176].view(torch.float32).view(3, 3)
+        hp = self.h_pose.numpy()
+        self.hn_slot, self.hn_sweeps = hp[0:8].view(np.int64), hp[8:32].view(np.int64)
+        self.hn_R, self.hn_t = hp[32:140].view(np.float32).reshape(3, 3, 3), hp[140:176].view(np.float32).reshape(3, 3)
+        self.h_det = torch.zeros((2, 15, 7), dtype=torch.float32).pin_memory()
+        self.h_actors = torch.zeros((45,), dtype=torch.float32).pin_memory()      # [15 x (x, y) | 15 x ori]
+        self.d_actors = torch.zeros((45,), **f)
+        self.hn_det, self.hn_actors = self.h_det.numpy(), self.h_actors.numpy()
+        self.ev_det = torch.cuda.Event()
         self.b_features = None   # (1,384,160,160): written by the lidar graph, read by heads / ego / others
-        self.b_locs = torch.zeros((15, 2), **f)
-        self.b_oris = torch.zeros((15,), **f)
+        self.b_locs, self.b_oris = self.d_actors[:30].view(15, 2), self.d_actors[30:]
         self.b_zero = torch.zeros((1, 4), **f)   # the ego vehicle's own (loc, ori)
         # capture streams double as workspace keys (lav_amd.ops._workspace): graphs that run concurrently must not
         # share split-K scratch, graphs of one stream may
@@ -241,10 +253,11 @@ class GraphedFramePipeline(FramePipeline):
             else:  # history not that deep yet: point at a slot that is still all-NaN (never written) or stale-free
                 Rs.append([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]]); ts.append([0., 0., 0.])
                 sweeps.append((slot - age) % self.num_frame_keep)
-        self.b_slot.copy_(torch.tensor([slot]), non_blocking=True)
-        self.b_sweeps.copy_(torch.tensor(sweeps), non_blocking=True)
-        self.b_R.copy_(torch.tensor(Rs, dtype=torch.float32), non_blocking=True)
-        self.b_t.copy_(torch.tensor(ts, dtype=torch.float32), non_blocking=True)
+        self.hn_slot[0] = slot
+        self.hn_sweeps[:] = sweeps
+        self.hn_R[:] = np.asarray(Rs, np.float64).astype(np.float32)
+        self.hn_t[:] = np.asarray(ts, np.float64).astype(np.float32)
+        self.d_pose.copy_(self.h_pose, non_blocking=True)
 
     @torch.no_grad()
     def step(self, lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value):
@@ -277,15 +290,19 @@ class GraphedFramePipeline(FramePipeline):
             o_ego = self._replay(("ego", cmd_value), self._g_ego, self.s_ego, cmd_value)
         o_heads = self._replay("heads", self._g_heads, self.s_cap)
         self.frame_no += 1
-        det_rows = o_heads["det_raw"].cpu().tolist()      # the frame's only blocking device->host copy before the others branch
-        det = self._decode(det_rows)
+        # the frame's only blocking device->host copy before the others branch: 840 bytes into pinned memory
+        self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
+        self.ev_det.record(main)
+        self.ev_det.synchronize()
+        det = self._decode(self.hn_det.tolist())
         up = self.infer_model.uniplanner
         H, W = self.b_features.size(2) * 2, self.b_features.size(3) * 2
         locs, oris = up.others_from_detections(det[1], H, W)
         N = min(len(locs), 15)
         if N > 0:
-            self.b_locs[:N].copy_(torch.tensor(locs[:N], dtype=torch.float32), non_blocking=True)
-            self.b_oris[:N].copy_(torch.tensor(oris[:N], dtype=torch.float32), non_blocking=True)
+            self.hn_actors[:2 * N] = np.asarray(locs[:N], np.float32).reshape(-1)
+            self.hn_actors[30:30 + N] = np.asarray(oris[:N], np.float32)
+            self.d_actors.copy_(self.h_actors, non_blocking=True)
             ob = self._replay(("others", N), self._g_others, self.s_cap, N)
             other_cast, other_cmds = ob["other_cast_locs"], ob["other_cast_cmds"]
         else:

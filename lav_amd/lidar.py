@@ -183,12 +183,29 @@ class LiDARModel(_Engine):
                        ("running_mean", "running_var", "weight", "bias"))
             hid = w.shape[0]
             per = hs[0].net[0].weight.shape[0]
-            eng = dict(device=dev,
+            # the four ConvTranspose2d(64 -> 2/2/2/3) as ONE transposed convolution 256 -> 9 with a block-diagonal weight
+            # (three launches less on the frame's critical path; the extra multiplies by zero are free at cout = 9)
+            cts = [h.net[3] for h in hs]
+            for h in hs:
+                if not (h._sigmoid or isinstance(h.output_activation, nn.Identity)):
+                    raise RuntimeError("Head.output_activation must be identity or sigmoid for the fused epilogue")
+            outs = [ct.weight.shape[1] for ct in cts]
+            wd = torch.zeros((hid, sum(outs), *cts[0].weight.shape[2:]), dtype=torch.float32)
+            o = 0
+            for i, ct in enumerate(cts):
+                wd[i * per:(i + 1) * per, o:o + outs[i]] = ct.weight.detach().cpu()
+                o += outs[i]
+            sig = [h._sigmoid for h in hs]
+            if any(sig[:-1]) or not all(isinstance(h.output_activation, nn.Identity) for h, s_ in zip(hs, sig) if not s_):
+                raise RuntimeError("fused head deconvolution expects the sigmoid head last")
+            eng = dict(device=dev, outs=outs,
                        conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=dev),
-                       deconvs=[h.deconv_layer(dev, in_c_total=hid, in_c_offset=i * per) for i, h in enumerate(hs)])
+                       deconv=ConvLayer(wd, stride=2, padding=1, transposed=True, output_padding=1,
+                                        bias=torch.cat([ct.bias.detach().cpu() for ct in cts]),
+                                        sigmoid=(1 + sum(outs[:-1])) if sig[-1] else 0, device=dev))
             object.__setattr__(self, "_eng", eng)
-        hidden = self._eng["conv"](features)
-        return tuple(d(hidden) for d in self._eng["deconvs"])
+        fused = self._eng["deconv"](self._eng["conv"](features))          # (B, 9, 2H, 2W)
+        return tuple(torch.split(fused, self._eng["outs"], dim=1))
 
     def forward(self, lidars, num_points):
         features = self.backbone(self.point_pillar_net(lidars, num_points))
