@@ -165,6 +165,8 @@ typedef struct lav_conv {
                                             are written (fused torch.cat, lidar.py:143) */
     int relu_pre, relu_post;
     int sigmoid;       /* 0: none; k > 0: sigmoid on output channels >= k-1 of this convolution (1 = all of them) */
+    int target_cus;    /* 0 = plan for the whole chip (256 CUs); n: plan tiles / split-K to fill n CUs - for layers of a
+                          network that runs on a side stream next to another network's kernels */
 } lav_conv;
 
 /* output spatial size of the convolution */

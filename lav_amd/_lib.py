@@ -33,7 +33,7 @@ class Camera(C.Structure):
 class Conv(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "batch", "in_c_total", "in_c_offset", "cin", "h", "w", "cout", "kh", "kw", "stride", "pad_h", "pad_w",
-        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid")]
+        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid", "target_cus")]
 
 
 # name -> (restype, argtypes); every symbol declared in include/lav_amd.h

@@ -442,6 +442,9 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     // part of the search whenever a layer has fewer tiles than CUs, so a layer never lands a few workgroups above a
     // multiple of 256.
     const int nchunks = (c.cin + CK - 1) / CK;
+    // CUs the plan aims to fill: a layer that runs beside another stream's kernels is better off NOT claiming every CU
+    static const long ncu_env = [] { const char *e = getenv("LAV_CONV_CUS"); const int v = e ? atoi(e) : 0; return (long)(v >= 16 && v <= 256 ? v : 256); }();
+    const long ncu = c.target_cus >= 16 && c.target_cus <= 256 ? c.target_cus : ncu_env;
     double best = 1e30;
     Geo bg{};
     bool found = false;
@@ -463,8 +466,8 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
             const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
             for (int ks = 1; ks <= ks_max; ++ks) {
                 const long wgs = g.nwg * ks;
-                const double t = (double)((wgs + 255) / 256) * ((nchunks + ks - 1) / ks) * unit +
-                                 (double)((wgs + 256 * per_cu - 1) / (256 * per_cu)) * 5.0 + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
+                const double t = (double)((wgs + ncu - 1) / ncu) * ((nchunks + ks - 1) / ks) * unit +
+                                 (double)((wgs + ncu * per_cu - 1) / (ncu * per_cu)) * 5.0 + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
                 if (t < best * (ks > 1 ? 0.97 : 1.0) - 1e-9) {   // a larger split must pay for its partial-sum traffic
                     best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; a.ksplit = ks;
                 }

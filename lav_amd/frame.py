@@ -10,6 +10,7 @@ detection decode inside InferModel.det_inference.
 from __future__ import annotations
 
 import math
+import os
 from collections import deque
 
 import numpy as np
@@ -159,6 +160,12 @@ class GraphedFramePipeline(FramePipeline):
         # share split-K scratch, graphs of one stream may
         self.s_cap, self.s_bra, self.s_ego = (torch.cuda.Stream(dev) for _ in range(3))
         self.ev_in, self.ev_feat = torch.cuda.Event(), torch.cuda.Event()
+        # the brake net runs beside the LiDAR chain: its layers are planned for part of the chip so that both fit
+        side = int(os.environ.get("LAV_BRAKE_CUS", "128"))
+        trunk = getattr(self.bra_model, "conv_backbone", None)
+        if side and trunk is not None:
+            object.__setattr__(trunk, "target_cus", side)
+            trunk._drop()
         self.graphs, self.outs = {}, {}
         self.frame_no = 0
         self.poses = deque()

@@ -51,7 +51,7 @@ class ResNet(_Engine):
             return self._eng
         def cl(conv, bn, **kw):
             return ConvLayer(conv.weight, stride=conv.stride[0], padding=conv.padding, bn=_bn_tuple(bn), bn_eps=bn.eps,
-                             device=device, **kw)
+                             device=device, target_cus=getattr(self, "target_cus", 0), **kw)
         blocks = []
         for i in range(1, 5):
             for blk in getattr(self, f"layer{i}"):
