@@ -406,7 +406,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
     const long Q = (long)p.QH * p.QW;
     struct Geo { int rowblock, xblocks, Wst, ROWS, plane_pad, tap_group, in_bufs; size_t lds; long nwg; bool ok; };
-    auto geo = [&](int mp, int mc, int rowblock, int in_bufs) {
+    auto geo = [&](int mp, int mc, int rowblock, int in_bufs, int tg_opt) {
         Geo g;
         const int PIXW = 128 * mp, CO_T = 32 * mc;
         g.rowblock = rowblock; g.in_bufs = in_bufs; g.xblocks = 1;
@@ -421,11 +421,11 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         const size_t LDS_MAX = 160 * 1024;
         const long pad = ((long)g.ROWS * g.Wst + 63) / 64 * 64;
         auto bytes_with = [&](int tg) { return (size_t)(g.in_bufs * (size_t)CK * pad + 2 * (size_t)tg * CK * CO_T) * 4; };
-        // weight slab: all taps when they fit, else one kernel row, else a single tap
-        g.tap_group = 0;
+        // weight slab: all taps of a class, one kernel row, or a single tap (tg_opt 0 / 1 / 2)
+        static const int force_tg = [] { const char *e = getenv("LAV_CONV_FORCE_TG"); return e ? atoi(e) : 0; }();   // experiments
         const int opts[3] = {p.taps_per_class, p.nclasses == 1 ? c.kw : 1, 1};
-        for (int tg : opts)
-            if (tg >= 1 && tg <= TAP_GROUP && bytes_with(tg) <= LDS_MAX) { g.tap_group = tg; break; }
+        g.tap_group = force_tg ? force_tg : opts[tg_opt];
+        if (g.tap_group < 1 || g.tap_group > TAP_GROUP || bytes_with(g.tap_group) > LDS_MAX) g.tap_group = 0;
         g.plane_pad = (int)pad;
         g.lds = bytes_with(std::max(g.tap_group, 1));
         g.ok = g.tap_group >= 1 && pad <= 256 * NPOS_MAX && g.lds <= LDS_MAX;
@@ -454,17 +454,29 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     for (auto &cd : cand) {
         if (cd[1] == 2 && c.cout <= 32) continue;
         for (int mode = 0; mode < 4; ++mode) {   // preference on ties: linearised before row-blocked, double before single buffer
-            const Geo g = geo(cd[0], cd[1], mode >> 1, (mode & 1) ? 1 : 2);
+          for (int tg_opt = 0; tg_opt < 3; ++tg_opt) {
+            if (tg_opt > 0 && (tg_opt == 1 ? (p.nclasses == 1 ? c.kw : 1) == p.taps_per_class : (p.nclasses == 1 ? c.kw : 1) == 1)) continue;  // duplicate slab size
+            const Geo g = geo(cd[0], cd[1], mode >> 1, (mode & 1) ? 1 : 2, tg_opt);
             if (!g.ok) continue;
             double unit = (0.45 + 0.3 * cd[0] * cd[1]) * p.taps_per_class;
+            const long per_cu = std::max<long>(1, std::min<long>(2, (long)(160 * 1024 / g.lds)));
             if (g.in_bufs == 1) unit *= 1.2;
             if (g.tap_group < full_group) unit *= 1.3;
             unit += 0.001 * g.plane_pad;   // issuing the chunk's DMA: ~9 instructions per 64 staged positions and channel, same waves
-            const long per_cu = std::max<long>(1, std::min<long>(2, (long)(160 * 1024 / g.lds)));
-            const int ks_max = nchunks >= 4 ? std::min(16, nchunks / 2) : 1;
+            // two workgroups per CU hide each other's barrier / DMA stalls: measured on the 384->256 head convolution
+            // (1200 workgroups): 76 KB single-buffered tiles 556 us vs 128 KB double-buffered ones 643 us.  It only pays
+            // when a layer is several rounds deep (BEV-size layers measured no gain).
+            const bool deep = g.nwg * std::max(1, std::min(16, nchunks / 2)) >= 3 * ncu && g.nwg >= ncu;
+            if (per_cu >= 2 && deep) unit *= g.in_bufs == 1 ? 0.85 / 1.2 : 0.85;
+            static const int force_ks = [] { const char *e = getenv("LAV_CONV_FORCE_KS"); return e ? atoi(e) : 0; }();   // experiments
+            static const int force_mode = [] { const char *e = getenv("LAV_CONV_FORCE_MODE"); return e ? atoi(e) : -1; }();
+            static const int force_tile = [] { const char *e = getenv("LAV_CONV_FORCE_TILE"); return e ? atoi(e) : 0; }();
+            if (force_mode >= 0 && mode != force_mode) continue;
+            if (force_tile && cd[0] * 10 + cd[1] != force_tile) continue;
+            const int ks_max = force_ks ? force_ks : (nchunks >= 4 ? std::min(16, nchunks / 2) : 1);
             // partial sums: ks slabs of the output written by the tiles and read back by the reduce launch (~4 TB/s)
             const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
-            for (int ks = 1; ks <= ks_max; ++ks) {
+            for (int ks = force_ks ? force_ks : 1; ks <= ks_max; ++ks) {
                 const long wgs = g.nwg * ks;
                 const double t = (double)((wgs + ncu - 1) / ncu) * ((nchunks + ks - 1) / ks) * unit +
                                  (double)((wgs + ncu * per_cu - 1) / (ncu * per_cu)) * 5.0 + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
@@ -472,6 +484,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
                     best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; a.ksplit = ks;
                 }
             }
+          }
         }
     }
     LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
