@@ -13,6 +13,8 @@
 // final top-k selection.  Compiled with -ffp-contract=off: the rotation below is two roundings per product-sum exactly
 // as written, like the oracle.
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -102,10 +104,12 @@ struct PeakArgs {
     float *out;                       // [ncls][max_det][3 + size_c + ori_c]
     unsigned long long *cand;         // [ncls][H*W]
     int *count;                       // [ncls] + ticket at [ncls]
+    unsigned long long *trace;        // debug (LAV_PEAKS_TRACE): [workgroup][8] wall-clock stamps, or null
 };
 
 __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
-    extern __shared__ __align__(16) unsigned char dyn_smem[];  // candidate keys of one class (last workgroup only)
+#define PK_STAMP(i) do { if (a.trace && threadIdx.x == 0) a.trace[((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+    PK_STAMP(0);
     __shared__ unsigned long long s_u64[256];
     __shared__ float s_tile[(PT_H + PEAK_MAX_KS - 1) * (PT_W + PEAK_MAX_KS - 1)];
     __shared__ int s_flag, s_cnt, s_base;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
         s_tile[j] = v;
     }
     __syncthreads();
+    PK_STAMP(1);
     const int lx = tid % PT_W, ly = tid / PT_W;
     const int x = x0 + lx, y = y0 + ly;
     // possible_det = heat - (max > heat)*1e5: only non-suppressed pixels can reach the top-k while there are at least
@@ -138,13 +143,15 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
             for (int dx = 0; dx < a.ks; ++dx) m = fmaxf(m, s_tile[(ly + dy) * TW + lx + dx]);
         if (!(m > c)) key = ((unsigned long long)ordered(c) << 32) | (0xffffffffu - (unsigned)(y * a.W + x));
     }
+    PK_STAMP(2);
     s_u64[tid] = key;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     int local = -1;
     if (key) {
         int rank = 0;
-        for (int j = 0; j < 256; ++j) rank += s_u64[j] > key;
+#pragma unroll 16
+        for (int j = 0; j < 256; ++j) rank += s_u64[j] > key;   // independent LDS reads, 16 in flight
         if (rank < a.max_det) local = atomicAdd(&s_cnt, 1);   // LDS atomic: order inside the tile is irrelevant
     }
     __syncthreads();
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
     // ---- hand-off to the last workgroup (MI355X guide G16, write-through form: sc1 payload stores, every wave drains
     // its stores, barrier, one relaxed agent-scope ticket; the last arriver takes ONE acquire before plain loads).
     // A release fence per workgroup (buffer_wbl2 from 800 workgroups) made this kernel 107 us instead of ~15.
+    PK_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int total = gridDim.x * gridDim.y * gridDim.z;
@@ -166,27 +174,33 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
         s_flag = last;
     }
     __syncthreads();
+    PK_STAMP(4);
     if (!s_flag) return;
     const int ncol = 3 + a.size_c + a.ori_c;
     // final selection by the last workgroup: candidates of one class into LDS (when they fit), then max_det rounds of
     // "largest key below the previous pick" - wave reduction by DPP shuffles, one barrier per round
-    unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(dyn_smem);
+    constexpr int PER_THREAD = 24;   // candidates a thread keeps in registers: 256 * 24 = 6144 >= 400 tiles * 15
     for (int c = 0; c < a.ncls; ++c) {
         const int n = min(__hip_atomic_load(&a.count[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.H * a.W);
         const unsigned long long *cand = a.cand + (long)c * a.H * a.W;
-        const bool in_lds = n <= a.lds_cand;
-        __syncthreads();
-        if (in_lds) {
-            for (int j = tid; j < n; j += 256) s_cand[j] = cand[j];
-            __syncthreads();
-            cand = s_cand;
+        const bool in_regs = n <= 256 * PER_THREAD;
+        unsigned long long mine[PER_THREAD];
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; ++j) mine[j] = j * 256 + tid < n ? cand[j * 256 + tid] : 0ull;
         }
         unsigned long long bound = ~0ull;  // keys are unique (they carry the pixel index): select strictly below the last pick
         for (int d = 0; d < a.max_det; ++d) {
             unsigned long long best = 0;
-            for (int j = tid; j < n; j += 256) {
-                const unsigned long long k = cand[j];
-                if (k < bound && k > best) best = k;
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < PER_THREAD; ++j)
+                    if (mine[j] < bound && mine[j] > best) best = mine[j];
+            } else {
+                for (int j = tid; j < n; j += 256) {
+                    const unsigned long long k = cand[j];
+                    if (k < bound && k > best) best = k;
+                }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -203,6 +217,7 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
         }
     }
     __syncthreads();
+    PK_STAMP(5);
     for (int e = tid; e < a.ncls * a.max_det * ncol; e += 256) {
         const int col = e % ncol, d = (e / ncol) % a.max_det, c = e / (ncol * a.max_det);
         const unsigned long long best = s_win[c * PEAK_MAX_DET + d];
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
         }
         a.out[e] = v;
     }
+    PK_STAMP(6);
     if (tid <= a.ncls) __hip_atomic_store(&a.count[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
 }
 }  // namespace
@@ -276,9 +292,35 @@ extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("extract_peaks", st);
     const dim3 grid((w + PT_W - 1) / PT_W, (h + PT_H - 1) / PT_H, ncls);
-    // every tile contributes at most max_det candidates; keep them in LDS for the final selection when <= 48 KB
-    a.lds_cand = (int)std::min<long>((long)grid.x * grid.y * max_det, 6144);
-    hipLaunchKernelGGL(k_extract_peaks, grid, dim3(256), (size_t)a.lds_cand * sizeof(unsigned long long), st, a);
+    a.lds_cand = 0;
+    a.trace = nullptr;
+    static const bool want_trace = getenv("LAV_PEAKS_TRACE") != nullptr;
+    static unsigned long long *d_trace = nullptr;
+    static int runs = 0;
+    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    if (want_trace && nwg <= 4096) {
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, 4096 * 8 * sizeof(unsigned long long)));
+        LAV_HIP(hipMemsetAsync(d_trace, 0, nwg * 64, st));
+        a.trace = d_trace;
+    }
+    hipLaunchKernelGGL(k_extract_peaks, grid, dim3(256), 0, st, a);
+    if (a.trace && ++runs % 10 == 0) {
+        std::vector<unsigned long long> h(nwg * 8);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            for (size_t i = 0; i < nwg; ++i) t0 = std::min(t0, h[i * 8]);
+            double ph[4] = {0, 0, 0, 0}, last_start = 0, last_ticket = 0;
+            for (size_t i = 0; i < nwg; ++i) {
+                for (int k = 0; k < 4; ++k) ph[k] += (double)(h[i * 8 + k + 1] - h[i * 8 + k]) / 100.0;
+                last_start = std::max(last_start, (double)(h[i * 8] - t0) / 100.0);
+                last_ticket = std::max(last_ticket, (double)(h[i * 8 + 4] - t0) / 100.0);
+                if (h[i * 8 + 6]) fprintf(stderr, "[peaks trace] last workgroup: ticket at %.2f us, selection done %.2f, rows written %.2f\n",
+                                          (double)(h[i * 8 + 4] - t0) / 100.0, (double)(h[i * 8 + 5] - t0) / 100.0, (double)(h[i * 8 + 6] - t0) / 100.0);
+            }
+            fprintf(stderr, "[peaks trace] %zu wgs: last start %.2f us, last ticket %.2f | mean us: tile load %.2f | nms %.2f | rank+emit %.2f | drain+ticket %.2f\n",
+                    nwg, last_start, last_ticket, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg);
+        }
+    }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
