@@ -74,14 +74,19 @@ class BEVPlanner(DecoderMixin, _Engine):
             flat_bev = bev[:, None].expand(-1, N, -1, -1, -1)[pick["typs"]]
             other_embd = self.bev_conv_emb(self.crop_feature(flat_bev, pick["crop_locs"], pick["crop_oris"], ppm, crop))
             other_locs = pick["other_locs"]
-            other_cast_locs, other_cast_cmds = self.cast(other_embd), self.cast_cmd_pred(other_embd)
+            other_cast_cmds = self.cast_cmd_pred(other_embd)
         else:
             z = dict(dtype=bev.dtype, device=bev.device)
             other_locs = torch.zeros((N, self.num_plan, 2), **z)
             other_cast_locs = torch.zeros((N, self.num_cmds, self.num_plan, 2), **z)
             other_cast_cmds = torch.zeros((N, self.num_cmds), **z)
+            other_embd = None
         B = bev.size(0)
         ego_embd = self.bev_conv_emb(self.crop_feature(bev, bev.new_zeros((B, 2)), bev.new_zeros((B,)), ppm, crop))
-        ego_cast_locs = self.cast(ego_embd)
+        if other_embd is not None:     # one cast() over others + ego: same arithmetic, half the GRU launches
+            both = self.cast(torch.cat([other_embd, ego_embd]))
+            other_cast_locs, ego_cast_locs = both[:other_embd.size(0)], both[other_embd.size(0):]
+        else:
+            ego_cast_locs = self.cast(ego_embd)
         ego_plan_locs = self.plan(ego_embd, nxps, cast_locs=ego_cast_locs, pixels_per_meter=ppm, crop_size=crop)
         return other_locs, other_cast_locs, other_cast_cmds, ego_plan_locs, ego_cast_locs, self.cast_cmd_pred(ego_embd)

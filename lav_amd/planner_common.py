@@ -133,14 +133,19 @@ class DecoderMixin:
         return torch.stack([torch.cumsum(mlp(gru(u)[0]), dim=1) for gru, mlp in zip(grus, mlps)], dim=1)
 
     def _plan_torch(self, embd, nxp, plan_loc, pixels_per_meter, crop_size, cmd=-1):
-        u0 = (nxp * pixels_per_meter / crop_size * 2 - 1)[:, None].expand(-1, self.num_plan, -1)
-        branches = range(self.num_cmds) if cmd < 0 else [cmd]
+        """The reference loops over the six command branches (uniplanner.py:264-275); they share the GRU and never interact,
+        so they are run as ONE batched GRU call per refinement iteration (sequences ordered branch-major) - MIOpen's RNN
+        costs ~2 ms per call forward + backward whatever the batch, which made 30 calls the bulk of a training step."""
+        B, T = embd.size(0), self.num_plan
         if cmd >= 0:
             plan_loc = plan_loc[:, cmd:cmd + 1]
+        nb = plan_loc.size(1)
+        u0 = (nxp * pixels_per_meter / crop_size * 2 - 1)[:, None].expand(-1, T, -1).repeat(nb, 1, 1)        # (nb*B, T, 2)
+        h0 = embd.repeat(nb, 1)[None].contiguous()                                                            # (1, nb*B, 512)
         outs = []
         for _ in range(self.num_plan_iter):
-            locs = [torch.cumsum(self.plan_mlp(self.plan_gru(torch.cat([u0, plan_loc[:, j]], dim=2), embd[None].contiguous())[0]), dim=1)
-                    for j, _b in enumerate(branches)]
-            plan_loc = torch.stack(locs, dim=1) + plan_loc
+            u = torch.cat([u0, plan_loc.transpose(0, 1).reshape(nb * B, T, 2)], dim=2)
+            step = torch.cumsum(self.plan_mlp(self.plan_gru(u, h0)[0]), dim=1)                                # (nb*B, T, 2)
+            plan_loc = step.view(nb, B, T, 2).transpose(0, 1) + plan_loc
             outs.append(plan_loc)
         return torch.stack(outs, dim=1)

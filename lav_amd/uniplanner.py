@@ -89,7 +89,6 @@ class UniPlanner(DecoderMixin, _Engine):
             flat_bev = bev[:, None].expand(-1, N, -1, -1, -1)[sel]
             other_embd = self.lidar_conv_emb(self.crop_feature(flat_features, pick["crop_locs"], pick["crop_oris"], ppm / 2, crop))
             other_locs = pick["other_locs"]
-            other_cast_locs = self.cast(other_embd, mode="other")
             other_cast_cmds = self.cast_cmd_pred(other_embd)
             with torch.no_grad():
                 t_embd = teacher.bev_conv_emb(teacher.crop_feature(flat_bev.contiguous(), pick["crop_locs"], pick["crop_oris"], ppm, crop * 2))
@@ -100,6 +99,7 @@ class UniPlanner(DecoderMixin, _Engine):
             other_cast_locs = torch.zeros((N, self.num_cmds, self.num_plan, 2), **z)
             other_cast_cmds = torch.zeros((N, self.num_cmds), **z)
             other_cast_locs_expert, other_cast_cmds_expert = torch.zeros_like(other_cast_locs), torch.zeros_like(other_cast_cmds)
+            other_embd = None
         B = features.size(0)
         locs_jitter = (torch.rand((B, 2)) * 2 - 1).float().to(locs.device) * self.feature_x_jitter
         locs_jitter[:, 1] = 0
@@ -111,7 +111,13 @@ class UniPlanner(DecoderMixin, _Engine):
             t_embd = teacher.bev_conv_emb(teacher.crop_feature(bev, locs_jitter, oris_jitter, ppm, crop * 2))
             ego_cast_locs_expert = teacher.cast(t_embd)
             ego_plan_locs_expert = teacher.plan(t_embd, nxps, cast_locs=ego_cast_locs_expert, pixels_per_meter=ppm, crop_size=crop * 2)
-        ego_cast_locs = self.cast(ego_embd, mode="ego")
+        # the reference decodes others and ego with separate cast() calls on the same *_ego GRUs (uniplanner.py:296-300):
+        # one call over the concatenated embeddings is the same arithmetic in half the GRU launches
+        if other_embd is not None:
+            both = self.cast(torch.cat([other_embd, ego_embd]), mode="ego")
+            other_cast_locs, ego_cast_locs = both[:other_embd.size(0)], both[other_embd.size(0):]
+        else:
+            ego_cast_locs = self.cast(ego_embd, mode="ego")
         ego_plan_locs = self.plan(ego_embd, nxps, cast_locs=ego_cast_locs, pixels_per_meter=ppm, crop_size=crop * 2)
         return (other_locs, other_cast_locs, other_cast_cmds, other_cast_locs_expert, other_cast_cmds_expert,
                 ego_locs, ego_plan_locs, ego_cast_locs, self.cast_cmd_pred(ego_embd), ego_cast_locs_expert, ego_plan_locs_expert)
