@@ -128,9 +128,26 @@ class DecoderMixin:
 
     # ---- train mode: the same decoders as differentiable torch ops (uniplanner.py:255-308) ----------------------
     def _cast_torch(self, embd):
+        """Six independent GRU(512 -> 64) decoders on the same input == ONE GRU(512 -> 384) whose recurrent matrix is
+        block diagonal (gate-major stacking [r | z | n], each 6 x 64 rows).  The combined weights are assembled from the
+        six modules' parameters with differentiable torch ops on every call, so gradients reach the original tensors;
+        MIOpen then runs one RNN call instead of six (each ~2 ms forward + backward at these sizes)."""
         grus, mlps = self._cast_modules()
-        u = embd[:, None].expand(-1, self.num_plan, -1)
-        return torch.stack([torch.cumsum(mlp(gru(u)[0]), dim=1) for gru, mlp in zip(grus, mlps)], dim=1)
+        nc, H = len(grus), grus[0].hidden_size
+        gate = lambda name, g: torch.cat([getattr(m, name).view(3, H, -1)[g] for m in grus], dim=0)
+        w_ih = torch.cat([gate("weight_ih_l0", g) for g in range(3)], dim=0)                                   # (3*nc*H, 512)
+        w_hh = torch.cat([torch.block_diag(*[m.weight_hh_l0.view(3, H, H)[g] for m in grus]) for g in range(3)], dim=0)
+        b_ih = torch.cat([torch.cat([m.bias_ih_l0.view(3, H)[g] for m in grus]) for g in range(3)])
+        b_hh = torch.cat([torch.cat([m.bias_hh_l0.view(3, H)[g] for m in grus]) for g in range(3)])
+        B = embd.size(0)
+        u = embd[:, None].expand(-1, self.num_plan, -1).contiguous()
+        h0 = embd.new_zeros((1, B, nc * H))
+        out, _ = torch._VF.gru(u, h0, [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, self.training, False, True)      # (B, T, nc*H)
+        out = out.view(B, self.num_plan, nc, H)
+        w = torch.stack([m.weight for m in mlps])                                                               # (nc, 2, H)
+        b = torch.stack([m.bias for m in mlps])                                                                 # (nc, 2)
+        step = torch.einsum("btch,cdh->bctd", out, w) + b[None, :, None, :]
+        return torch.cumsum(step, dim=2)
 
     def _plan_torch(self, embd, nxp, plan_loc, pixels_per_meter, crop_size, cmd=-1):
         """The reference loops over the six command branches (uniplanner.py:264-275); they share the GRU and never interact,

@@ -69,6 +69,13 @@ class _Student(nn.Module):
         return lidar_out, uni_out
 
 
+def _scalars(loss, terms):
+    """Loss terms as Python floats with ONE device->host copy (the reference pays one float(tensor) sync per term)."""
+    keys = list(terms)
+    vals = torch.stack([loss.detach()] + [terms[k].detach() for k in keys]).tolist()
+    return dict(loss=vals[0], **dict(zip(keys, vals[1:])))
+
+
 def _ddp(module, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return module
@@ -157,7 +164,7 @@ class LAV:
         self.bev_optim.zero_grad()
         loss.backward()
         self.bev_optim.step()
-        return dict(loss=float(loss.detach()), **{k: float(v.detach()) for k, v in terms.items()})
+        return _scalars(loss, terms)
 
     def train_lidar(self, lidars, num_points, heatmaps, sizemaps, orimaps, bev, ego_locs, cmds, nxps, bras, locs, oris, typs,
                     num_objs):
@@ -173,7 +180,7 @@ class LAV:
         self.lidar_optim.zero_grad()
         loss.backward()
         self.lidar_optim.step()
-        info = dict(loss=float(loss.detach()), **{k: float(v.detach()) for k, v in terms.items()})
+        info = _scalars(loss, terms)
         if cfg.log_inference:
             info.update(self.mot_inference(lidars[0], num_points[0], cmds[0], nxps[0]))
         return info
