@@ -20,6 +20,7 @@ from . import ops
 from .model_inference import InferModel
 
 GAP = 5  # NUM_REPEAT + 1 (lav_agent_fast.py:32-33)
+_DIAG_SKIP = set(filter(None, os.environ.get("LAV_DIAG_SKIP", "").split(",")))   # timing diagnosis: skip side graphs
 
 
 def ego_box_mask(lidar: torch.Tensor) -> torch.Tensor:
@@ -220,7 +221,7 @@ class GraphedFramePipeline(FramePipeline):
         cast = transform_points(cast, oris[:, None].repeat(1, up.num_cmds)) + locs.view(n, 1, 1, 2)
         return dict(other_cast_locs=cast, other_cast_cmds=cmds)
 
-    def _replay(self, key, fn, stream, *args):
+    def _replay(self, key, fn, stream, *args, _skip=False):
         """Replay graph `key` on the current stream; first use: one eager run on the capture stream (builds the
         convolution engines and the per-stream workspaces), then the capture.  Every graph has a PRIVATE memory pool:
         graphs that share one may only be replayed in capture order."""
@@ -238,7 +239,8 @@ class GraphedFramePipeline(FramePipeline):
             torch.cuda.synchronize()
             self.ring.copy_(state[0]); self.b_prev.copy_(state[1])
             self.graphs[key], self.outs[key] = g, out
-        g.replay()
+        if not _skip:     # _skip: diagnosis only (LAV_DIAG_SKIP), outputs keep their last values
+            g.replay()
         return self.outs[key]
 
     def _set_pose_buffers(self):
@@ -290,11 +292,12 @@ class GraphedFramePipeline(FramePipeline):
         o_lidar = self._replay("lidar", self._g_lidar, self.s_cap)
         self.s_bra.wait_event(self.ev_in)
         with torch.cuda.stream(self.s_bra):
-            o_bra = self._replay("brake", self._g_brake, self.s_bra)
+            o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
         self.ev_feat.record(main)                                      # feature map complete
         self.s_ego.wait_event(self.ev_feat)
         with torch.cuda.stream(self.s_ego):
-            o_ego = self._replay(("ego", cmd_value), self._g_ego, self.s_ego, cmd_value)
+            o_ego = self._replay(("ego", cmd_value), self._g_ego, self.s_ego, cmd_value,
+                                 _skip="ego" in _DIAG_SKIP and ("ego", cmd_value) in self.graphs)
         o_heads = self._replay("heads", self._g_heads, self.s_cap)
         self.frame_no += 1
         # the frame's only blocking device->host copy before the others branch: 840 bytes into pinned memory
