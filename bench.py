@@ -243,7 +243,7 @@ def main():
         lm = pipe.infer_model.lidar_model
         feats = torch.randn((1, 384, 160, 160), device=device)
         lm.heads(feats)
-        layer = lm._eng["conv"]
+        layer = lm._head_engine(lm.ALL_HEADS, device)["conv"]
         for _ in range(3):
             layer(feats)
         torch.cuda.synchronize()

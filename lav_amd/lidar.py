@@ -170,42 +170,48 @@ class LiDARModel(_Engine):
         self.seg_head = Head(6 * nf, 3, output_activation=torch.sigmoid)
         self._drop()
 
-    def heads(self, features):
-        """(center, box, ori, seg) from the shared feature map: one fused 384->256 convolution, then four
-        ConvTranspose2d(64->n) over their channel windows of the hidden tensor (lidar.py:30-33,159-161)."""
-        hs = (self.center_head, self.box_head, self.ori_head, self.seg_head)
-        if self.training:
-            return tuple(h(features) for h in hs)
-        if self._eng is None or self._eng["device"] != features.device:
-            dev = features.device
-            w = torch.cat([h.net[0].weight.detach() for h in hs], dim=0)
-            bn = tuple(torch.cat([getattr(h.net[2], n).detach() for h in hs]) for n in
-                       ("running_mean", "running_var", "weight", "bias"))
-            hid = w.shape[0]
-            per = hs[0].net[0].weight.shape[0]
-            # the four ConvTranspose2d(64 -> 2/2/2/3) as ONE transposed convolution 256 -> 9 with a block-diagonal weight
-            # (three launches less on the frame's critical path; the extra multiplies by zero are free at cout = 9)
-            cts = [h.net[3] for h in hs]
+    def _head_engine(self, names, device):
+        """Fused engine of a subset of the heads: ONE convolution 384 -> 64*len(names) (the 39 MB feature map is read once)
+        and ONE transposed convolution with a block-diagonal weight 64*len -> sum(outputs) (the extra multiplies by zero
+        are free at a handful of output channels); a sigmoid head must come last (lidar.py:30-33,159-161)."""
+        eng = self._eng if self._eng is not None and self._eng.get("device") == device else dict(device=device)
+        if names not in eng:
+            hs = [getattr(self, n) for n in names]
             for h in hs:
                 if not (h._sigmoid or isinstance(h.output_activation, nn.Identity)):
                     raise RuntimeError("Head.output_activation must be identity or sigmoid for the fused epilogue")
+            sig = [h._sigmoid for h in hs]
+            if any(sig[:-1]):
+                raise RuntimeError("fused head deconvolution expects the sigmoid head last")
+            w = torch.cat([h.net[0].weight.detach() for h in hs], dim=0)
+            bn = tuple(torch.cat([getattr(h.net[2], n).detach() for h in hs]) for n in ("running_mean", "running_var", "weight", "bias"))
+            per = hs[0].net[0].weight.shape[0]
+            cts = [h.net[3] for h in hs]
             outs = [ct.weight.shape[1] for ct in cts]
-            wd = torch.zeros((hid, sum(outs), *cts[0].weight.shape[2:]), dtype=torch.float32)
+            wd = torch.zeros((w.shape[0], sum(outs), *cts[0].weight.shape[2:]), dtype=torch.float32)
             o = 0
             for i, ct in enumerate(cts):
                 wd[i * per:(i + 1) * per, o:o + outs[i]] = ct.weight.detach().cpu()
                 o += outs[i]
-            sig = [h._sigmoid for h in hs]
-            if any(sig[:-1]) or not all(isinstance(h.output_activation, nn.Identity) for h, s_ in zip(hs, sig) if not s_):
-                raise RuntimeError("fused head deconvolution expects the sigmoid head last")
-            eng = dict(device=dev, outs=outs,
-                       conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=dev),
-                       deconv=ConvLayer(wd, stride=2, padding=1, transposed=True, output_padding=1,
-                                        bias=torch.cat([ct.bias.detach().cpu() for ct in cts]),
-                                        sigmoid=(1 + sum(outs[:-1])) if sig[-1] else 0, device=dev))
+            eng[names] = dict(outs=outs,
+                              conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=device),
+                              deconv=ConvLayer(wd, stride=2, padding=1, transposed=True, output_padding=1,
+                                               bias=torch.cat([ct.bias.detach().cpu() for ct in cts]),
+                                               sigmoid=(1 + sum(outs[:-1])) if sig[-1] else 0, device=device))
             object.__setattr__(self, "_eng", eng)
-        fused = self._eng["deconv"](self._eng["conv"](features))          # (B, 9, 2H, 2W)
-        return tuple(torch.split(fused, self._eng["outs"], dim=1))
+        return self._eng[names]
+
+    ALL_HEADS = ("center_head", "box_head", "ori_head", "seg_head")
+
+    def heads(self, features, names=ALL_HEADS):
+        """Outputs of the named heads (default: center, box, ori, seg) from the shared feature map.  The frame pipeline
+        asks for the three detection heads first - the others branch waits on them - and for the segmentation head
+        on a side stream."""
+        if self.training:
+            return tuple(getattr(self, n)(features) for n in names)
+        e = self._head_engine(tuple(names), features.device)
+        fused = e["deconv"](e["conv"](features))          # (B, sum(outs), 2H, 2W)
+        return tuple(torch.split(fused, e["outs"], dim=1))
 
     def forward(self, lidars, num_points):
         features = self.backbone(self.point_pillar_net(lidars, num_points))
