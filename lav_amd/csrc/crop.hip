@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void k_crop_rotate(const float *__restrict__ f
     const float *f = feat + (feat_batch > 1 ? (long)n * C * plane : 0);
     const int c_lo = blockIdx.y * c_per_block, c_hi = min(C, c_lo + c_per_block);
     float *o_ = out + ((long)n * C) * crop * crop + pix;
+#pragma unroll 8   // 32 independent gathers in flight per thread: the loop is latency bound, not bandwidth bound
     for (int c = c_lo; c < c_hi; ++c) {
         const float *p = f + c * plane;
         const float v = p[cy0 * W + cx0] * w00 + p[cy0 * W + cx1] * w01 + p[cy1 * W + cx0] * w10 + p[cy1 * W + cx1] * w11;
