@@ -304,14 +304,12 @@ class GraphedFramePipeline(FramePipeline):
         self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
         self.ev_det.record(main)
         self.ev_det.synchronize()
-        det = self._decode(self.hn_det.tolist())
-        up = self.infer_model.uniplanner
-        H, W = self.b_features.size(2) * 2, self.b_features.size(3) * 2
-        locs, oris = up.others_from_detections(det[1], H, W)
+        det, locs, oris = self.infer_model.det_decode_fast(self.hn_det)     # numpy masks: ~3x faster than the row loops
         N = min(len(locs), 15)
+        up = self.infer_model.uniplanner
         if N > 0:
-            self.hn_actors[:2 * N] = np.asarray(locs[:N], np.float32).reshape(-1)
-            self.hn_actors[30:30 + N] = np.asarray(oris[:N], np.float32)
+            self.hn_actors[:2 * N] = locs[:N].reshape(-1)
+            self.hn_actors[30:30 + N] = oris[:N]
             self.d_actors.copy_(self.h_actors, non_blocking=True)
             ob = self._replay(("others", N), self._g_others, self.s_cap, N)
             other_cast, other_cmds = ob["other_cast_locs"], ob["other_cast_cmds"]

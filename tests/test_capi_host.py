@@ -198,3 +198,28 @@ def test_every_layer_shape_of_the_frame_has_a_launch_plan():
         rc = lib.lav_conv_tile_info(C.byref(d), info)
         assert rc == 0, f"{conv} on {shp}: {lib.lav_last_error().decode()}"
         assert info[3] * info[4] <= 256 * 12 and info[5] <= 160 * 1024
+
+
+def test_vectorised_detection_decode_equals_the_loops():
+    """InferModel.det_decode_fast (numpy masks; used on the frame's critical chain) == det_decode +
+    UniPlanner.others_from_detections (the row loops that restate model_inference.py:95-144)."""
+    import types
+    from lav_amd.model_inference import InferModel
+    from lav_amd.uniplanner import UniPlanner
+    up = types.SimpleNamespace(pixels_per_meter=4, offsets=lambda: (0.0, 0.75))
+    up.others_from_detections = lambda det, H, W: UniPlanner.others_from_detections(up, det, H, W)
+    im = types.SimpleNamespace(pixels_per_meter=4, uniplanner=up, _bev_hw=(320, 320))
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        rows = np.zeros((2, 15, 7), np.float32)
+        rows[..., 0] = rng.uniform(-0.2, 1.0, (2, 15))
+        rows[..., 1] = rng.integers(100, 220, (2, 15)); rows[..., 2] = rng.integers(150, 319, (2, 15))
+        rows[..., 3:5] = rng.uniform(0, 3, (2, 15, 2)); rows[..., 5:7] = rng.normal(size=(2, 15, 2))
+        rows[1, 0, 1:3] = (160, 280); rows[1, 1, 1:3] = (161, 282); rows[1, 2, 1:3] = (163, 281)    # ego pixel neighbourhood
+        rows[0, 3, 0] = 0.2                                                                          # score threshold is strict
+        dets = InferModel.det_decode(im, rows.tolist())
+        locs, oris = up.others_from_detections(dets[1], 320, 320)
+        fd, fl, fo = InferModel.det_decode_fast(im, rows)
+        assert fd == dets
+        np.testing.assert_allclose(fl, np.asarray(locs, np.float64).reshape(-1, 2), rtol=0, atol=0)
+        np.testing.assert_allclose(fo, np.asarray(oris, np.float64), rtol=0, atol=1e-15)
