@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 5
+#define LAV_ABI_VERSION 6
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -167,6 +167,8 @@ typedef struct lav_conv {
     int sigmoid;       /* 0: none; k > 0: sigmoid on output channels >= k-1 of this convolution (1 = all of them) */
     int target_cus;    /* 0 = plan for the whole chip (256 CUs); n: plan tiles / split-K to fill n CUs - for layers of a
                           network that runs on a side stream next to another network's kernels */
+    float pad_value;   /* what out-of-image taps read (0 = zero padding).  A network whose input normalisation x' = s*x + t
+                          has been folded into its first convolution pads the RAW image with -t/s instead */
 } lav_conv;
 
 /* output spatial size of the convolution */
@@ -269,6 +271,13 @@ size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b);
 int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,
                     const float *bias_a, const float *wb_packed, const float *bias_b, const float *scale, const float *shift,
                     const float *residual, int relu_post, float *y, void *stream);
+
+/* 2x2/stride-2 max pooling + per-channel affine (+ ReLU) written into a channel window of y: the pooled branch of
+ * ERFNet's DownsamplerBlock, cat([conv(x), pool(x)]) -> BatchNorm -> ReLU (lav/models/erfnet.py:9-23), whose
+ * convolution branch is lav_conv2d writing the other window of the same tensor.
+ * x [batch][channels][h][w] (h, w even); y [batch][out_c_total][h/2][w/2]. */
+int lav_pool_affine(const float *x, int batch, int channels, int h, int w, const float *scale, const float *shift, int relu,
+                    float *y, int out_c_total, int out_c_offset, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblav_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_CAM = 4
 
 
@@ -33,7 +33,7 @@ class Camera(C.Structure):
 class Conv(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "batch", "in_c_total", "in_c_offset", "cin", "h", "w", "cout", "kh", "kw", "stride", "pad_h", "pad_w",
-        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid", "target_cus")]
+        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid", "target_cus")] + [("pad_value", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/lav_amd.h
@@ -67,6 +67,7 @@ SIGNATURES = {
     "lav_conv1d_pair_pack_weights": (_I, [_I, _P, _P]),
     "lav_conv1d_pair_lds_bytes": (_Z, [_I, _I, _I]),
     "lav_conv1d_pair": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "lav_pool_affine": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "lav_merge_ticks": (_I, [_P, _P, _I, _I, _P, _P]),
     "lav_stack_sweeps": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "lav_extract_peaks_workspace_bytes": (_Z, [_I, _I, _I]),

@@ -665,13 +665,21 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     } else {
         a.partial = nullptr;
     }
-    {   // 256 zero bytes in HBM that padding / out-of-image lanes of the LDS-DMA read from (created once per process)
-        static float *zero_page = nullptr;
-        if (!zero_page) {
-            LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
-            LAV_HIP(hipMemset(zero_page, 0, 256));
+    {   // 256 bytes in HBM holding the padding value (zero, or a folded normalisation's pre-image of zero) that
+        // out-of-image lanes of the LDS-DMA read from; one page per distinct value, created once per process
+        static std::vector<std::pair<float, float *>> pages;
+        float *page = nullptr;
+        for (auto &pv : pages)
+            if (pv.first == c->pad_value) page = pv.second;
+        if (!page) {
+            LAV_REQUIRE(pages.size() < 16, "lav_conv2d: too many distinct pad values");
+            float h_page[64];
+            for (float &v : h_page) v = c->pad_value;
+            LAV_HIP(hipMalloc(reinterpret_cast<void **>(&page), sizeof(h_page)));
+            LAV_HIP(hipMemcpy(page, h_page, sizeof(h_page), hipMemcpyHostToDevice));
+            pages.emplace_back(c->pad_value, page);
         }
-        a.zero_page = zero_page;
+        a.zero_page = page;
         a.trace = nullptr;
     }
     for (int i = 0; i < MAX_CLASSES; ++i) {

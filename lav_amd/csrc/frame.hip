@@ -240,6 +240,39 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ pooled branch
+namespace {
+__global__ __launch_bounds__(256) void k_pool_affine(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ scale,
+                                                     const float *__restrict__ shift, int relu, float *__restrict__ y, int out_c_total,
+                                                     int out_c_offset, long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;   // one output element (n, c, oy, ox) of the pooled tensor
+    if (e >= total) return;
+    const int OW = W >> 1, OH = H >> 1;
+    const int ox = (int)(e % OW), oy = (int)((e / OW) % OH), c = (int)((e / ((long)OW * OH)) % C);
+    const long n = e / ((long)OW * OH * C);
+    const float2 *p = reinterpret_cast<const float2 *>(x + ((n * C + c) * H + 2 * oy) * (long)W + 2 * ox);
+    const float2 r0 = p[0], r1 = p[W >> 1];
+    float v = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y));
+    v = fmaf(v, scale[c], shift[c]);
+    if (relu) v = v > 0.f ? v : 0.f;
+    y[((n * out_c_total + out_c_offset + c) * OH + oy) * (long)OW + ox] = v;
+}
+}  // namespace
+
+extern "C" int lav_pool_affine(const float *x, int batch, int channels, int h, int w, const float *scale, const float *shift, int relu,
+                               float *y, int out_c_total, int out_c_offset, void *stream) {
+    LAV_REQUIRE(batch >= 1 && channels >= 1 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "lav_pool_affine: even h, w expected");
+    LAV_REQUIRE(x && scale && shift && y && out_c_offset >= 0 && out_c_offset + channels <= out_c_total, "lav_pool_affine: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long total = (long)batch * channels * (h / 2) * (w / 2);
+    const int tok = timer_begin("pool_affine", st);
+    hipLaunchKernelGGL(k_pool_affine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, channels, h, w, scale, shift, relu, y,
+                       out_c_total, out_c_offset, total);
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
 extern "C" int lav_merge_ticks(const float *tick, float *prev, int rows, int dim, float *cur, void *stream) {
     LAV_REQUIRE(rows >= 0 && dim == 4, "lav_merge_ticks: rows >= 0 and dim == 4 (x, y, z, intensity) expected");
     if (rows == 0) return LAV_OK;

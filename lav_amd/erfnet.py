@@ -34,17 +34,34 @@ class DownsamplerBlock(nn.Module):
     def forward(self, x):
         return F.relu(self.bn(torch.cat([self.conv(x), self.pool(x)], 1)))
 
-    def engine(self, device):
+    def engine(self, device, input_affine=None):
+        """Two launches: the convolution branch (bias, BatchNorm slice, ReLU fused) and lav_pool_affine for the pooled
+        branch, each writing its channel window of the output.  input_affine=(s, t): the block sees RAW input x while the
+        reference feeds x' = s*x + t (s > 0): the affine is folded into the convolution (W*s, b + t*sum(W), out-of-image
+        taps read -t/s, the pre-image of the reference's zero padding) and into the pooled branch's BatchNorm
+        (max commutes with an increasing map)."""
+        from . import ops
         nconv = self.conv.out_channels
         cout = self.bn.num_features
-        conv = ConvLayer.from_module(self.conv, self.bn, slice(0, nconv), relu_post=True, out_c_total=cout, device=device)
+        w, b, pad = self.conv.weight.detach(), self.conv.bias.detach(), 0.0
+        s_in, t_in = (1.0, 0.0) if input_affine is None else input_affine
+        if input_affine is not None:
+            if not s_in > 0:
+                raise RuntimeError("input_affine needs a positive scale")
+            b = (b.double() + t_in * w.double().sum(dim=(1, 2, 3))).float()
+            w = (w.double() * s_in).float()
+            pad = -t_in / s_in
+        sl = slice(0, nconv)
+        bn = tuple(t[sl] for t in (self.bn.running_mean, self.bn.running_var, self.bn.weight, self.bn.bias))
+        conv = ConvLayer(w, stride=2, padding=(1, 1), bias=b, bn=bn, bn_eps=self.bn.eps, relu_post=True, out_c_total=cout,
+                         pad_value=pad, device=device)
         ps, pt = _affine(self.bn, slice(nconv, cout))
-        ps, pt = ps.to(device), pt.to(device)
+        ps, pt = ps.reshape(-1).double(), pt.reshape(-1).double()
+        ps, pt = (ps * s_in).float().to(device), (pt + ps * t_in).float().to(device)
 
         def run(x):
             out = conv(x)                                                    # channels [0, nconv): conv+bias -> BN -> ReLU
-            out[:, nconv:] = torch.relu(F.max_pool2d(x, 2, 2) * ps + pt)     # channels [nconv, cout): pool -> BN -> ReLU
-            return out
+            return ops.pool_affine(x, ps, pt, out, nconv, relu=True)         # channels [nconv, cout): pool -> BN -> ReLU
         return run
 
 
@@ -147,18 +164,22 @@ class ERFNet(nn.Module):
         self._drop()
         return super()._load_from_state_dict(*a, **k)
 
-    def _engine(self, device):
-        if self._eng is None or self._eng[0] != device:
-            stages = [self.encoder.initial_block.engine(device)]
+    def _engine(self, device, input_affine=None):
+        if self._eng is None or self._eng[0] != (device, input_affine):
+            stages = [self.encoder.initial_block.engine(device, input_affine)]
             stages += [m.engine(device) for m in self.encoder.layers]
             stages += [m.engine(device) for m in self.decoder.layers]
             stages.append(ConvLayer.from_module(self.decoder.output_conv, device=device))
-            object.__setattr__(self, "_eng", (device, stages))
+            object.__setattr__(self, "_eng", ((device, input_affine), stages))
         return self._eng[1]
 
-    def forward(self, x):
+    def forward(self, x, input_affine=None):
+        """input_affine=(s, t): x is the raw input and the network behaves as on s*x + t (folded into the first block in
+        the HIP path, applied explicitly in the torch path)."""
         if self.training or not x.is_cuda:
+            if input_affine is not None:
+                x = x * input_affine[0] + input_affine[1]
             return self.decoder(self.encoder(x))
-        for stage in self._engine(x.device):
+        for stage in self._engine(x.device, input_affine):
             x = stage(x)
         return x

@@ -221,7 +221,7 @@ class ConvLayer:
 
     def __init__(self, weight: torch.Tensor, *, stride=1, padding=(0, 0), dilation=(1, 1), transposed=False,
                  output_padding=0, bias: Optional[torch.Tensor] = None, bn=None, bn_eps: float = 1e-5,
-                 relu_pre=False, relu_post=False, sigmoid=False, in_c_total=None, in_c_offset=0, out_c_total=None, target_cus=0,
+                 relu_pre=False, relu_post=False, sigmoid=False, in_c_total=None, in_c_offset=0, out_c_total=None, target_cus=0, pad_value=0.0,
                  out_c_offset=0, device=None):
         lib = _lib.load()
         w = weight.detach().to("cpu", torch.float32).contiguous()
@@ -239,7 +239,7 @@ class ConvLayer:
         self.desc = Conv(1, self.in_c_total, in_c_offset, cin, 0, 0, cout, kh, kw, int(stride), int(padding[0]),
                          int(padding[1]), int(dilation[0]), int(dilation[1]), int(bool(transposed)),
                          int(output_padding), self.out_c_total, out_c_offset, int(relu_pre), int(relu_post),
-                         int(sigmoid), int(target_cus))
+                         int(sigmoid), int(target_cus), float(pad_value))
         probe = Conv.from_buffer_copy(self.desc)
         probe.h, probe.w = 64, 64
         nfl = lib.lav_conv_packed_weight_floats(C.byref(probe))
@@ -358,6 +358,17 @@ class Conv1dPair:
                                           _ptr(self.bb), _ptr(self.scale), _ptr(self.shift), _ptr(residual), int(self.relu_post),
                                           _ptr(y), _stream()), "lav_conv1d_pair")
         return y
+
+
+def pool_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out: torch.Tensor, out_c_offset: int, relu: bool = True):
+    """2x2 max pooling + per-channel affine (+ ReLU) of x (B,C,H,W) into channels [out_c_offset, +C) of out (B,Ct,H/2,W/2)."""
+    x = _f32c(x, "x")
+    B, Cc, H, W = x.shape
+    if out.shape[0] != B or out.shape[2:] != (H // 2, W // 2) or not out.is_contiguous():
+        raise RuntimeError("pool_affine: output buffer does not match")
+    check(_lib.load().lav_pool_affine(_ptr(x), B, Cc, H, W, _ptr(_f32c(scale, "scale")), _ptr(_f32c(shift, "shift")), int(relu),
+                                      _ptr(out), out.shape[1], int(out_c_offset), _stream()), "lav_pool_affine")
+    return out
 
 
 def crop_rotate(features: torch.Tensor, locs: torch.Tensor, oris: torch.Tensor, pixels_per_meter: float, crop: int,

@@ -31,6 +31,8 @@ class RGBSegmentationModel(nn.Module):
         self.erfnet = ERFNet(len(seg_channels) + 1)
 
     def forward(self, rgb):
+        if not self.training and rgb.is_cuda:     # (rgb/255 - .5)*2 folded into the first block: three launches less
+            return self.erfnet(rgb, input_affine=(2.0 / 255.0, -1.0))
         return self.erfnet((rgb / 255. - .5) * 2)
 
 

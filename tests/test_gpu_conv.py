@@ -180,3 +180,23 @@ def test_conv1d_pair_rejects_unsupported_rows():
     assert not pair.supported(torch.zeros((1, 64, 8, 48))) and not pair.supported(torch.zeros((1, 64, 8, 128)))
     with pytest.raises(RuntimeError, match="row width"):
         pair(torch.zeros((1, 64, 8, 48), device="cuda"))
+
+
+def test_pool_affine_and_folded_input_normalisation():
+    """lav_pool_affine + a convolution with pad_value: ERFNet's DownsamplerBlock on RAW input with (x/255 - .5)*2 folded in
+    == the torch block on the normalised input (lav/models/erfnet.py:9-23, team_code_v2/models/rgb.py:44-46)."""
+    from lav_amd.erfnet import DownsamplerBlock
+    g = torch.Generator().manual_seed(7)
+    blk = DownsamplerBlock(3, 16).eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        blk.bn.running_mean.copy_(torch.randn(16, generator=g) * 0.1); blk.bn.running_var.copy_(torch.rand(16, generator=g) + 0.5)
+        raw = torch.randint(0, 256, (2, 3, 40, 36), generator=g).float()
+        ref = blk((raw / 255. - .5) * 2)
+    run = blk.engine(torch.device("cuda"), input_affine=(2.0 / 255.0, -1.0))
+    out = run(raw.cuda()).cpu()
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+    plain = blk.engine(torch.device("cuda"))(((raw / 255. - .5) * 2).cuda()).cpu()      # no folding: same block, same answer
+    np.testing.assert_allclose(plain.numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
