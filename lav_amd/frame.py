@@ -322,5 +322,25 @@ class GraphedFramePipeline(FramePipeline):
                     other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=o_heads["pred_bev"],
                     det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])
 
+    @torch.no_grad()
+    def precapture(self, cmds=range(6), max_others=4):
+        """Capture every graph a drive will need up front - the frame graphs, one ego graph per command value, one others
+        graph per vehicle count up to `max_others` - so that no 20 Hz tick pays a capture (hundreds of ms) the first time a
+        command or a vehicle count occurs.  Runs two synthetic ticks and then resets the pipeline."""
+        dev, P = self.device, self.P
+        tick = torch.zeros((P, 4), dtype=torch.float32, device=dev)
+        tick[:, 0] = torch.linspace(5.0, 60.0, P, device=dev); tick[:, 2] = -1.0
+        rgb = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        args = (rgb(3, 3, 288, 256), rgb(1, 3, 288, 768), rgb(1, 3, 192, 480), np.zeros(2), 0.0, torch.zeros(2, device=dev))
+        self.step(tick, *args, 3)
+        self.step(tick, *args, 3)
+        for cmd in cmds:
+            with torch.cuda.stream(self.s_ego):
+                self._replay(("ego", int(cmd)), self._g_ego, self.s_ego, int(cmd))
+        for n in range(1, max_others + 1):
+            self._replay(("others", n), self._g_others, self.s_cap, n)
+        torch.cuda.synchronize()
+        self.reset()
+
     def _decode(self, det_rows, min_score=0.2):
         return self.infer_model.det_decode(det_rows, min_score)

@@ -38,7 +38,7 @@ DEFAULT_CONFIG = dict(
     speed_KD=1.0, speed_n=40, brake_speed=0.2, brake_ratio=1.1, clip_delta=0.25, max_throttle=0.8, max_speed=35,
     speed_ratio=[0.8, 0.8, 0.8, 0.6, 0.8, 0.8], lidar_model_dir="weights/lidar_v2_7.th",
     uniplanner_dir="weights/uniplanner_v2_7.th", bra_model_dir="weights/bra_v2_9.th", seg_model_dir="weights/seg_1.th",
-    synthetic_weights=False, hip_graphs=True, points_per_tick=32768, log_wandb=False)
+    synthetic_weights=False, hip_graphs=True, points_per_tick=32768, precapture=False, log_wandb=False)
 
 
 def get_entry_point():
@@ -101,6 +101,8 @@ class LAVAgent(AutonomousAgent):
         cls = GraphedFramePipeline if self.hip_graphs else FramePipeline
         self.pipeline = cls(self.lidar_model, self.uniplanner, self.seg_model, self.bra_model, self.camera_x,
                             self.camera_z, num_frame_stack=self.num_frame_stack, device=self.device, **extra)
+        if self.hip_graphs and self.precapture:
+            self.pipeline.precapture()
         self.infer_model = self.pipeline.infer_model
         self.coord_converters = self.infer_model.coord_converters
 

@@ -63,6 +63,16 @@ def test_graphed_agent_equals_eager_agent_and_restated_wiring(tmp_path):
     assert a.ekf is None and not hasattr(a, "lidar_model")
 
 
+def test_precapture_leaves_nothing_to_capture_during_the_drive(tmp_path):
+    a, sc = _make(tmp_path, hip_graphs=True, precapture=True)
+    have = set(a.pipeline.graphs)
+    assert {("ego", c) for c in range(6)} <= have and {("others", n) for n in range(1, 5)} <= have and {"lidar", "heads", "brake"} <= have
+    for i in range(0, 40, 4):
+        a.run_step(synth.agent_inputs(i, sc), i * 0.05)
+    new = {k for k in set(a.pipeline.graphs) - have if not (isinstance(k, tuple) and k[0] == "others")}
+    assert not new, new            # only an others graph for an unusually crowded frame may still be captured lazily
+
+
 def test_tick_larger_than_static_buffers_is_rejected(tmp_path):
     a, sc = _make(tmp_path, hip_graphs=True)
     data = synth.agent_inputs(0, sc, n_points=9000)
