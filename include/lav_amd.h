@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 6
+#define LAV_ABI_VERSION 7
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -200,6 +200,16 @@ int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const f
  * ------------------------------------------------------------------------------------------ */
 int lav_crop_rotate(const float *feat, int feat_batch, int C, int H, int W, const float *locs, const float *oris, int n,
                     float pixels_per_meter, int crop, float offset_x, float offset_y, float *out, void *stream);
+/* Training form (lav/models/uniplanner.py:84-95, bev_planner_v2.py:91-104): crop n is taken from map map_index[n]
+ * (int32, device) of feat [num_maps][C][H][W] - the reference materialises features.expand(N, ...)[mask], one 39 MB
+ * copy of the feature map per sampled vehicle, before cropping.  The backward spreads grad_out [n][C][crop][crop] over
+ * the source pixels of grad_feat [num_maps][C][H][W] (zeroed by the call; fp32 atomics, like torch's grid_sampler). */
+int lav_crop_rotate_indexed(const float *feat, int num_maps, const int *map_index, int C, int H, int W, const float *locs,
+                            const float *oris, int n, float pixels_per_meter, int crop, float offset_x, float offset_y,
+                            float *out, void *stream);
+int lav_crop_rotate_backward(const float *grad_out, int num_maps, const int *map_index, int C, int H, int W, const float *locs,
+                             const float *oris, int n, float pixels_per_meter, int crop, float offset_x, float offset_y,
+                             float *grad_feat, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 6. Per-frame glue of LAVAgent.run_step between the big kernels (one launch each).

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblav_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_CAM = 4
 
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_crop_rotate": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
+    "lav_crop_rotate_indexed": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
+    "lav_crop_rotate_backward": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
     "lav_pillar_decorate": (_I, [_P, C.POINTER(_I), _I, _I, _I, C.POINTER(Grid), _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_scatter_max": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "lav_scatter_max_backward": (_I, [_P, _P, _I, _I, _I, _P, _P]),

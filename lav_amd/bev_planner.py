@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import ops
 from .lidar import _Engine
 from .planner_common import DecoderMixin, crop_feature, crop_feature_torch, sample_others
 from .resnet import resnet18
@@ -49,8 +50,14 @@ class BEVPlanner(DecoderMixin, _Engine):
     def _cast_modules(self):
         return self.cast_grus, self.cast_mlps
 
-    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
+    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96, map_index=None):
+        """map_index (int32, per crop): take crop i from features[map_index[i]] instead of features[i] - the training
+        forwards crop several vehicles out of each sample's map without materialising one copy of the map per vehicle."""
         ox, oy = self.offsets()
+        if map_index is not None and features.is_cuda:          # HIP forward + backward (autograd.Function)
+            return ops.crop_rotate_indexed(features, map_index, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
+        if map_index is not None:
+            features = features[map_index.long()]
         if self.training:   # autograd path (affine_grid + grid_sample)
             return crop_feature_torch(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
         return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
@@ -71,8 +78,7 @@ class BEVPlanner(DecoderMixin, _Engine):
         pick, N = sample_others(self, ego_locs, locs, oris, typs)
         ppm, crop = self.pixels_per_meter, self.crop_size * 2
         if pick is not None:
-            flat_bev = bev[:, None].expand(-1, N, -1, -1, -1)[pick["typs"]]
-            other_embd = self.bev_conv_emb(self.crop_feature(flat_bev, pick["crop_locs"], pick["crop_oris"], ppm, crop))
+            other_embd = self.bev_conv_emb(self.crop_feature(bev, pick["crop_locs"], pick["crop_oris"], ppm, crop, map_index=pick["sample"]))
             other_locs = pick["other_locs"]
             other_cast_cmds = self.cast_cmd_pred(other_embd)
         else:
@@ -82,7 +88,8 @@ class BEVPlanner(DecoderMixin, _Engine):
             other_cast_cmds = torch.zeros((N, self.num_cmds), **z)
             other_embd = None
         B = bev.size(0)
-        ego_embd = self.bev_conv_emb(self.crop_feature(bev, bev.new_zeros((B, 2)), bev.new_zeros((B,)), ppm, crop))
+        ego_embd = self.bev_conv_emb(self.crop_feature(bev, bev.new_zeros((B, 2)), bev.new_zeros((B,)), ppm, crop,
+                                                       map_index=torch.arange(B, dtype=torch.int32, device=bev.device)))
         if other_embd is not None:     # one cast() over others + ego: same arithmetic, half the GRU launches
             both = self.cast(torch.cat([other_embd, ego_embd]))
             other_cast_locs, ego_cast_locs = both[:other_embd.size(0)], both[other_embd.size(0):]

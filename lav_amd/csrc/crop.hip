@@ -20,8 +20,11 @@ __device__ __forceinline__ float lin(int i, int n) {
     return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
 }
 
-__global__ __launch_bounds__(256) void k_crop_rotate(const float *__restrict__ feat, int feat_batch, int C, int H, int W,
-                                                     const float *__restrict__ locs, const float *__restrict__ oris,
+// BACKWARD=false: out[n][c][y][x] = bilinear(feat[map(n)][c]);  BACKWARD=true: feat_or_grad[map(n)][c] += weights * out[n][c][y][x]
+// (`out` is then the incoming gradient, read only).  map(n) = map_index[n] when given, n when there is one map per crop, else 0.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void k_crop_rotate(float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index, int C,
+                                                     int H, int W, const float *__restrict__ locs, const float *__restrict__ oris,
                                                      float ppm, int crop, float ox, float oy, int c_per_block,
                                                      float *__restrict__ out) {
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -50,15 +53,45 @@ __global__ __launch_bounds__(256) void k_crop_rotate(const float *__restrict__ f
     const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
     const long plane = (long)H * W;
-    const float *f = feat + (feat_batch > 1 ? (long)n * C * plane : 0);
+    const int m = map_index ? map_index[n] : (feat_batch > 1 ? n : 0);
+    float *f = feat + (long)m * C * plane;
     const int c_lo = blockIdx.y * c_per_block, c_hi = min(C, c_lo + c_per_block);
     float *o_ = out + ((long)n * C) * crop * crop + pix;
+    if constexpr (!BACKWARD) {
 #pragma unroll 8   // 32 independent gathers in flight per thread: the loop is latency bound, not bandwidth bound
-    for (int c = c_lo; c < c_hi; ++c) {
-        const float *p = f + c * plane;
-        const float v = p[cy0 * W + cx0] * w00 + p[cy0 * W + cx1] * w01 + p[cy1 * W + cx0] * w10 + p[cy1 * W + cx1] * w11;
-        o_[(long)c * crop * crop] = v;
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float *p = f + c * plane;
+            const float v = p[cy0 * W + cx0] * w00 + p[cy0 * W + cx1] * w01 + p[cy1 * W + cx0] * w10 + p[cy1 * W + cx1] * w11;
+            o_[(long)c * crop * crop] = v;
+        }
+    } else {
+        // transpose of the gather: every output-pixel gradient is spread over its four source pixels (crops overlap and
+        // share maps, hence atomics - the same choice torch's grid_sampler backward makes)
+        for (int c = c_lo; c < c_hi; ++c) {
+            float *p = f + c * plane;
+            const float g = o_[(long)c * crop * crop];
+            if (w00 != 0.f) atomicAdd(p + cy0 * W + cx0, g * w00);
+            if (w01 != 0.f) atomicAdd(p + cy0 * W + cx1, g * w01);
+            if (w10 != 0.f) atomicAdd(p + cy1 * W + cx0, g * w10);
+            if (w11 != 0.f) atomicAdd(p + cy1 * W + cx1, g * w11);
+        }
     }
+}
+}  // namespace
+
+namespace {
+int crop_launch(bool backward, float *feat, int nmaps, const int *map_index, int C, int H, int W, const float *locs, const float *oris,
+                int n, float ppm, int crop, float ox, float oy, float *out, hipStream_t st, const char *what) {
+    const int c_per_block = 32;
+    dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
+    const int tok = timer_begin(what, st);
+    if (backward)
+        hipLaunchKernelGGL(k_crop_rotate<true>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out);
+    else
+        hipLaunchKernelGGL(k_crop_rotate<false>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out);
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
 }
 }  // namespace
 
@@ -69,12 +102,29 @@ extern "C" int lav_crop_rotate(const float *feat, int feat_batch, int C, int H, 
     if (n == 0) return LAV_OK;
     LAV_REQUIRE(feat && locs && oris && out, "lav_crop_rotate: null argument");
     LAV_REQUIRE(feat_batch == 1 || feat_batch == n, "lav_crop_rotate: feat_batch must be 1 or n");
-    const int c_per_block = 32;
-    dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
-    const int tok = timer_begin("crop_rotate", static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(k_crop_rotate, grid, dim3(256), 0, static_cast<hipStream_t>(stream), feat, feat_batch, C, H, W, locs, oris,
-                       pixels_per_meter, crop, offset_x, offset_y, c_per_block, out);
-    timer_end(tok, static_cast<hipStream_t>(stream));
-    LAV_LAUNCH_CHECK();
-    return LAV_OK;
+    return crop_launch(false, const_cast<float *>(feat), feat_batch, nullptr, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x,
+                       offset_y, out, static_cast<hipStream_t>(stream), "crop_rotate");
+}
+
+extern "C" int lav_crop_rotate_indexed(const float *feat, int num_maps, const int *map_index, int C, int H, int W, const float *locs,
+                                       const float *oris, int n, float pixels_per_meter, int crop, float offset_x, float offset_y,
+                                       float *out, void *stream) {
+    LAV_REQUIRE(n >= 0 && num_maps >= 1 && C > 0 && H > 1 && W > 1 && crop > 1, "lav_crop_rotate_indexed: bad sizes");
+    if (n == 0) return LAV_OK;
+    LAV_REQUIRE(feat && map_index && locs && oris && out, "lav_crop_rotate_indexed: null argument");
+    return crop_launch(false, const_cast<float *>(feat), num_maps, map_index, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x,
+                       offset_y, out, static_cast<hipStream_t>(stream), "crop_rotate");
+}
+
+extern "C" int lav_crop_rotate_backward(const float *grad_out, int num_maps, const int *map_index, int C, int H, int W, const float *locs,
+                                        const float *oris, int n, float pixels_per_meter, int crop, float offset_x, float offset_y,
+                                        float *grad_feat, void *stream) {
+    LAV_REQUIRE(n >= 0 && num_maps >= 1 && C > 0 && H > 1 && W > 1 && crop > 1, "lav_crop_rotate_backward: bad sizes");
+    LAV_REQUIRE(grad_feat, "lav_crop_rotate_backward: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LAV_HIP(hipMemsetAsync(grad_feat, 0, (size_t)num_maps * C * H * W * sizeof(float), st));
+    if (n == 0) return LAV_OK;
+    LAV_REQUIRE(grad_out && map_index && locs && oris, "lav_crop_rotate_backward: null argument");
+    return crop_launch(true, grad_feat, num_maps, map_index, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x, offset_y,
+                       const_cast<float *>(grad_out), st, "crop_rotate_backward");
 }

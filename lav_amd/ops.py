@@ -360,6 +360,41 @@ class Conv1dPair:
         return y
 
 
+class _CropRotateIndexed(torch.autograd.Function):
+    """Rotated crops taken from per-sample feature maps by index, differentiable in the maps (training path)."""
+
+    @staticmethod
+    def forward(ctx, features, map_index, locs, oris, ppm, crop, ox, oy):
+        lib = _lib.load()
+        features = _f32c(features, "features")
+        locs, oris = _f32c(locs.detach().reshape(-1, 2), "locs"), _f32c(oris.detach().reshape(-1), "oris")
+        if map_index.dtype != torch.int32 or not map_index.is_cuda:
+            raise RuntimeError("crop_rotate_indexed: map_index must be an int32 tensor in HBM")
+        M, Cc, H, W = features.shape
+        n = locs.shape[0]
+        out = torch.empty((n, Cc, crop, crop), dtype=torch.float32, device=features.device)
+        check(lib.lav_crop_rotate_indexed(_ptr(features), M, _ptr(map_index), Cc, H, W, _ptr(locs), _ptr(oris), n, float(ppm), int(crop),
+                                          float(ox), float(oy), _ptr(out), _stream()), "lav_crop_rotate_indexed")
+        ctx.save_for_backward(map_index, locs, oris)
+        ctx.geom = (M, Cc, H, W, float(ppm), int(crop), float(ox), float(oy))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        map_index, locs, oris = ctx.saved_tensors
+        M, Cc, H, W, ppm, crop, ox, oy = ctx.geom
+        grad_out = _f32c(grad_out, "grad_out")
+        grad_feat = torch.empty((M, Cc, H, W), dtype=torch.float32, device=grad_out.device)
+        check(_lib.load().lav_crop_rotate_backward(_ptr(grad_out), M, _ptr(map_index), Cc, H, W, _ptr(locs), _ptr(oris), locs.shape[0], ppm,
+                                                   crop, ox, oy, _ptr(grad_feat), _stream()), "lav_crop_rotate_backward")
+        return grad_feat, None, None, None, None, None, None, None
+
+
+def crop_rotate_indexed(features, map_index, locs, oris, pixels_per_meter, crop, offset_x, offset_y):
+    """features (M,C,H,W); crop i = rotated crop of features[map_index[i]] at (locs[i], oris[i]) -> (n,C,crop,crop)."""
+    return _CropRotateIndexed.apply(features, map_index, locs, oris, pixels_per_meter, crop, offset_x, offset_y)
+
+
 def pool_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out: torch.Tensor, out_c_offset: int, relu: bool = True):
     """2x2 max pooling + per-channel affine (+ ReLU) of x (B,C,H,W) into channels [out_c_offset, +C) of out (B,Ct,H/2,W/2)."""
     x = _f32c(x, "x")

@@ -89,7 +89,8 @@ def sample_others(self, ego_locs, locs, oris, typs):
     locs_jitter[:, 1] = 0
     oris_jitter = (torch.rand((K,)) * 2 - 1).float().to(oris.device) * self.feature_angle_jitter
     other_locs = transform_points(flat_locs - locs_jitter[:, None], -rel_ori0 - oris_jitter)
-    return dict(typs=typs, crop_locs=rel_loc0 + locs_jitter, crop_oris=rel_ori0 + oris_jitter, other_locs=other_locs), locs.size(1)
+    sample = torch.nonzero(typs)[:, 0].int()      # which sample's maps each picked vehicle is cropped from
+    return dict(typs=typs, sample=sample, crop_locs=rel_loc0 + locs_jitter, crop_oris=rel_ori0 + oris_jitter, other_locs=other_locs), locs.size(1)
 
 
 class DecoderMixin:

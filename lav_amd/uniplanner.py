@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import ops
 from .lidar import _Engine
 from .planner_common import DecoderMixin, crop_feature, crop_feature_torch, sample_others, transform_points
 from .resnet import resnet18
@@ -54,8 +55,14 @@ class UniPlanner(DecoderMixin, _Engine):
     def _cast_modules(self):
         return self.cast_grus_ego, self.cast_mlps_ego
 
-    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96):
+    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96, map_index=None):
+        """map_index (int32, per crop): take crop i from features[map_index[i]] instead of features[i] - the training
+        forwards crop several vehicles out of each sample's map without materialising one copy of the map per vehicle."""
         ox, oy = self.offsets()
+        if map_index is not None and features.is_cuda:          # HIP forward + backward (autograd.Function)
+            return ops.crop_rotate_indexed(features, map_index, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
+        if map_index is not None:
+            features = features[map_index.long()]
         if self.training:   # autograd path (affine_grid + grid_sample)
             return crop_feature_torch(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
         return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
@@ -84,14 +91,13 @@ class UniPlanner(DecoderMixin, _Engine):
         ppm, crop = self.pixels_per_meter, self.crop_size
         pick, N = sample_others(self, ego_locs, locs, oris, typs)
         if pick is not None:
-            sel = pick["typs"]
-            flat_features = features[:, None].expand(-1, N, -1, -1, -1)[sel]
-            flat_bev = bev[:, None].expand(-1, N, -1, -1, -1)[sel]
-            other_embd = self.lidar_conv_emb(self.crop_feature(flat_features, pick["crop_locs"], pick["crop_oris"], ppm / 2, crop))
+            other_embd = self.lidar_conv_emb(self.crop_feature(features, pick["crop_locs"], pick["crop_oris"], ppm / 2, crop,
+                                                               map_index=pick["sample"]))
             other_locs = pick["other_locs"]
             other_cast_cmds = self.cast_cmd_pred(other_embd)
             with torch.no_grad():
-                t_embd = teacher.bev_conv_emb(teacher.crop_feature(flat_bev.contiguous(), pick["crop_locs"], pick["crop_oris"], ppm, crop * 2))
+                t_embd = teacher.bev_conv_emb(teacher.crop_feature(bev, pick["crop_locs"], pick["crop_oris"], ppm, crop * 2,
+                                                                   map_index=pick["sample"]))
                 other_cast_locs_expert, other_cast_cmds_expert = teacher.cast(t_embd), teacher.cast_cmd_pred(t_embd)
         else:
             z = dict(dtype=features.dtype, device=features.device)
@@ -106,9 +112,10 @@ class UniPlanner(DecoderMixin, _Engine):
         oris_jitter = (torch.rand((B,)) * 2 - 1).float().to(oris.device) * self.feature_angle_jitter
         ego_locs = transform_points(ego_locs[:, 1:] - locs_jitter[:, None], -oris_jitter)
         nxps = transform_points(nxps[:, None] - locs_jitter[:, None], -oris_jitter)[:, 0]
-        ego_embd = self.lidar_conv_emb(self.crop_feature(features, locs_jitter, oris_jitter, ppm / 2, crop))
+        every = torch.arange(B, dtype=torch.int32, device=features.device)
+        ego_embd = self.lidar_conv_emb(self.crop_feature(features, locs_jitter, oris_jitter, ppm / 2, crop, map_index=every))
         with torch.no_grad():
-            t_embd = teacher.bev_conv_emb(teacher.crop_feature(bev, locs_jitter, oris_jitter, ppm, crop * 2))
+            t_embd = teacher.bev_conv_emb(teacher.crop_feature(bev, locs_jitter, oris_jitter, ppm, crop * 2, map_index=every))
             ego_cast_locs_expert = teacher.cast(t_embd)
             ego_plan_locs_expert = teacher.plan(t_embd, nxps, cast_locs=ego_cast_locs_expert, pixels_per_meter=ppm, crop_size=crop * 2)
         # the reference decodes others and ego with separate cast() calls on the same *_ego GRUs (uniplanner.py:296-300):
