@@ -130,7 +130,8 @@ def train_bench(args):
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
                               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                               config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
-                                          + (", 120000-point clouds, 320x320 maps" if what == "lidar" else ", (9,320,320) BEV"),
+                                          + (", 120000-point clouds, 320x320 maps; the log-only eval inference runs on logged steps (every 100th)"
+                                             if what == "lidar" else ", (9,320,320) BEV"),
                                           parallelism=f"dp{world}", loss=round(info["loss"], 4)),
                               roofline=None, cpu_baseline=None)))
     if world > 1:

@@ -28,7 +28,8 @@ class _Engine(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def train(self, mode: bool = True):
-        self._drop()
+        if mode != self.training:     # packed engines only go stale when the mode really changes (or weights do: _apply / load)
+            self._drop()
         return super().train(mode)
 
     def _load_from_state_dict(self, *a, **k):

@@ -52,7 +52,8 @@ class TrainConfig:
     lr: float = 3e-4
     perceive_only: bool = False
     motion_only: bool = False
-    log_inference: bool = True     # the reference runs one eval-mode inference per step for its logs (lav_final_v2.py:228-236)
+    log_inference: bool = True     # the reference runs one eval-mode inference of sample 0 per step, for its logs only
+    log_every: int = 100           # (lav_final_v2.py:228-236; logged every --num-per-log = 100 steps): here it runs on those steps
     seed: int = 2021
 
 
@@ -88,6 +89,7 @@ class LAV:
         """what: "bev" (train_bev_v2.py) or "lidar" (train_full_v2.py).  checkpoints: optional dict name -> state_dict
         ('bev', 'lidar', 'uniplanner'); missing ones are seeded random weights (the released files are LFS objects)."""
         self.cfg, self.device, self.what = cfg, torch.device(device), what
+        self.steps = 0
         ck = checkpoints or {}
         y_off = 1 + cfg.min_x / ((cfg.max_x - cfg.min_x) / 2)
         common = dict(pixels_per_meter=cfg.pixels_per_meter, crop_size=cfg.crop_size, feature_x_jitter=cfg.feature_x_jitter,
@@ -181,8 +183,11 @@ class LAV:
         loss.backward()
         self.lidar_optim.step()
         info = _scalars(loss, terms)
-        if cfg.log_inference:
+        # The inference below only feeds the visualisation log.  It needs the inference engines re-packed from the
+        # just-updated weights (~500 small copies), so it runs on the steps that are logged, not on all of them.
+        if cfg.log_inference and self.steps % max(cfg.log_every, 1) == 0:
             info.update(self.mot_inference(lidars[0], num_points[0], cmds[0], nxps[0]))
+        self.steps += 1
         return info
 
     @torch.no_grad()

@@ -52,6 +52,19 @@ class UniPlanner(DecoderMixin, _Engine):
             object.__setattr__(self, "_offsets", (float(self.offset_x), float(self.offset_y)))
         return self._offsets
 
+    def train(self, mode: bool = True):
+        """The privileged teacher rides along as a submodule but is frozen: it stays in eval mode (the reference re-applies
+        bev_planner.eval() at every forward, uniplanner.py:58) and is skipped when the mode of the rest is switched, which
+        also keeps its packed inference engines alive across the trainer's train()/eval() toggles."""
+        if mode != self.training:
+            self._drop()
+        self.training = mode
+        for name, child in self.named_children():
+            if name != "bev_planner":
+                child.train(mode)
+        self.bev_planner.eval()
+        return self
+
     def _cast_modules(self):
         return self.cast_grus_ego, self.cast_mlps_ego
 

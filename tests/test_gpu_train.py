@@ -115,7 +115,7 @@ def test_train_lidar_on_gpu_matches_reference_trainer(golden):
     """Full train_full_v2 step (LiDARModel + UniPlanner distilled from the frozen BEVPlanner, detection + segmentation +
     motion losses, Adam) vs the reference's own LAV.train_lidar run on CPU with the same seeded weights and batch."""
     ref = golden["train"]["lidar_terms"]
-    lav = LAV(TrainConfig(), DEV, what="lidar")
+    lav = LAV(TrainConfig(log_every=1), DEV, what="lidar")      # log_every=1: the log-only eval inference runs on every step, as in the reference
     batch = synthetic_lidar_batch(2, seed=12, max_points=20000, num_objs=3)
     keys = ("hm_loss", "box_loss", "ori_loss", "seg_loss", "plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
     for step in range(2):

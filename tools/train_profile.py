@@ -28,4 +28,4 @@ print(f"step {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms")
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60))
+print(prof.key_averages().table(sort_by=os.environ.get("SORT", "cuda_time_total"), row_limit=30, max_name_column_width=60))
