@@ -174,6 +174,8 @@ def main():
         loc, ori = pose(i)
         return pipe.step(dev["ticks"][i % nt], dev["all_rgbs"], dev["rgbs"], dev["tel_rgbs"], loc, ori, dev["nxp"], 3)
 
+    if not args.eager:
+        pipe.precapture(cmds=[3], max_others=8)   # no HIP-graph capture inside the timed region, whatever the detections do
     # fill the 15-frame history + warm up (untimed); profiling is armed here so its event pools are created now
     if args.eager:
         lib.lav_profile_enable(min(65000, 200 * args.steps))
