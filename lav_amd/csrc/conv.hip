@@ -36,7 +36,7 @@ constexpr int TAP_GROUP = 9;  // taps per weight stage (a 7x7 kernel is staged o
 constexpr int NPOS_MAX = 40;  // bound on staged input positions per thread (LDS capacity is the real limit)
 
 struct ConvArgs {
-    const float *x, *w, *bias, *scale, *shift, *res, *zero_page;
+    const float *x, *w, *bias, *scale, *shift, *res;
     unsigned long long *trace;  // debug (LAV_CONV_TRACE): [workgroup][8] wall-clock stamps
     float *y;
     int in_c_total, in_c_offset, cin, H, W;
@@ -46,6 +46,7 @@ struct ConvArgs {
     int Wst, ROWS, plane_pad, nclasses, taps_per_class, tap_group;
     int cps;      // 16-channel chunks staged per pipeline stage (short layers stage all of K at once)
     int ksplit;   // >1: the cin chunks are split over `ksplit` workgroups writing raw partial sums to `partial`
+    float pad_value;   // what out-of-image input positions hold (zero, or a folded normalisation's pre-image of zero)
     float *partial;
     int in_bufs;  // 2: input tile double buffered; 1: tile too large for that (wide 7x7 stems) - loaded at chunk start
     int rowblock, xblocks;  // 1: tiles are PIXW-wide segments of ONE output-grid row (wide images); 0: linearised pixels
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     CONV_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CO_T = 32 * MC, PIXW = 128 * MP;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: loops over this wave's slices run on the SALU
     const int ks = blockIdx.z % a.ksplit;
     const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
     const int cb = blockIdx.y * CO_T;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     float *s_w0 = smem + a.in_bufs * in_floats;        // [2][tap_group][CK][CO_T]   double-buffered weight slab
     // all scalar arguments the prologue needs, fetched in ONE batch of kernarg loads with a single wait (instead of a
     // dependent s_load + s_waitcnt round trip at each first use)
-    asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.zero_page), "s"(a.in_c_total), "s"(a.in_c_offset), "s"(a.cin), "s"(a.H), "s"(a.W),
+    asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.pad_value), "s"(a.in_c_total), "s"(a.in_c_offset), "s"(a.cin), "s"(a.H), "s"(a.W),
                  "s"(a.cin_pad), "s"(a.cout_pad), "s"(a.QH), "s"(a.QW), "s"(a.in_s), "s"(a.Wst), "s"(a.ROWS), "s"(a.plane_pad),
                  "s"(a.taps_per_class), "s"(a.tap_group), "s"(a.cps), "s"(a.in_bufs), "s"(a.rowblock), "s"(a.xblocks));
     const int ntaps = a.cls_ntaps[cls];
@@ -164,8 +166,30 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     // Asynchronous global -> LDS DMA (global_load_lds): data never passes through VGPRs, so the loads of stage
     // s+1 are in flight while stage s runs on the matrix pipes.  The LDS destination of one wave-instruction is
     // wave-uniform base + lane*size, which is exactly how both tiles are laid out (positions / float4s in thread
-    // order).  Padding and out-of-image positions read a zero page.
-    const long zoff = a.zero_page - xin;  // flat address space: the zero page as an element offset from xin
+    // order).
+    // Out-of-image positions (the same ones in every chunk and stage - they only depend on the tile) and the
+    // planes of a ragged channel tail are written ONCE, with the pad value; the DMA then runs under an exec mask with the
+    // channel plane as a scalar base and the pixel as a 32-bit lane offset: 4 mostly scalar instructions per load
+    // (s_mov m0 / s_add / load / 64-bit add).
+    {
+        const int nplanes = a.in_bufs * a.cps * CK;
+        const int tail = a.cin % CK;   // last chunk's live channels when the channel count is ragged (0: none)
+        int rr = rr0, xx = xx0;
+        for (int pb = 64 * wid; pb < plane; pb += 256) {
+            const int iy = iy_base + rr, ix = in_ox + xx;
+            const bool valid = pb + lane < live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            if (!valid) {
+                for (int s = 0; s < nplanes; ++s) s_in0[s * plane + pb + lane] = a.pad_value;
+            } else if (tail) {   // planes >= tail of every chunk slot may be the last chunk's dead channels
+                for (int s = 0; s < nplanes; ++s)
+                    if ((s % CK) >= tail) s_in0[s * plane + pb + lane] = 0.f;
+            }
+            rr += step_q;
+            xx += step_r;
+            if (xx >= Wst) { xx -= Wst; ++rr; }
+        }
+        if (tail) __syncthreads();   // the zeroed tail planes of a slot are DMA targets while it holds a full chunk
+    }
     auto issue_input = [&](int sc) {  // super-chunk sc: chunks chunk_lo + sc*cps ... (up to cps of them)
         float *dst0 = s_in0 + (a.in_bufs == 2 ? (sc & 1) * in_floats : 0);
         const int c_first = chunk_lo + sc * a.cps, c_last = min(c_first + a.cps, chunk_hi);
@@ -176,13 +200,24 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
             for (int pb = 64 * wid; pb < plane; pb += 256) {  // wave-uniform: this wave's 64 positions pb..pb+63
                 const int iy = iy_base + rr, ix = in_ox + xx;
                 const int g = (pb + lane < live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? iy * a.W + ix : -1;
+                if (g >= 0) {   // exec mask: lanes on padding keep the prefilled value
+                    const char *pix = reinterpret_cast<const char *>(xin + (long)ci0 * cplane) + (size_t)(unsigned)(g * 4);
+                    float *d = dst + pb;
+                    const size_t cstride = (size_t)cplane * 4;
+                    const int nc = min(CK, a.cin - ci0);   // wave-uniform
+                    if (nc == CK) {
 #pragma unroll
-                for (int c = 0; c < CK; ++c) {
-                    // integer select (v_cndmask), not a branch around the load: element offset of the position's
-                    // pixel inside channel ci0+c, or of the zero page, both relative to xin
-                    const long chan = (ci0 + c < a.cin) ? (long)(ci0 + c) * cplane : -1;  // wave-uniform
-                    const long off = (g >= 0 && chan >= 0) ? chan + g : zoff;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(xin + off), (lptr_t)(dst + c * plane + pb), 4, 0, 0);
+                        for (int c = 0; c < CK; ++c) {
+                            __builtin_amdgcn_global_load_lds((gptr_t)pix, (lptr_t)(d + c * plane), 4, 0, 0);
+                            pix += cstride;
+                            asm volatile("" : "+v"(pix));   // keep the pointer a running sum (one 64-bit add per channel)
+                        }
+                    } else {
+                        for (int c = 0; c < nc; ++c) {
+                            __builtin_amdgcn_global_load_lds((gptr_t)pix, (lptr_t)(d + c * plane), 4, 0, 0);
+                            pix += cstride;
+                        }
+                    }
                 }
                 rr += step_q;
                 xx += step_r;
@@ -665,21 +700,8 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     } else {
         a.partial = nullptr;
     }
-    {   // 256 bytes in HBM holding the padding value (zero, or a folded normalisation's pre-image of zero) that
-        // out-of-image lanes of the LDS-DMA read from; one page per distinct value, created once per process
-        static std::vector<std::pair<float, float *>> pages;
-        float *page = nullptr;
-        for (auto &pv : pages)
-            if (pv.first == c->pad_value) page = pv.second;
-        if (!page) {
-            LAV_REQUIRE(pages.size() < 16, "lav_conv2d: too many distinct pad values");
-            float h_page[64];
-            for (float &v : h_page) v = c->pad_value;
-            LAV_HIP(hipMalloc(reinterpret_cast<void **>(&page), sizeof(h_page)));
-            LAV_HIP(hipMemcpy(page, h_page, sizeof(h_page), hipMemcpyHostToDevice));
-            pages.emplace_back(c->pad_value, page);
-        }
-        a.zero_page = page;
+    {
+        a.pad_value = c->pad_value;
         a.trace = nullptr;
     }
     for (int i = 0; i < MAX_CLASSES; ++i) {

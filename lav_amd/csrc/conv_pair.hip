@@ -47,7 +47,7 @@ __device__ __forceinline__ void load_w(const float *__restrict__ wp, int tap, in
 template <int KS>  // KS = 2: 8 waves, the two halves of the channel loop on different waves, partial sums combined through LDS
 __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid8 = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int wid = wid8 & 3, kpart = wid8 >> 2;   // kpart: which half of the channel loop this wave walks (KS = 2)
     const int C = a.C, W = a.W, H = a.H, CP = a.CP;
     const int n = blockIdx.x / H, y = blockIdx.x - n * H;

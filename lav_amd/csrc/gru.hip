@@ -45,7 +45,7 @@ __global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restri
     __shared__ float gh[G];
     __shared__ float h[H];
     const int cmd = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *e = embd + (long)b * embd_dim;
     const float *wih = w_ih + (long)cmd * G * embd_dim;
     // input projection, once: wave `wid` owns 16 rows, done 8 at a time with independent accumulators so the
@@ -130,7 +130,7 @@ __device__ __forceinline__ void row_decode(const PlanArgs &a, int r, int &b, int
 
 __global__ __launch_bounds__(256) void k_plan_step(PlanArgs a, int it, int t) {
     const int H = a.H;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = H / 64;
     __shared__ float gh_s[3 * PLAN_UNITS][PLAN_RC];
     const int j0 = blockIdx.x * PLAN_UNITS;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_plan_step(PlanArgs a, int it, int t) {
 constexpr int OUT_WAVES = 8;
 __global__ __launch_bounds__(64 * OUT_WAVES) void k_plan_out(PlanArgs a, int it) {
     __shared__ float wp[64][2];  // T <= 64
-    const int r = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, H = a.H;
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), H = a.H;
     int b, ci, c;
     row_decode(a, r, b, ci, c);
     for (int t = wid; t < a.T; t += OUT_WAVES) {
@@ -269,7 +269,7 @@ constexpr long long PLAN_SPIN_LIMIT = 1ll << 22;
 
 __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status) {
     const int H = a.H, T = a.T, R = a.R;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = H / 64;
     __shared__ float gh_s[3 * PLAN_UNITS][PLAN_RC];
     __shared__ float loc_s[2][PLAN_RC][64][2];
