@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 7
+#define LAV_ABI_VERSION 8
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -176,11 +176,13 @@ int lav_conv_out_hw(const lav_conv *c, int *oh, int *ow);
 /* number of floats of the packed weight buffer */
 size_t lav_conv_packed_weight_floats(const lav_conv *c);
 /* host-side repack of a PyTorch-layout weight (Conv2d: [cout][cin][kh][kw]; ConvTranspose2d:
- * [cin][cout][kh][kw]) into the kernel's [class][tap][cin][cout] layout.  Pure host code. */
+ * [cin][cout][kh][kw]) into the kernel's layout [class][cout block of 32][tap][8-channel group][lane][channel pair] -
+ * the order in which the MFMA A operands are consumed, so both kernels fetch 16 bytes per lane.  Pure host code. */
 int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed);
 /* introspection of the launch plan (host only, no device access): info[0..8] = { MP, MC, row-blocked tiles,
- * staged tile width, staged tile rows, LDS bytes, split-K factor, taps per weight slab, chunks per stage }.  Fails exactly when
- * lav_conv2d would reject the shape. */
+ * staged tile width, staged tile rows, LDS bytes, split-K factor, taps per weight slab, chunks per stage }; small layers
+ * that take the direct kernel (whole batch in one GEMM dimension, operands straight from L2, no LDS staging) report
+ * info[0] = 0 and info[1] = waves per workgroup.  Fails exactly when lav_conv2d would reject the shape. */
 int lav_conv_tile_info(const lav_conv *c, int *info);
 /* scratch for the split-K partial sums of small-output / deep-channel layers (0 when the layer is not split) */
 size_t lav_conv_workspace_bytes(const lav_conv *c);

@@ -62,15 +62,22 @@ struct TapOps {
     float a[CK / 2][MC], b[CK / 2][MP];
 };
 
+// Weight slab of one tap in LDS (and in HBM, see lav_conv_pack_weights): [cout block of 32][8-channel group][lane][4],
+// lane = (channel parity)*32 + cout, element q = channel pair q of the group - i.e. exactly the A operands of four
+// consecutive k-steps per lane, fetched with one ds_read_b128.
 template <int MP, int MC>
 __device__ __forceinline__ void load_tap(TapOps<MP, MC> &o, const float *__restrict__ s_w_tap, const float *__restrict__ s_in,
-                                         const int (&base)[MP], int to, int plane, int l31, int half) {
-    constexpr int CO_T = 32 * MC;
+                                         const int (&base)[MP], int to, int plane, int lane, int half) {
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+        for (int g = 0; g < CK / 8; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(s_w_tap + mc * (CK * 32) + g * 256 + lane * 4);
+            o.a[4 * g + 0][mc] = v.x; o.a[4 * g + 1][mc] = v.y; o.a[4 * g + 2][mc] = v.z; o.a[4 * g + 3][mc] = v.w;
+        }
 #pragma unroll
     for (int cp = 0; cp < CK / 2; ++cp) {
         const int c = 2 * cp + half;
-#pragma unroll
-        for (int mc = 0; mc < MC; ++mc) o.a[cp][mc] = s_w_tap[c * CO_T + mc * 32 + l31];
 #pragma unroll
         for (int mp = 0; mp < MP; ++mp) o.b[cp][mp] = s_in[c * plane + base[mp] + to];
     }
@@ -230,15 +237,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         const int c_first = chunk_lo + sc * a.cps, c_last = min(c_first + a.cps, chunk_hi);
         const int t0 = grp * a.tap_group;
         const int nt = min(a.tap_group, ntaps - t0);
-        constexpr int V = CO_T / 4;
+        // one tap of one 16-channel chunk and cout block is 512 contiguous floats in HBM (2 groups x 64 lanes x 4)
+        const long blk_stride = (long)ntaps * a.cin_pad * 32;
         for (int chunk = c_first; chunk < c_last; ++chunk) {
             const int ci0 = chunk * CK;
             float *wdst = s_w0 + (stage & 1) * w_floats + (chunk - c_first) * a.tap_group * CK * CO_T;
-            for (int f0 = 64 * wid; f0 < nt * CK * V; f0 += 256) {  // wave-uniform bounds (CK*V is a multiple of 64)
-                const int f = f0 + lane;
-                const int row = f / V, c4 = f - row * V;
-                const int tap = row / CK, c = row - tap * CK;
-                const float *src = wbase + ((long)(t0 + tap) * a.cin_pad + ci0 + c) * a.cout_pad + cb + 4 * c4;
+            for (int f0 = 64 * wid; f0 < nt * MC * 128; f0 += 256) {  // float4 index; wave-uniform bounds
+                const int piece = f0 >> 7;   // (tap, cout block): 128 float4s each, a wave's 64 never straddle two
+                const int tap = piece / MC, mc = piece - tap * MC;
+                const float *src = wbase + (long)(blockIdx.y * MC + mc) * blk_stride + ((long)(t0 + tap) * a.cin_pad + ci0) * 32 +
+                                   4 * ((f0 & 127) + lane);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(wdst + 4 * f0), 16, 0, 0);
             }
         }
@@ -270,12 +278,12 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
             const float *s_w = s_w0 + (stage & 1) * w_floats + sub * a.tap_group * CK * CO_T;
             // software pipeline over taps: operands of tap t+1 are fetched from LDS while tap t runs on the MFMA pipe
             TapOps<MP, MC> o0, o1;
-            load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, l31, half);
+            load_tap<MP, MC>(o0, s_w, s_in, base, toff[t0], plane, lane, half);
             int t = 0;
             for (; t + 1 < nt; t += 2) {
-                load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, l31, half);
+                load_tap<MP, MC>(o1, s_w + (t + 1) * CK * CO_T, s_in, base, toff[t0 + t + 1], plane, lane, half);
                 mma_tap<MP, MC>(o0, acc);
-                if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, l31, half);
+                if (t + 2 < nt) load_tap<MP, MC>(o0, s_w + (t + 2) * CK * CO_T, s_in, base, toff[t0 + t + 2], plane, lane, half);
                 mma_tap<MP, MC>(o1, acc);
             }
             if (t < nt) mma_tap<MP, MC>(o0, acc);
@@ -437,7 +445,8 @@ int build_plan(const lav_conv &c, Plan &p) {
 // back to back on its matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch.
 // Wide images switch to row-blocked tiles (a tile = PIXW pixels of ONE output-grid row) when the full-width rows of
 // a linearised tile do not fit the staging map / LDS.
-int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds) {
+int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds, double *cost = nullptr) {
+    // *cost: the plan's estimate in us; made infinite-cheap (0) for deep 2x2-tile plans, which the direct kernel never beats
     a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
     const long Q = (long)p.QH * p.QW;
     struct Geo { int rowblock, xblocks, Wst, ROWS, plane_pad, tap_group, in_bufs; size_t lds; long nwg; bool ok; };
@@ -522,6 +531,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
           }
         }
     }
+    if (cost) *cost = (found && MP == 2 && MC == 2 && bg.nwg * a.ksplit >= 512) ? 0.0 : best;   // 384->256 head conv: tiled 486 us (93 TF/s), direct 565
     LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
     a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
     a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group; a.in_bufs = bg.in_bufs;
@@ -551,6 +561,180 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
     }
     return LAV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ direct path
+// Small layers (the 24x24 ... 3x3 maps of the ResNet-18 embedders, a few hundred output pixels per image): the tiled
+// kernel above costs ~17-30 us there whatever the work, because every workgroup stages a 128-pixel tile through LDS
+// behind barriers, each IMAGE gets its own (mostly empty) tiles, and split-K needs a second launch.  Here the GEMM's
+// M dimension is the pixels of the whole batch (n, oy, ox linearised), a workgroup owns 32 pixels x 32 couts, its
+// waves split the input channels between them and feed the MFMAs straight from global memory / L2 (one dword per lane
+// and operand per k-step: the packed weights [tap][cin][cout] are already cout-contiguous, the activation gather is
+// pixel-contiguous), and the waves' partial tiles are summed through LDS in a fixed order.  No staging, one barrier.
+struct DirectArgs {
+    const float *x, *w, *bias, *scale, *shift, *res;
+    float *y, *partial;
+    int in_c_total, in_c_offset, H, W;
+    int cout, out_c_total, out_c_offset, OH, OW;
+    int cin_pad, cout_pad, kh, kw, stride, pad_h, pad_w, dil_h, dil_w;
+    int M;        // batch * OH * OW
+    int cw;       // input channels per wave (even)
+    int cks;      // input channels per split-K slice (= waves * cw)
+    int ksplit;
+    int relu_pre, relu_post, sigmoid;
+    float pad_value;
+};
+
+// DEPTH = load batches in flight per wave: every weight byte is used once, so the stream runs at (bytes in flight) /
+// (HBM latency) - a wave keeps up to DEPTH * (PAIRS/4 KB of weights + PAIRS gathers) outstanding.
+template <int DEPTH>
+__global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];   // [waves][32][33]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int ks = blockIdx.z;
+    const int plane_o = a.OH * a.OW;
+    const int m = blockIdx.x * 32 + l31;
+    const bool mvalid = m < a.M;
+    const int mc = min(m, a.M - 1);
+    const int n = mc / plane_o, pix = mc - n * plane_o, oy = pix / a.OW, ox = pix - oy * a.OW;
+    const int cb = blockIdx.y * 32;
+    const int cplane = a.H * a.W;
+    const int c0 = ks * a.cks + wid * a.cw + half;   // this lane's channel of pair 0 (pair j: c0 + 2j)
+    // Addressing is kept off the vector ALU: both operands are (scalar base) + (32-bit lane offset) loads.  Activations:
+    // byte offset of (image, channel c0, pixel 0) per lane, + the tap's pixel, advanced by 8 channels per batch.
+    // Packed weights [cout block][tap][8-channel group][lane][pair]: a wave's slice of a tap is contiguous, one dwordx4
+    // per lane = the A operands of 4 k-steps; the base pointer is a scalar that walks through the slice.
+    const unsigned xlane = (unsigned)((n * a.in_c_total + a.in_c_offset + c0) * cplane) * 4u;
+    const unsigned pstride = (unsigned)cplane * 8u;                 // bytes between the channels of consecutive pairs
+    const char *xbase = reinterpret_cast<const char *>(a.x);
+    const int wslice = ks * a.cks + wid * a.cw;                     // first channel of this wave
+    const long wtap = (long)a.cin_pad * 32;
+    const float *wtap0 = a.w + (long)blockIdx.y * (a.kh * a.kw) * wtap + (long)wslice * 32;   // scalar
+    const unsigned wlane = lane * 16u;
+    const int iy0 = oy * a.stride - a.pad_h, ix0 = ox * a.stride - a.pad_w;
+    constexpr int PAIRS = 4;                                        // channel pairs (= MFMAs) per load batch
+    const int spt = a.cw / (2 * PAIRS);                             // load batches per tap
+    const int nsteps = a.kh * a.kw * spt;
+
+    // running state of the load stream: tap (ky, kx), batch j within the tap
+    int ky = 0, kx = 0, j = 0;
+    const char *wp = reinterpret_cast<const char *>(wtap0);         // scalar
+    bool ok;
+    unsigned xoff;
+    auto enter_tap = [&]() {
+        const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
+        ok = mvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        xoff = xlane + (ok ? (unsigned)(iy * a.W + ix) * 4u : 0u);
+    };
+    enter_tap();
+    struct Ops { float av[PAIRS], bv[PAIRS]; bool ok; };
+    auto load = [&](Ops &o) {
+        const float4 v = *reinterpret_cast<const float4 *>(wp + wlane);
+        o.av[0] = v.x; o.av[1] = v.y; o.av[2] = v.z; o.av[3] = v.w;
+        // every lane loads (padding lanes read pixel 0 of their channel) and the pad value is selected when the batch is
+        // consumed: loads under an exec-mask branch would hide from the compiler's vmcnt bookkeeping and force it to
+        // drain the whole queue at each wait
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) o.bv[p] = *reinterpret_cast<const float *>(xbase + (xoff + p * pstride));
+        o.ok = ok;
+        // advance (scalar control): next batch of this tap, or the first of the next tap
+        wp += 256 * 4;
+        xoff += PAIRS * pstride;
+        if (++j == spt) {
+            j = 0;
+            if (++kx == a.kw) { kx = 0; ++ky; }
+            wp += (wtap - (long)a.cw * 32) * 4;
+            enter_tap();
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mma = [&](const Ops &o) {
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[p], o.ok ? o.bv[p] : a.pad_value, acc, 0, 0, 0);
+    };
+    // nsteps is a multiple of DEPTH (host picks DEPTH that way), so every load / MFMA batch below is unconditional and
+    // the compiler can wait for exactly the oldest batch (s_waitcnt vmcnt(n)) instead of draining the queue
+    Ops ring[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) load(ring[i]);
+    for (int s = DEPTH; s < nsteps; s += DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            mma(ring[i]);
+            load(ring[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) mma(ring[i]);
+
+    float *mine = s_red + wid * (32 * 33);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[r];
+    __syncthreads();
+    // (A ticket / last-arriver reduction inside this kernel was measured slower than the second launch: 15.1 vs 13.6 us on
+    // the 512-channel 3x3 layer - the write-through stores, the atomic round trip and the acquire cost as much as a launch.)
+    for (int e = tid; e < 1024; e += blockDim.x) {
+        const int i = e >> 5, col = e & 31;
+        const int co = cb + i, mm = blockIdx.x * 32 + col;
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += s_red[(w * 32 + i) * 33 + col];
+        if (co >= a.cout || mm >= a.M) continue;
+        const int on = mm / plane_o, opix = mm - on * plane_o;
+        if (a.ksplit > 1) {   // raw partial sums in k_conv_reduce's layout [ks][n][cout][OH][OW]
+            a.partial[((long)ks * (a.M / plane_o) + on) * a.cout * plane_o + (long)co * plane_o + opix] = v;
+            continue;
+        }
+        if (a.bias) v += a.bias[co];
+        if (a.relu_pre) v = v > 0.f ? v : 0.f;
+        if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+        const long idx = ((long)on * a.out_c_total + a.out_c_offset + co) * plane_o + opix;
+        if (a.res) v += a.res[idx];
+        if (a.relu_post) v = v > 0.f ? v : 0.f;
+        if (a.sigmoid && co >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
+        a.y[idx] = v;
+    }
+}
+
+// Direct-path plan: waves per workgroup, split-K factor and a cost estimate (us) comparable with choose_tile's.
+struct DirectPlan { bool ok; int waves, ksplit, cw; double cost; long tiles; };
+
+DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
+    DirectPlan d{false, 0, 1, 0, 1e30, 0};
+    // experiments (read per call so that a probe can sweep them): LAV_CONV_DIRECT 0 never / 1 by cost / 2 whenever possible,
+    // LAV_CONV_DIRECT_WAVES and LAV_CONV_DIRECT_KS pin the workgroup size and the split
+    auto env_int = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
+    const int mode = env_int("LAV_CONV_DIRECT", 1), force_w = env_int("LAV_CONV_DIRECT_WAVES", 0), force_k = env_int("LAV_CONV_DIRECT_KS", 0);
+    if (!mode || c.transposed || c.cin % 16 != 0 || c.cin < 32) return d;
+    const long M = (long)c.batch * p.OH * p.OW;
+    const long tiles = (M + 31) / 32 * ((c.cout + 31) / 32);
+    if (tiles > 8192 || M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 31)) return d;
+    const int taps = c.kh * c.kw;
+    if (taps > 9 && mode != 2) return d;   // 7x7 stems re-read too much without an LDS tile (measured 93 vs 86 us, 475 vs 416)
+    const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
+    for (int ks = 1; ks <= 16; ks *= 2) {
+        if (c.cin % (ks * 8) != 0) break;
+        if (force_k && ks != force_k) continue;
+        const int cks = c.cin / ks;
+        for (int waves : {4, 8, 16}) {
+            if (cks % (8 * waves) != 0 || (force_w && waves != force_w)) continue;
+            const int cw = cks / waves;
+            // calibrated on MI355X (tools/direct_probe.py): ~6.5 us of launch + prologue + LDS reduction + epilogue, the
+            // MFMAs of the waves that share a SIMD at ~2/3 of the pipe's rate, ~3.5 us for the split-K reduce launch
+            const long wgs = tiles * ks;
+            const double mpw = (double)taps * (cw / 2);   // MFMAs per wave
+            const double waves_per_simd = std::max((double)waves / 4.0, (double)wgs * waves / 1024.0);
+            // every tap re-reads its operands from L2 (no LDS tile): ~10.8 TB/s over the chip bounds large layers; a wave's
+            // load batches are serialised nine at a time (+0.05 us per batch favours more, shorter waves)
+            const double l2_us = (double)wgs * taps * cks * 32 * 8.0 / 10.8e6;
+            const double t = 6.5 + std::max(1.5 * waves_per_simd * mpw * 0.0267, l2_us) + 0.05 * taps * (cw / 8) + 0.04 * waves * std::max(1.0, (double)wgs / 256.0) + (ks > 1 ? 3.5 + ks * slab_us : 0.0);   // + LDS reduction per workgroup round
+            if (t < d.cost) d = DirectPlan{true, waves, ks, cw, t, tiles};
+        }
+    }
+    if (mode == 2 && d.ok) d.cost = 0.0;
+    return d;
+}
 }  // namespace
 
 extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
@@ -561,8 +745,15 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     ConvArgs a;
     int MP, MC;
     size_t lds;
-    rc = choose_tile(*c, p, a, MP, MC, lds);
+    double cost = 0;
+    rc = choose_tile(*c, p, a, MP, MC, lds, &cost);
     if (rc) return rc;
+    const DirectPlan d = choose_direct(*c, p);
+    if (d.ok && d.cost < cost) {   // direct path: info[0] = 0, info[1] = waves per workgroup
+        info[0] = 0; info[1] = d.waves; info[2] = 0; info[3] = 0; info[4] = 0; info[5] = d.waves * 32 * 33 * 4;
+        info[6] = d.ksplit; info[7] = 1; info[8] = 1;
+        return LAV_OK;
+    }
     info[0] = MP; info[1] = MC; info[2] = a.rowblock; info[3] = a.Wst; info[4] = a.ROWS; info[5] = (int)lds;
     info[6] = a.ksplit; info[7] = a.tap_group; info[8] = a.cps;
     return LAV_OK;
@@ -656,7 +847,8 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
                     const size_t src = c->transposed
                                            ? (((size_t)ci * c->cout + co) * c->kh + t[ti].ky) * c->kw + t[ti].kx
                                            : (((size_t)co * c->cin + ci) * c->kh + t[ti].ky) * c->kw + t[ti].kx;
-                    dst[(ti * p.cin_pad + ci) * p.cout_pad + co] = h_weight[src];
+                    // [cout block][tap][8-channel group][lane = parity*32 + cout][pair]
+                    dst[(size_t)(co / 32) * t.size() * p.cin_pad * 32 + ((ti * p.cin_pad + ci) / 8) * 256 + ((ci & 1) * 32 + co % 32) * 4 + (ci % 8) / 2] = h_weight[src];
                 }
     }
     return LAV_OK;
@@ -669,7 +861,10 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     ConvArgs a;
     int MP, MC;
     size_t lds;
-    if (choose_tile(*c, p, a, MP, MC, lds)) return 0;
+    double cost = 0;
+    if (choose_tile(*c, p, a, MP, MC, lds, &cost)) return 0;
+    const DirectPlan d = choose_direct(*c, p);
+    if (d.ok && d.cost < cost) a.ksplit = d.ksplit;
     return a.ksplit > 1 ? (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float) : 0;
 }
 
@@ -691,8 +886,12 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
 
     int MP, MC;
     size_t lds;
-    rc = choose_tile(*c, p, a, MP, MC, lds);
+    double cost = 0;
+    rc = choose_tile(*c, p, a, MP, MC, lds, &cost);
     if (rc) return rc;
+    const DirectPlan dp = choose_direct(*c, p);
+    const bool direct = dp.ok && dp.cost < cost;
+    if (direct) a.ksplit = dp.ksplit;
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float);
         if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, need);
@@ -716,6 +915,39 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         for (size_t t = 0; t < p.taps[cl].size(); ++t) a.toff[cl * p.taps_per_class + t] = p.taps[cl][t].dy * a.Wst + p.taps[cl][t].dx;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (direct) {
+        DirectArgs d;
+        d.x = x; d.w = w_packed; d.bias = bias; d.scale = scale; d.shift = shift; d.res = residual; d.y = y; d.partial = a.partial;
+        d.in_c_total = c->in_c_total; d.in_c_offset = c->in_c_offset; d.H = c->h; d.W = c->w;
+        d.cout = c->cout; d.out_c_total = c->out_c_total; d.out_c_offset = c->out_c_offset; d.OH = p.OH; d.OW = p.OW;
+        d.cin_pad = p.cin_pad; d.cout_pad = p.cout_pad; d.kh = c->kh; d.kw = c->kw; d.stride = c->stride;
+        d.pad_h = c->pad_h; d.pad_w = c->pad_w; d.dil_h = c->dil_h; d.dil_w = c->dil_w;
+        d.M = c->batch * p.OH * p.OW; d.cw = dp.cw; d.cks = dp.cw * dp.waves; d.ksplit = dp.ksplit;
+        d.relu_pre = c->relu_pre; d.relu_post = c->relu_post; d.sigmoid = c->sigmoid; d.pad_value = c->pad_value;
+        const int tok = timer_begin("conv2d", st);
+        dim3 grid((d.M + 31) / 32, (c->cout + 31) / 32, dp.ksplit);
+        const dim3 block(64 * dp.waves);
+        const size_t lds_red = (size_t)dp.waves * 32 * 33 * 4;   // <= 66 KB
+        const int nsteps = c->kh * c->kw * (dp.cw / 8);
+        int depth = 9;
+        while (nsteps % depth) --depth;
+        switch (depth) {
+#define LAV_DIRECT_CASE(D) case D: { \
+            static bool attr = false; \
+            if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_direct<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 32 * 33 * 4)); attr = true; } \
+            hipLaunchKernelGGL(k_conv_direct<D>, grid, block, lds_red, st, d); } break;
+            LAV_DIRECT_CASE(1) LAV_DIRECT_CASE(2) LAV_DIRECT_CASE(3) LAV_DIRECT_CASE(4) LAV_DIRECT_CASE(5)
+            LAV_DIRECT_CASE(6) LAV_DIRECT_CASE(7) LAV_DIRECT_CASE(8) LAV_DIRECT_CASE(9)
+#undef LAV_DIRECT_CASE
+        }
+        if (dp.ksplit > 1) {
+            const long total = (long)c->batch * c->cout * p.OH * p.OW;
+            hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, c->batch);
+        }
+        timer_end(tok, st);
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
+    }
     if (MP == 2 && MC == 2) return launch<2, 2>(a, p, c->batch, lds, st);
     if (MP == 1 && MC == 2) return launch<1, 2>(a, p, c->batch, lds, st);
     return launch<1, 1>(a, p, c->batch, lds, st);

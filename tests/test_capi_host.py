@@ -43,7 +43,15 @@ def conv_desc(cin, cout, k, s, p, tr=False, op=0, h=8, w=8):
     return Conv(1, cin, 0, cin, h, w, cout, k, k, s, p, p, 1, 1, int(tr), op, cout, 0, 0, 0, 0)
 
 
-@pytest.mark.parametrize("cin,cout,k,s,p,tr,op", [(5, 7, 3, 1, 1, False, 0), (6, 3, 4, 2, 1, True, 0), (4, 5, 4, 4, 1, True, 2),
+def tap_matrix(pk, class_off, ntaps, t, cin_pad, cout_pad):
+    """[cin_pad][cout_pad] weights of tap t of one class out of the packed layout
+    [cout block of 32][tap][8-channel group][channel parity][cout in block][channel pair] (include/lav_amd.h)."""
+    blk = pk[class_off:class_off + ntaps * cin_pad * cout_pad].reshape(cout_pad // 32, ntaps, cin_pad // 8, 2, 32, 4)
+    # channel = 8*group + 2*pair + parity, cout = 32*block + column
+    return blk[:, t].transpose(1, 4, 2, 0, 3).reshape(cin_pad, cout_pad)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,tr,op", [(5, 7, 3, 1, 1, False, 0), (40, 70, 3, 2, 1, False, 0), (6, 3, 4, 2, 1, True, 0), (4, 5, 4, 4, 1, True, 2),
                                                   (3, 2, 3, 2, 1, True, 1), (2, 3, 1, 1, 0, True, 0)])
 def test_conv_weight_packing_and_class_decomposition(cin, cout, k, s, p, tr, op):
     """Emulate the kernel's gather from the packed layout on the CPU and compare with torch: checks the host-side
@@ -68,7 +76,7 @@ def test_conv_weight_packing_and_class_decomposition(cin, cout, k, s, p, tr, op)
     if not tr:
         taps = [(ky, kx) for ky in range(k) for kx in range(k)]
         for t, (ky, kx) in enumerate(taps):
-            wt = pk[t * cin_pad * cout_pad:(t + 1) * cin_pad * cout_pad].reshape(cin_pad, cout_pad)[:cin, :cout]
+            wt = tap_matrix(pk, 0, len(taps), t, cin_pad, cout_pad)[:cin, :cout]
             for oy in range(oh.value):
                 for ox in range(ow.value):
                     iy, ix = oy * s - p + ky, ox * s - p + kx
@@ -82,14 +90,14 @@ def test_conv_weight_packing_and_class_decomposition(cin, cout, k, s, p, tr, op)
                 ntx = (k - rx + s - 1) // s if rx < k else 0
                 for dy in range(nty):
                     for dx in range(ntx):
-                        wt = pk[off:off + cin_pad * cout_pad].reshape(cin_pad, cout_pad)[:cin, :cout]
-                        off += cin_pad * cout_pad
+                        wt = tap_matrix(pk, off, nty * ntx, dy * ntx + dx, cin_pad, cout_pad)[:cin, :cout]
                         for qy in range((oh.value - 1 + p) // s + 1):
                             for qx in range((ow.value - 1 + p) // s + 1):
                                 oy, ox = s * qy + ry - p, s * qx + rx - p
                                 iy, ix = qy - (nty - 1) + dy, qx - (ntx - 1) + dx
                                 if 0 <= oy < oh.value and 0 <= ox < ow.value and 0 <= iy < H and 0 <= ix < W:
                                     out[:, oy, ox] += xn[:, iy, ix] @ wt
+                off += nty * ntx * cin_pad * cout_pad
     np.testing.assert_allclose(out, ref[0].numpy(), atol=1e-4)
 
 

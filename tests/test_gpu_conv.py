@@ -200,3 +200,45 @@ def test_pool_affine_and_folded_input_normalisation():
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
     plain = blk.engine(torch.device("cuda"))(((raw / 255. - .5) * 2).cuda()).cpu()      # no folding: same block, same answer
     np.testing.assert_allclose(plain.numpy(), ref.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
+
+DIRECT_CASES = [
+    # name, batch, cin, cout, k, stride, pad, dil, H, W
+    ("layer1 block 64->64 24x24 x7", 7, 64, 64, 3, 1, 1, 1, 24, 24),
+    ("layer2 down 64->128 s2 x3", 3, 64, 128, 3, 2, 1, 1, 24, 24),
+    ("layer2 1x1 s2 x1", 1, 64, 128, 1, 2, 0, 1, 24, 24),
+    ("layer3 block 256->256 6x6 x1", 1, 256, 256, 3, 1, 1, 1, 6, 6),
+    ("layer4 block 512->512 3x3 x7", 7, 512, 512, 3, 1, 1, 1, 3, 3),
+    ("layer4 block 512->512 3x3 x1", 1, 512, 512, 3, 1, 1, 1, 3, 3),
+    ("ragged: 96->40 5x7 map dil 2 x5", 5, 96, 40, 3, 1, 2, 2, 5, 7),
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
+def test_direct_path_small_layers(case):
+    """Small maps take the direct kernel (pixels of the whole batch in one GEMM dimension, operands straight from L2):
+    full epilogue (bias, BN, residual, ReLU), channel windows on both sides and a non-zero pad value."""
+    import ctypes as C
+    from lav_amd import _lib
+    name, B, cin, cout, k, s, p, d, H, W = case
+    x = rnd((B, cin + 16, H, W), 21)
+    w = rnd((cout, cin, k, k), 22, scale=1.0 / np.sqrt(cin * k * k))
+    bias = rnd((cout,), 23)
+    bn = (rnd((cout,), 24, 0.1), rnd((cout,), 25).abs() + 0.5, rnd((cout,), 26).abs() + 0.5, rnd((cout,), 27, 0.1))
+    pad_value = 0.25
+    layer = ConvLayer(w, stride=s, padding=p, dilation=d, bias=bias, bn=bn, relu_post=True, in_c_total=cin + 16, in_c_offset=8,
+                      out_c_total=cout + 8, out_c_offset=8, pad_value=pad_value, device=DEV)
+    desc = _lib.Conv.from_buffer_copy(layer.desc)
+    desc.batch, desc.h, desc.w = B, H, W
+    info = (C.c_int * 9)()
+    assert _lib.load().lav_conv_tile_info(C.byref(desc), info) == 0
+    assert info[0] == 0, f"{name}: expected the direct plan, got tile {info[0]}x{info[1]}"
+    xin = F.pad(x[:, 8:8 + cin], (p, p, p, p), value=pad_value)
+    pre = F.batch_norm(F.conv2d(xin, w, bias, s, 0, d), bn[0], bn[1], bn[2], bn[3], False, 0., 1e-5)
+    res = rnd((B, cout + 8, *pre.shape[2:]), 28)
+    ref = F.relu(pre + res[:, 8:])
+    out = torch.full((B, cout + 8, *pre.shape[2:]), -3.0, device=DEV)
+    layer(x.to(DEV), out=out, residual=res.to(DEV))
+    out = out.cpu()
+    assert_close(out[:, 8:].numpy(), ref.numpy(), atol=3e-5, rtol=1e-5, what=name)
+    assert (out[:, :8] == -3).all(), "channels outside the output window were touched"
