@@ -192,6 +192,17 @@ int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const f
                const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
                void *stream);
 
+/* Grouped ConvTranspose2d with few output channels (memory bound, vector-ALU kernel): group g maps input channels
+ * [g*cin/groups, (g+1)*cin/groups) to cout_per_group[g] (1..8) output channels; y is [batch][sum cout][oh][ow] with the
+ * groups' channels in order.  weight: the groups' PyTorch-layout ConvTranspose2d weights [cin/groups][cout_g][k][k]
+ * concatenated (device).  bias: [sum cout] device or NULL.  sigmoid_from: output channels >= it get a sigmoid, -1 = none.
+ * (kernel, stride) = (3, 2) or (2, 2).  cout_per_group is a host array.  Replaces the four head tails
+ * ConvTranspose2d(64, out, 3, 2, 1, 1) of team_code_v2/models/lidar.py:30-33 (one launch for all heads) and ERFNet's
+ * output layer lav/models/erfnet.py:137. */
+int lav_deconv_grouped(int batch, int cin, int h, int w, int groups, const int *cout_per_group, int kernel, int stride,
+                       int pad, int out_pad, const float *x, const float *weight, const float *bias, int sigmoid_from,
+                       float *y, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * 5. Rotated crop of the BEV feature map around each actor.  Replaces crop_feature
  *    (team_code_v2/model_inference.py:204-238; same maths team_code_v2/models/uniplanner.py:310-352):

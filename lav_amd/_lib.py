@@ -59,6 +59,7 @@ SIGNATURES = {
     "lav_conv_tile_info": (_I, [C.POINTER(Conv), C.POINTER(_I)]),
     "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_deconv_grouped": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "lav_crop_rotate": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
     "lav_crop_rotate_indexed": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
     "lav_crop_rotate_backward": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),

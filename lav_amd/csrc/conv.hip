@@ -706,7 +706,7 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
     // LAV_CONV_DIRECT_WAVES and LAV_CONV_DIRECT_KS pin the workgroup size and the split
     auto env_int = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
     const int mode = env_int("LAV_CONV_DIRECT", 1), force_w = env_int("LAV_CONV_DIRECT_WAVES", 0), force_k = env_int("LAV_CONV_DIRECT_KS", 0);
-    if (!mode || c.transposed || c.cin % 16 != 0 || c.cin < 32) return d;
+    if (!mode || c.transposed || c.cin % 16 != 0) return d;
     const long M = (long)c.batch * p.OH * p.OW;
     const long tiles = (M + 31) / 32 * ((c.cout + 31) / 32);
     if (tiles > 8192 || M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 31)) return d;
@@ -717,7 +717,7 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
         if (c.cin % (ks * 8) != 0) break;
         if (force_k && ks != force_k) continue;
         const int cks = c.cin / ks;
-        for (int waves : {4, 8, 16}) {
+        for (int waves : {1, 2, 4, 8, 16}) {
             if (cks % (8 * waves) != 0 || (force_w && waves != force_w)) continue;
             const int cw = cks / waves;
             // calibrated on MI355X (tools/direct_probe.py): ~6.5 us of launch + prologue + LDS reduction + epilogue, the

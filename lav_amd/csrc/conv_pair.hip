@@ -23,6 +23,7 @@
 // Bound: launch/latency (a pair is 0.06-0.45 GFLOP); the design target is the fixed cost, not the matrix pipes.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -33,6 +34,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct PairArgs {
     const float *x, *wA, *bA, *wB, *bB, *scale, *shift, *res, *zero_page;
     float *y;
+    unsigned long long *trace;   // debug (LAV_PAIR_TRACE): [workgroup][8] wall-clock stamps
     int B, C, H, W, dA, dB, relu_post;
     int CP;  // output channels padded to a multiple of 32 (packed-weight stride)
 };
@@ -44,8 +46,16 @@ __device__ __forceinline__ void load_w(const float *__restrict__ wp, int tap, in
     a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
 }
 
-template <int KS>  // KS = 2: 8 waves, the two halves of the channel loop on different waves, partial sums combined through LDS
+// KS = 2: 8 waves, the two halves of the channel loop on different waves, partial sums combined through LDS.
+// R = weight ring: a wave keeps the fragments of R chunks (R x 3 taps x 8 registers) in flight; its chunk count is a
+// multiple of R.  With R = all of a phase's chunks (ERFNet: 4 at 128 channels, 2 at 64, 1 at 16) the phase-A weights are
+// requested once at kernel start, and each slot is refilled with the phase-B fragment of the same index the moment
+// phase A has consumed it - the MFMA loops then never wait for L2 (before: one dependent round trip per chunk, 42 % of
+// the matrix pipe's rate inside a workgroup).
+template <int KS, int R>
 __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
+#define PAIR_STAMP(i) do { if (a.trace && threadIdx.x == 0) a.trace[(long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+    PAIR_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int wid = wid8 & 3, kpart = wid8 >> 2;   // kpart: which half of the channel loop this wave walks (KS = 2)
@@ -80,54 +90,51 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
         }
     }
     // first weight fragments and the epilogue vectors travel while the DMA is in flight
-    float wa[3][8], wn[3][8];
+    float wr[R][3][8];
+    const int nch = ch_hi - ch_lo;   // multiple of R
     if (co_ok) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch_lo, nchunk, half, co_lane, CP, wa[t]);
-    }
-    float bAv[16], bBv[16], sv[16], tv[16];
+        for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
-        bAv[r] = a.bA[co];
-        bBv[r] = a.bB[co];
-        sv[r] = a.scale ? a.scale[co] : 1.f;
-        tv[r] = a.scale ? a.shift[co] : 0.f;
+            for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch_lo + i, nchunk, half, co_lane, CP, wr[i][t]);
     }
+    float bAv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bAv[r] = a.bA[min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1)];
     // zero halo of the intermediate row
     for (int i = tid; i < C * 2 * a.dB; i += 256 * KS) {
         const int c = i / (2 * a.dB), j = i - c * 2 * a.dB;
         s_mid[c * WM + (j < a.dB ? j : W + j)] = 0.f;
     }
+    PAIR_STAMP(1);
     __syncthreads();  // DMA landed (hipcc drains vmcnt before the barrier), halo written
+    PAIR_STAMP(2);
 
     // ---- phase A: vertical taps
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (co_ok) {
-        for (int ch = ch_lo; ch < ch_hi; ++ch) {
-            if (ch + 1 < ch_hi) {
+        for (int j0 = 0; j0 < nch; j0 += R) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch + 1, nchunk, half, co_lane, CP, wn[t]);
-            }
+            for (int i = 0; i < R; ++i) {
+                const int ch = ch_lo + j0 + i;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const float *b = s_in + ((ch * 16 + half) * 3 + t) * W + px;
+                for (int t = 0; t < 3; ++t) {
+                    const float *b = s_in + ((ch * 16 + half) * 3 + t) * W + px;
 #pragma unroll
-                for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][cp], b[cp * 2 * 3 * W], acc, 0, 0, 0);
-            }
-            if (ch + 1 < ch_hi) {
+                    for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i][t][cp], b[cp * 2 * 3 * W], acc, 0, 0, 0);
+                }
+                // refill the slot: the next phase-A chunk that maps to it, else the phase-B chunk of the same slot
+                const int nxt = j0 + i + R;
+                const float *wsrc = nxt < nch ? a.wA : a.wB;
+                const int nch_src = nxt < nch ? ch_lo + nxt : ch_lo + nxt - nch;
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int cp = 0; cp < 8; ++cp) wa[t][cp] = wn[t][cp];
+                for (int t = 0; t < 3; ++t) load_w(wsrc, t, nch_src, nchunk, half, co_lane, CP, wr[i][t]);
             }
         }
-        // first fragments of phase B travel while the intermediate is written
-#pragma unroll
-        for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch_lo, nchunk, half, co_lane, CP, wa[t]);
     }
+    PAIR_STAMP(3);
     if constexpr (KS == 2) {   // combine the two halves of K: upper waves park their accumulators in LDS (s_in is consumed)
         __syncthreads();
         if (kpart == 1) {
@@ -150,27 +157,29 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     }
     __syncthreads();
 
+    PAIR_STAMP(4);
     // ---- phase B: horizontal taps over the intermediate
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int ch = ch_lo; ch < ch_hi && co_ok; ++ch) {
-        if (ch + 1 < ch_hi) {
+    if (co_ok) {
+        for (int j0 = 0; j0 < nch; j0 += R) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch + 1, nchunk, half, co_lane, CP, wn[t]);
-        }
+            for (int i = 0; i < R; ++i) {
+                const int ch = ch_lo + j0 + i;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float *b = s_mid + (ch * 16 + half) * WM + px + t * a.dB;
+                for (int t = 0; t < 3; ++t) {
+                    const float *b = s_mid + (ch * 16 + half) * WM + px + t * a.dB;
 #pragma unroll
-            for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][cp], b[cp * 2 * WM], acc, 0, 0, 0);
-        }
-        if (ch + 1 < ch_hi) {
+                    for (int cp = 0; cp < 8; ++cp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i][t][cp], b[cp * 2 * WM], acc, 0, 0, 0);
+                }
+                if (j0 + i + R < nch) {   // wave-uniform
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int cp = 0; cp < 8; ++cp) wa[t][cp] = wn[t][cp];
+                    for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch + R, nchunk, half, co_lane, CP, wr[i][t]);
+                }
+            }
         }
     }
+    PAIR_STAMP(5);
     if constexpr (KS == 2) {
         if (kpart == 1) {   // s_red aliases s_in, which nobody reads in phase B
 #pragma unroll
@@ -185,15 +194,25 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     // ---- epilogue
     const long plane = (long)H * W;
     const long base = (long)n * C * plane + (long)y * W + px;
+    asm volatile("" ::: "memory");   // keep the residual loads down here: hoisted above the phases they only cost registers
+    float rv[16], bBv[16], sv[16], tv[16];   // residual and epilogue vectors: all loads in flight together, one round trip
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
+        rv[r] = a.res ? a.res[base + co * plane] : 0.f;
+        bBv[r] = a.bB[co];
+        sv[r] = a.scale ? a.scale[co] : 1.f;
+        tv[r] = a.scale ? a.shift[co] : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= C) continue;
-        float v = fmaf(acc[r] + bBv[r], sv[r], tv[r]);
-        if (a.res) v += a.res[base + co * plane];
+        float v = fmaf(acc[r] + bBv[r], sv[r], tv[r]) + rv[r];
         if (a.relu_post) v = v > 0.f ? v : 0.f;
-        a.y[base + co * plane] = v;
+        if (co < C) a.y[base + co * plane] = v;
     }
+    PAIR_STAMP(6);
+#undef PAIR_STAMP
 }
 }  // namespace
 
@@ -239,15 +258,17 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
         LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
         LAV_HIP(hipMemset(zero_page, 0, 256));
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     PairArgs a;
     a.x = x; a.wA = wa_packed; a.bA = bias_a; a.wB = wb_packed; a.bB = bias_b; a.scale = scale; a.shift = shift; a.res = residual;
     a.zero_page = zero_page; a.y = y;
+    a.trace = nullptr;
+    static const bool want_trace = getenv("LAV_PAIR_TRACE") != nullptr;
+    static unsigned long long *d_trace = nullptr;
+    static int runs = 0;
+    if (want_trace && batch * h <= 8192) {
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)8192 * 8 * sizeof(unsigned long long)));
+        a.trace = d_trace;
+    }
     a.B = batch; a.C = channels; a.H = h; a.W = w; a.dA = d_a; a.dB = d_b; a.relu_post = relu_post;
     a.CP = (channels + 31) / 32 * 32;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -255,10 +276,32 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
     // rows are few (one workgroup each, at most one per CU for ERFNet's shapes): put 8 waves on the channel loop when it
     // is long enough to halve (the partial sums need 16 KB of the staging area)
     static const bool no_split = getenv("LAV_PAIR_KSPLIT") && getenv("LAV_PAIR_KSPLIT")[0] == '0';
-    if (channels >= 64 && !no_split && (size_t)channels * 3 * w * sizeof(float) >= 16 * 1024)
-        hipLaunchKernelGGL(k_conv1d_pair<2>, dim3(batch * h), dim3(512), lds, st, a);
-    else
-        hipLaunchKernelGGL(k_conv1d_pair<1>, dim3(batch * h), dim3(256), lds, st, a);
+    const int ks = (channels >= 64 && !no_split && (size_t)channels * 3 * w * sizeof(float) >= 16 * 1024) ? 2 : 1;
+    const int nch = channels / 16 / ks;              // chunks per wave
+    const int ring = nch % 4 == 0 ? 4 : nch % 2 == 0 ? 2 : 1;
+#define LAV_PAIR_CASE(KS_, R_) if (ks == KS_ && ring == R_) { \
+        static bool attr = false; \
+        if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_conv1d_pair<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, st, a); }
+    LAV_PAIR_CASE(1, 1) LAV_PAIR_CASE(1, 2) LAV_PAIR_CASE(1, 4) LAV_PAIR_CASE(2, 1) LAV_PAIR_CASE(2, 2) LAV_PAIR_CASE(2, 4)
+#undef LAV_PAIR_CASE
+    if (a.trace && ++runs % 10 == 0) {   // debug: per-workgroup phase times of every 10th launch
+        const size_t nwg = (size_t)batch * h;
+        std::vector<unsigned long long> hst(nwg * 8);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hst.data(), d_trace, hst.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double ph[6] = {0, 0, 0, 0, 0, 0}, last_start = 0;
+            for (size_t i = 0; i < nwg; ++i) {
+                t0 = std::min(t0, hst[i * 8]); t1 = std::max(t1, hst[i * 8 + 6]);
+            }
+            for (size_t i = 0; i < nwg; ++i) {
+                for (int k = 0; k < 6; ++k) ph[k] += (double)(hst[i * 8 + k + 1] - hst[i * 8 + k]) / 100.0;
+                last_start = std::max(last_start, (double)(hst[i * 8] - t0) / 100.0);
+            }
+            fprintf(stderr, "[pair trace] C %d W %d d %d/%d ks %d ring %d, %zu wgs: span %.2f us, last start %.2f | mean us: issue %.2f | dma wait %.2f | phase A %.2f | combine+mid %.2f | phase B %.2f | combine+epilogue %.2f\n",
+                    channels, w, d_a, d_b, ks, ring, nwg, (double)(t1 - t0) / 100.0, last_start, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, ph[5] / nwg);
+        }
+    }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

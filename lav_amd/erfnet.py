@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import Conv1dPair, ConvLayer
+from .ops import Conv1dPair, ConvLayer, GroupedDeconv
 
 _USE_PAIRS = os.environ.get("LAV_ERFNET_PAIRS", "1") != "0"   # A/B switch: 0 = four lav_conv2d launches per block
 
@@ -169,7 +169,7 @@ class ERFNet(nn.Module):
             stages = [self.encoder.initial_block.engine(device, input_affine)]
             stages += [m.engine(device) for m in self.encoder.layers]
             stages += [m.engine(device) for m in self.decoder.layers]
-            stages.append(ConvLayer.from_module(self.decoder.output_conv, device=device))
+            stages.append(GroupedDeconv([self.decoder.output_conv], device=device))   # 16 -> classes, k2 s2: memory bound
             object.__setattr__(self, "_eng", ((device, input_affine), stages))
         return self._eng[1]
 

@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .ops import ConvLayer
+from .ops import ConvLayer, GroupedDeconv
 from .point_pillar import PointPillarNet
 
 _NORM = dict(eps=1e-3, momentum=0.01)
@@ -173,8 +173,8 @@ class LiDARModel(_Engine):
 
     def _head_engine(self, names, device):
         """Fused engine of a subset of the heads: ONE convolution 384 -> 64*len(names) (the 39 MB feature map is read once)
-        and ONE transposed convolution with a block-diagonal weight 64*len -> sum(outputs) (the extra multiplies by zero
-        are free at a handful of output channels); a sigmoid head must come last (lidar.py:30-33,159-161)."""
+        and ONE grouped transposed convolution 64*len -> sum(outputs) (lav_deconv_grouped: every head's tail reads its own
+        64 channels); a sigmoid head must come last (lidar.py:30-33,159-161)."""
         eng = self._eng if self._eng is not None and self._eng.get("device") == device else dict(device=device)
         if names not in eng:
             hs = [getattr(self, n) for n in names]
@@ -186,19 +186,11 @@ class LiDARModel(_Engine):
                 raise RuntimeError("fused head deconvolution expects the sigmoid head last")
             w = torch.cat([h.net[0].weight.detach() for h in hs], dim=0)
             bn = tuple(torch.cat([getattr(h.net[2], n).detach() for h in hs]) for n in ("running_mean", "running_var", "weight", "bias"))
-            per = hs[0].net[0].weight.shape[0]
             cts = [h.net[3] for h in hs]
             outs = [ct.weight.shape[1] for ct in cts]
-            wd = torch.zeros((w.shape[0], sum(outs), *cts[0].weight.shape[2:]), dtype=torch.float32)
-            o = 0
-            for i, ct in enumerate(cts):
-                wd[i * per:(i + 1) * per, o:o + outs[i]] = ct.weight.detach().cpu()
-                o += outs[i]
             eng[names] = dict(outs=outs,
                               conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=device),
-                              deconv=ConvLayer(wd, stride=2, padding=1, transposed=True, output_padding=1,
-                                               bias=torch.cat([ct.bias.detach().cpu() for ct in cts]),
-                                               sigmoid=(1 + sum(outs[:-1])) if sig[-1] else 0, device=device))
+                              deconv=GroupedDeconv(cts, sigmoid_from=sum(outs[:-1]) if sig[-1] else -1, device=device))
             object.__setattr__(self, "_eng", eng)
         return self._eng[names]
 

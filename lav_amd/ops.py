@@ -309,6 +309,48 @@ class ConvLayer:
         return out
 
 
+class GroupedDeconv:
+    """ConvTranspose2d layers with few output channels that share geometry and read disjoint channel groups of one
+    input, as ONE lav_deconv_grouped launch (memory-bound vector kernel): the tails of the detection / segmentation heads
+    (4 x 64 channels -> 1 + 2 + 2 + 4), or a single layer (groups = 1: ERFNet's output layer)."""
+
+    def __init__(self, deconvs, sigmoid_from: int = -1, device=None):
+        ct0 = deconvs[0]
+        for ct in deconvs:
+            if (ct.kernel_size, ct.stride, ct.padding, ct.output_padding, ct.in_channels) != \
+                    (ct0.kernel_size, ct0.stride, ct0.padding, ct0.output_padding, ct0.in_channels) or ct.dilation != (1, 1) or ct.groups != 1:
+                raise RuntimeError("GroupedDeconv: layers must share kernel / stride / padding / input channels")
+        k, s_ = ct0.kernel_size, ct0.stride
+        if k[0] != k[1] or s_[0] != s_[1] or (k[0], s_[0]) not in ((3, 2), (2, 2)) or ct0.padding[0] != ct0.padding[1]:
+            raise RuntimeError(f"GroupedDeconv: kernel {k} stride {s_} unsupported")
+        dev = device if device is not None else ct0.weight.device
+        self.k, self.s, self.pad, self.opad = k[0], s_[0], ct0.padding[0], ct0.output_padding[0]
+        self.cin_g, self.groups = ct0.in_channels, len(deconvs)
+        self.outs = [ct.out_channels for ct in deconvs]
+        if max(self.outs) > 8 or self.groups > 8:
+            raise RuntimeError("GroupedDeconv: at most 8 groups of at most 8 output channels")
+        self.w = torch.cat([ct.weight.detach().to(torch.float32).reshape(-1).cpu() for ct in deconvs]).to(dev)
+        self.bias = None
+        if ct0.bias is not None:
+            self.bias = torch.cat([ct.bias.detach().to(torch.float32).cpu() for ct in deconvs]).to(dev)
+        self._outs_c = (C.c_int * self.groups)(*self.outs)
+        self.sigmoid_from = int(sigmoid_from)
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None):
+        x = _f32c(x, "x")
+        B, c, h, w = x.shape
+        if c != self.cin_g * self.groups:
+            raise RuntimeError(f"GroupedDeconv input has {c} channels, expects {self.cin_g * self.groups}")
+        oh = (h - 1) * self.s - 2 * self.pad + self.k + self.opad
+        ow = (w - 1) * self.s - 2 * self.pad + self.k + self.opad
+        if out is None:
+            out = torch.empty((B, sum(self.outs), oh, ow), dtype=torch.float32, device=x.device)
+        check(_lib.load().lav_deconv_grouped(B, c, h, w, self.groups, self._outs_c, self.k, self.s, self.pad, self.opad, _ptr(x),
+                                             _ptr(self.w), _ptr(self.bias), self.sigmoid_from, _ptr(out), _stream()),
+              "lav_deconv_grouped")
+        return out
+
+
 class Conv1dPair:
     """conv(3,1) -> ReLU -> conv(1,3) (+ eval BatchNorm, + residual, ReLU) as ONE lav_conv1d_pair launch: half of ERFNet's
     non_bottleneck_1d block.  `supported(x)` tells whether the row-tile kernel takes this shape."""

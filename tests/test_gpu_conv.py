@@ -242,3 +242,21 @@ def test_direct_path_small_layers(case):
     out = out.cpu()
     assert_close(out[:, 8:].numpy(), ref.numpy(), atol=3e-5, rtol=1e-5, what=name)
     assert (out[:, :8] == -3).all(), "channels outside the output window were touched"
+
+
+@pytest.mark.parametrize("outs,cin_g,k,pad,opad,B,H,W,sig", [((1, 2, 2, 4), 64, 3, 1, 1, 1, 40, 56, True), ((5,), 16, 2, 0, 0, 3, 36, 32, False),
+                                                           ((3, 8), 32, 3, 1, 1, 2, 17, 9, False), ((2,), 48, 3, 1, 0, 1, 8, 300, True)])
+def test_grouped_deconv_matches_torch(outs, cin_g, k, pad, opad, B, H, W, sig):
+    """lav_deconv_grouped (heads' tails, ERFNet output layer) against torch's ConvTranspose2d per group."""
+    from lav_amd.ops import GroupedDeconv
+    torch.manual_seed(5)
+    cts = [torch.nn.ConvTranspose2d(cin_g, o, k, stride=2, padding=pad, output_padding=opad) for o in outs]
+    x = rnd((B, cin_g * len(outs), H, W), 31)
+    with torch.no_grad():
+        ref = torch.cat([ct(x[:, i * cin_g:(i + 1) * cin_g]) for i, ct in enumerate(cts)], dim=1)
+        sf = sum(outs[:-1]) if sig else -1
+        if sig:
+            ref[:, sf:] = torch.sigmoid(ref[:, sf:])
+    y = GroupedDeconv(cts, sigmoid_from=sf, device=DEV)(x.to(DEV)).cpu()
+    assert y.shape == ref.shape
+    assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=f"grouped deconv {outs}")
