@@ -586,18 +586,20 @@ struct DirectArgs {
 
 // DEPTH = load batches in flight per wave: every weight byte is used once, so the stream runs at (bytes in flight) /
 // (HBM latency) - a wave keeps up to DEPTH * (PAIRS/4 KB of weights + PAIRS gathers) outstanding.
-template <int DEPTH>
-__global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_red[];   // [waves][32][33]
+// MC = 32-cout blocks per workgroup: the gathered activations of a batch feed MC MFMAs each (the texture path issues
+// ~16 cycles per wave load, a CU's four matrix pipes want an operand pair every 16: one cout block is gather bound).
+template <int DEPTH, int MC>
+__global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];   // [waves][MC * 32][33]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int ks = blockIdx.z;
     const int plane_o = a.OH * a.OW;
     const int m = blockIdx.x * 32 + l31;
     const bool mvalid = m < a.M;
-    const int mc = min(m, a.M - 1);
-    const int n = mc / plane_o, pix = mc - n * plane_o, oy = pix / a.OW, ox = pix - oy * a.OW;
-    const int cb = blockIdx.y * 32;
+    const int mcl = min(m, a.M - 1);
+    const int n = mcl / plane_o, pix = mcl - n * plane_o, oy = pix / a.OW, ox = pix - oy * a.OW;
+    const int cb = blockIdx.y * 32 * MC;
     const int cplane = a.H * a.W;
     const int c0 = ks * a.cks + wid * a.cw + half;   // this lane's channel of pair 0 (pair j: c0 + 2j)
     // Addressing is kept off the vector ALU: both operands are (scalar base) + (32-bit lane offset) loads.  Activations:
@@ -609,7 +611,8 @@ __global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
     const char *xbase = reinterpret_cast<const char *>(a.x);
     const int wslice = ks * a.cks + wid * a.cw;                     // first channel of this wave
     const long wtap = (long)a.cin_pad * 32;
-    const float *wtap0 = a.w + (long)blockIdx.y * (a.kh * a.kw) * wtap + (long)wslice * 32;   // scalar
+    const long wblk = (long)(a.kh * a.kw) * wtap;                   // floats per cout block
+    const float *wtap0 = a.w + (long)blockIdx.y * MC * wblk + (long)wslice * 32;   // scalar
     const unsigned wlane = lane * 16u;
     const int iy0 = oy * a.stride - a.pad_h, ix0 = ox * a.stride - a.pad_w;
     constexpr int PAIRS = 4;                                        // channel pairs (= MFMAs) per load batch
@@ -627,10 +630,13 @@ __global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
         xoff = xlane + (ok ? (unsigned)(iy * a.W + ix) * 4u : 0u);
     };
     enter_tap();
-    struct Ops { float av[PAIRS], bv[PAIRS]; bool ok; };
+    struct Ops { float av[MC][PAIRS], bv[PAIRS]; bool ok; };
     auto load = [&](Ops &o) {
-        const float4 v = *reinterpret_cast<const float4 *>(wp + wlane);
-        o.av[0] = v.x; o.av[1] = v.y; o.av[2] = v.z; o.av[3] = v.w;
+#pragma unroll
+        for (int b = 0; b < MC; ++b) {
+            const float4 v = *reinterpret_cast<const float4 *>(wp + b * wblk * 4 + wlane);
+            o.av[b][0] = v.x; o.av[b][1] = v.y; o.av[b][2] = v.z; o.av[b][3] = v.w;
+        }
         // every lane loads (padding lanes read pixel 0 of their channel) and the pad value is selected when the batch is
         // consumed: loads under an exec-mask branch would hide from the compiler's vmcnt bookkeeping and force it to
         // drain the whole queue at each wait
@@ -647,12 +653,18 @@ __global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
             enter_tap();
         }
     };
-    f32x16 acc;
+    f32x16 acc[MC];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int b = 0; b < MC; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     auto mma = [&](const Ops &o) {
 #pragma unroll
-        for (int p = 0; p < PAIRS; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[p], o.ok ? o.bv[p] : a.pad_value, acc, 0, 0, 0);
+        for (int p = 0; p < PAIRS; ++p) {
+            const float bvp = o.ok ? o.bv[p] : a.pad_value;
+#pragma unroll
+            for (int b = 0; b < MC; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[b][p], bvp, acc[b], 0, 0, 0);
+        }
     };
     // nsteps is a multiple of DEPTH (host picks DEPTH that way), so every load / MFMA batch below is unconditional and
     // the compiler can wait for exactly the oldest batch (s_waitcnt vmcnt(n)) instead of draining the queue
@@ -669,17 +681,19 @@ __global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) mma(ring[i]);
 
-    float *mine = s_red + wid * (32 * 33);
+    float *mine = s_red + wid * (MC * 32 * 33);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[r];
+    for (int b = 0; b < MC; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(b * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[b][r];
     __syncthreads();
     // (A ticket / last-arriver reduction inside this kernel was measured slower than the second launch: 15.1 vs 13.6 us on
     // the 512-channel 3x3 layer - the write-through stores, the atomic round trip and the acquire cost as much as a launch.)
-    for (int e = tid; e < 1024; e += blockDim.x) {
+    for (int e = tid; e < MC * 1024; e += blockDim.x) {
         const int i = e >> 5, col = e & 31;
         const int co = cb + i, mm = blockIdx.x * 32 + col;
         float v = 0.f;
-        for (int w = 0; w < nw; ++w) v += s_red[(w * 32 + i) * 33 + col];
+        for (int w = 0; w < nw; ++w) v += s_red[(w * (MC * 32) + i) * 33 + col];
         if (co >= a.cout || mm >= a.M) continue;
         const int on = mm / plane_o, opix = mm - on * plane_o;
         if (a.ksplit > 1) {   // raw partial sums in k_conv_reduce's layout [ks][n][cout][OH][OW]
@@ -698,38 +712,50 @@ __global__ __launch_bounds__(1024) void k_conv_direct(DirectArgs a) {
 }
 
 // Direct-path plan: waves per workgroup, split-K factor and a cost estimate (us) comparable with choose_tile's.
-struct DirectPlan { bool ok; int waves, ksplit, cw; double cost; long tiles; };
+struct DirectPlan { bool ok; int waves, ksplit, cw; double cost; long tiles; int mc; };
 
 DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
-    DirectPlan d{false, 0, 1, 0, 1e30, 0};
+    DirectPlan d{false, 0, 1, 0, 1e30, 0, 1};
     // experiments (read per call so that a probe can sweep them): LAV_CONV_DIRECT 0 never / 1 by cost / 2 whenever possible,
     // LAV_CONV_DIRECT_WAVES and LAV_CONV_DIRECT_KS pin the workgroup size and the split
     auto env_int = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
     const int mode = env_int("LAV_CONV_DIRECT", 1), force_w = env_int("LAV_CONV_DIRECT_WAVES", 0), force_k = env_int("LAV_CONV_DIRECT_KS", 0);
     if (!mode || c.transposed || c.cin % 16 != 0) return d;
     const long M = (long)c.batch * p.OH * p.OW;
-    const long tiles = (M + 31) / 32 * ((c.cout + 31) / 32);
-    if (tiles > 8192 || M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 31)) return d;
+    if (M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 31)) return d;
     const int taps = c.kh * c.kw;
     if (taps > 9 && mode != 2) return d;   // 7x7 stems re-read too much without an LDS tile (measured 93 vs 86 us, 475 vs 416)
     const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
-    for (int ks = 1; ks <= 16; ks *= 2) {
-        if (c.cin % (ks * 8) != 0) break;
-        if (force_k && ks != force_k) continue;
-        const int cks = c.cin / ks;
-        for (int waves : {1, 2, 4, 8, 16}) {
-            if (cks % (8 * waves) != 0 || (force_w && waves != force_w)) continue;
-            const int cw = cks / waves;
-            // calibrated on MI355X (tools/direct_probe.py): ~6.5 us of launch + prologue + LDS reduction + epilogue, the
-            // MFMAs of the waves that share a SIMD at ~2/3 of the pipe's rate, ~3.5 us for the split-K reduce launch
-            const long wgs = tiles * ks;
-            const double mpw = (double)taps * (cw / 2);   // MFMAs per wave
-            const double waves_per_simd = std::max((double)waves / 4.0, (double)wgs * waves / 1024.0);
-            // every tap re-reads its operands from L2 (no LDS tile): ~10.8 TB/s over the chip bounds large layers; a wave's
-            // load batches are serialised nine at a time (+0.05 us per batch favours more, shorter waves)
-            const double l2_us = (double)wgs * taps * cks * 32 * 8.0 / 10.8e6;
-            const double t = 6.5 + std::max(1.5 * waves_per_simd * mpw * 0.0267, l2_us) + 0.05 * taps * (cw / 8) + 0.04 * waves * std::max(1.0, (double)wgs / 256.0) + (ks > 1 ? 3.5 + ks * slab_us : 0.0);   // + LDS reduction per workgroup round
-            if (t < d.cost) d = DirectPlan{true, waves, ks, cw, t, tiles};
+    const int force_mc = env_int("LAV_CONV_DIRECT_MC", 0);
+    for (int mc = 1; mc <= 2; ++mc) {
+        if ((mc == 2 && c.cout < 64) || (force_mc && mc != force_mc)) continue;
+        const long tiles = (M + 31) / 32 * ((c.cout + 32 * mc - 1) / (32 * mc));
+        if (tiles > 8192) continue;
+        // sharing a gather between two cout blocks pays once the layer is a few workgroups per CU deep (measured: 8-12 % at
+        // >= 400 tiles, a loss on the small ResNet maps)
+        if (mc == 2 && !force_mc && (M + 31) / 32 * ((c.cout + 31) / 32) < 512) continue;
+        for (int ks = 1; ks <= 16; ks *= 2) {
+            if (c.cin % (ks * 8) != 0) break;
+            if (force_k && ks != force_k) continue;
+            const int cks = c.cin / ks;
+            if (ks > 1 && cks < 32 && !force_k) break;   // keep at least 4 waves x 8 channels per slice
+            for (int waves : {1, 2, 4, 8, 16}) {
+                if (cks % (8 * waves) != 0 || (force_w && waves != force_w) || (mc == 2 && waves > 8)) continue;
+                if (waves < 4 && cks % 32 == 0 && !force_w) continue;   // 1-2 waves only for 16-channel inputs
+                const int cw = cks / waves;
+                // calibrated on MI355X (tools/direct_probe.py): ~6.5 us of launch + prologue + LDS reduction + epilogue, the
+                // MFMAs of the waves that share a SIMD at ~2/3 of the pipe's rate (gather bound; two cout blocks per
+                // gather: ~0.87), ~3.5 us for the split-K reduce launch
+                const long wgs = tiles * ks;
+                const double mpw = (double)taps * (cw / 2) * mc;   // MFMAs per wave
+                const double waves_per_simd = std::max((double)waves / 4.0, (double)wgs * waves / 1024.0);
+                // every tap re-reads its operands from L2 (no LDS tile): ~10.8 TB/s over the chip bounds large layers; a wave's
+                // load batches are serialised a ring at a time (+0.05 us per batch favours more, shorter waves)
+                const double l2_us = (double)wgs * taps * cks * 32 * 4.0 * (mc + 1) / 10.8e6;
+                const double t = 6.5 + std::max((mc == 1 ? 1.5 : 1.15) * waves_per_simd * mpw * 0.0267, l2_us) + 0.05 * taps * (cw / 8) +
+                                 0.04 * mc * waves * std::max(1.0, (double)wgs / 256.0) + (ks > 1 ? 3.5 + ks * slab_us : 0.0);   // + LDS reduction per workgroup round
+                if (t < d.cost) d = DirectPlan{true, waves, ks, cw, t, tiles, mc};
+            }
         }
     }
     if (mode == 2 && d.ok) d.cost = 0.0;
@@ -750,7 +776,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     if (rc) return rc;
     const DirectPlan d = choose_direct(*c, p);
     if (d.ok && d.cost < cost) {   // direct path: info[0] = 0, info[1] = waves per workgroup
-        info[0] = 0; info[1] = d.waves; info[2] = 0; info[3] = 0; info[4] = 0; info[5] = d.waves * 32 * 33 * 4;
+        info[0] = 0; info[1] = d.waves; info[2] = d.mc; info[3] = 0; info[4] = 0; info[5] = d.waves * d.mc * 32 * 33 * 4;
         info[6] = d.ksplit; info[7] = 1; info[8] = 1;
         return LAV_OK;
     }
@@ -925,19 +951,20 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         d.M = c->batch * p.OH * p.OW; d.cw = dp.cw; d.cks = dp.cw * dp.waves; d.ksplit = dp.ksplit;
         d.relu_pre = c->relu_pre; d.relu_post = c->relu_post; d.sigmoid = c->sigmoid; d.pad_value = c->pad_value;
         const int tok = timer_begin("conv2d", st);
-        dim3 grid((d.M + 31) / 32, (c->cout + 31) / 32, dp.ksplit);
+        dim3 grid((d.M + 31) / 32, (c->cout + 32 * dp.mc - 1) / (32 * dp.mc), dp.ksplit);
         const dim3 block(64 * dp.waves);
-        const size_t lds_red = (size_t)dp.waves * 32 * 33 * 4;   // <= 66 KB
+        const size_t lds_red = (size_t)dp.waves * dp.mc * 32 * 33 * 4;   // <= 66 KB
         const int nsteps = c->kh * c->kw * (dp.cw / 8);
-        int depth = 9;
+        int depth = dp.mc == 1 ? 9 : 6;   // ring registers: DEPTH * (4 * MC + 4)
         while (nsteps % depth) --depth;
-        switch (depth) {
-#define LAV_DIRECT_CASE(D) case D: { \
+        switch (depth * 10 + dp.mc) {
+#define LAV_DIRECT_CASE(D, MC_) case D * 10 + MC_: { \
             static bool attr = false; \
-            if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_direct<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 32 * 33 * 4)); attr = true; } \
-            hipLaunchKernelGGL(k_conv_direct<D>, grid, block, lds_red, st, d); } break;
-            LAV_DIRECT_CASE(1) LAV_DIRECT_CASE(2) LAV_DIRECT_CASE(3) LAV_DIRECT_CASE(4) LAV_DIRECT_CASE(5)
-            LAV_DIRECT_CASE(6) LAV_DIRECT_CASE(7) LAV_DIRECT_CASE(8) LAV_DIRECT_CASE(9)
+            if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_direct<D, MC_>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 32 * 33 * 4)); attr = true; } \
+            hipLaunchKernelGGL((k_conv_direct<D, MC_>), grid, block, lds_red, st, d); } break;
+            LAV_DIRECT_CASE(1, 1) LAV_DIRECT_CASE(2, 1) LAV_DIRECT_CASE(3, 1) LAV_DIRECT_CASE(4, 1) LAV_DIRECT_CASE(5, 1)
+            LAV_DIRECT_CASE(6, 1) LAV_DIRECT_CASE(7, 1) LAV_DIRECT_CASE(8, 1) LAV_DIRECT_CASE(9, 1)
+            LAV_DIRECT_CASE(1, 2) LAV_DIRECT_CASE(2, 2) LAV_DIRECT_CASE(3, 2) LAV_DIRECT_CASE(4, 2) LAV_DIRECT_CASE(5, 2) LAV_DIRECT_CASE(6, 2)
 #undef LAV_DIRECT_CASE
         }
         if (dp.ksplit > 1) {

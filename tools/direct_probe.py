@@ -67,17 +67,18 @@ def main():
         for B in batches:
             x = torch.randn((B, cin, H, W), device=dev)
             res = {}
-            for cfg in ["tiled", "auto"] + [f"w{wv}k{ks}" for wv in (4, 8, 16) for ks in (1, 2, 4, 8, 16)]:
-                os.environ.pop("LAV_CONV_DIRECT_WAVES", None); os.environ.pop("LAV_CONV_DIRECT_KS", None)
+            for cfg in ["tiled", "auto"] + [f"w{wv}k{ks}m{mc}" for mc in (1, 2) for wv in (4, 8, 16) for ks in (1, 2, 4, 8, 16)]:
+                os.environ.pop("LAV_CONV_DIRECT_WAVES", None); os.environ.pop("LAV_CONV_DIRECT_KS", None); os.environ.pop("LAV_CONV_DIRECT_MC", None)
                 if cfg == "tiled":
                     os.environ["LAV_CONV_DIRECT"] = "0"
                 elif cfg == "auto":
                     os.environ["LAV_CONV_DIRECT"] = "1"
                 else:
-                    wv, ks = cfg[1:].split("k")
-                    if cin % (8 * int(wv) * int(ks)):
+                    wv, rest = cfg[1:].split("k")
+                    ks, mc = rest.split("m")
+                    if cin % (8 * int(wv) * int(ks)) or (mc == "2" and (cout < 64 or int(wv) > 8)):
                         continue
-                    os.environ.update(LAV_CONV_DIRECT="2", LAV_CONV_DIRECT_WAVES=wv, LAV_CONV_DIRECT_KS=ks)
+                    os.environ.update(LAV_CONV_DIRECT="2", LAV_CONV_DIRECT_WAVES=wv, LAV_CONV_DIRECT_KS=ks, LAV_CONV_DIRECT_MC=mc)
                 layer = ConvLayer(w, stride=s, padding=p, relu_post=True, device=dev)
                 try:
                     res[cfg] = timed(layer, x)
@@ -86,11 +87,11 @@ def main():
             best = min((v, c) for c, v in res.items() if c not in ("tiled", "auto") and v == v)
             d = Conv.from_buffer_copy(layer.desc); d.batch, d.h, d.w = B, H, W
             info = (ctypes.c_int * 9)()
-            os.environ["LAV_CONV_DIRECT"] = "1"; os.environ.pop("LAV_CONV_DIRECT_WAVES", None); os.environ.pop("LAV_CONV_DIRECT_KS", None)
+            os.environ["LAV_CONV_DIRECT"] = "1"; os.environ.pop("LAV_CONV_DIRECT_WAVES", None); os.environ.pop("LAV_CONV_DIRECT_KS", None); os.environ.pop("LAV_CONV_DIRECT_MC", None)
             lib.lav_conv_tile_info(ctypes.byref(d), info)
-            plan = f"w{info[1]}k{info[6]}" if info[0] == 0 else f"tile{info[0]}x{info[1]}k{info[6]}"
+            plan = f"w{info[1]}k{info[6]}m{info[2]}" if info[0] == 0 else f"tile{info[0]}x{info[1]}k{info[6]}"
             print(f"{name:24s} B={B}  tiled {res['tiled']:6.1f}  auto {res['auto']:6.1f} ({plan:10s})  best direct {best[1]:6s} {best[0]:6.1f} | " +
-                  " ".join(f"{c}:{v:.1f}" for c, v in res.items() if c not in ("tiled", "auto")), flush=True)
+                  " ".join(f"{c}:{v:.1f}" for c, v in sorted(res.items(), key=lambda cv: cv[1])[:8] if c not in ("tiled", "auto")), flush=True)
 
 
 if __name__ == "__main__":
