@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     const int C = a.C, W = a.W, H = a.H, CP = a.CP;
     const int n = blockIdx.x / H, y = blockIdx.x - n * H;
     const int NPG = W >> 5;                       // 32-pixel groups per row: 1, 2 or 4
-    const int pg = wid % NPG, cg = wid / NPG;     // this wave's pixel group / 32-channel output group
+    const int npg_sh = NPG >> 1;                  // log2(NPG): W is 32, 64 or 128, so the index maths below is shifts
+    const int pg = wid & (NPG - 1), cg = wid >> npg_sh;   // this wave's pixel group / 32-channel output group
     const int px = pg * 32 + l31;
     const int co_lane = cg * 32 + l31;            // A-operand row (output channel) of this lane
     const bool co_ok = cg * 32 < CP;              // wave has output channels at all (C = 16 -> one group)
@@ -77,12 +78,12 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
 
     // ---- stage the three input rows of every channel (16 B per lane; rows outside the image read the zero page)
     {
-        const int W4 = W >> 2, F4 = C * 3 * W4;
+        const int W4 = W >> 2, F4 = C * 3 * W4, w4_sh = 3 + npg_sh;   // W4 = 8 << npg_sh
         const float *xn = a.x + (long)n * C * H * W;
         for (int f0 = 64 * wid8; f0 < F4; f0 += 256 * KS) {   // wave-uniform: this wave's 64 float4 slots f0 .. f0+63
             const int f = f0 + lane;
-            const int q = f / W4, x4 = f - q * W4;
-            const int c = q / 3, t = q - 3 * c;
+            const int q = f >> w4_sh, x4 = f & (W4 - 1);
+            const int c = (int)(((unsigned)q * 43691u) >> 17), t = q - 3 * c;   // q / 3, exact below 2^16
             const int yy = y + (t - 1) * a.dA;
             const bool ok = f < F4 && yy >= 0 && yy < H;
             const float *src = ok ? xn + ((long)c * H + yy) * W + 4 * x4 : a.zero_page;
@@ -102,9 +103,8 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) bAv[r] = a.bA[min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1)];
     // zero halo of the intermediate row
-    for (int i = tid; i < C * 2 * a.dB; i += 256 * KS) {
-        const int c = i / (2 * a.dB), j = i - c * 2 * a.dB;
-        s_mid[c * WM + (j < a.dB ? j : W + j)] = 0.f;
+    if (const int j = tid & 31; j < 2 * a.dB) {   // dB <= 16: 32 lanes per channel cover both halos
+        for (int c = tid >> 5; c < C; c += 8 * KS) s_mid[c * WM + (j < a.dB ? j : W + j)] = 0.f;
     }
     PAIR_STAMP(1);
     __syncthreads();  // DMA landed (hipcc drains vmcnt before the barrier), halo written
@@ -158,6 +158,22 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     __syncthreads();
 
     PAIR_STAMP(4);
+    // residual and epilogue vectors: all loads in flight together (one round trip, not sixteen); with a shallow weight
+    // ring there are registers to spare and they travel during phase B
+    const long plane = (long)H * W;
+    const long base = (long)n * C * plane + (long)y * W + px;
+    float rv[16], bBv[16], sv[16], tv[16];
+    auto load_epilogue = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
+            rv[r] = a.res ? a.res[base + co * plane] : 0.f;
+            bBv[r] = a.bB[co];
+            sv[r] = a.scale ? a.scale[co] : 1.f;
+            tv[r] = a.scale ? a.shift[co] : 0.f;
+        }
+    };
+    if constexpr (R <= 2) load_epilogue();
     // ---- phase B: horizontal taps over the intermediate
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -192,17 +208,9 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     }
     if (!co_ok) return;
     // ---- epilogue
-    const long plane = (long)H * W;
-    const long base = (long)n * C * plane + (long)y * W + px;
-    asm volatile("" ::: "memory");   // keep the residual loads down here: hoisted above the phases they only cost registers
-    float rv[16], bBv[16], sv[16], tv[16];   // residual and epilogue vectors: all loads in flight together, one round trip
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
-        rv[r] = a.res ? a.res[base + co * plane] : 0.f;
-        bBv[r] = a.bB[co];
-        sv[r] = a.scale ? a.scale[co] : 1.f;
-        tv[r] = a.scale ? a.shift[co] : 0.f;
+    if constexpr (R > 2) {
+        asm volatile("" ::: "memory");   // deep weight ring: keep these loads down here, hoisted above the phases they only cost registers
+        load_epilogue();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -245,7 +253,7 @@ extern "C" size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b) {
 extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,
                                const float *bias_a, const float *wb_packed, const float *bias_b, const float *scale,
                                const float *shift, const float *residual, int relu_post, float *y, void *stream) {
-    LAV_REQUIRE(batch >= 1 && h >= 1 && d_a >= 1 && d_b >= 1, "lav_conv1d_pair: bad sizes");
+    LAV_REQUIRE(batch >= 1 && h >= 1 && d_a >= 1 && d_b >= 1 && d_b <= 16, "lav_conv1d_pair: bad sizes (dilation of the 1x3 convolution at most 16)");
     LAV_REQUIRE(w == 32 || w == 64 || w == 128, "lav_conv1d_pair: row width %d not in {32, 64, 128}", w);
     LAV_REQUIRE(channels >= 16 && channels % 16 == 0 && (channels + 31) / 32 <= 128 / w,
                 "lav_conv1d_pair: %d channels do not fit a %d-pixel row tile (at most %d)", channels, w, 32 * (128 / w));
