@@ -231,3 +231,45 @@ def test_vectorised_detection_decode_equals_the_loops():
         assert fd == dets
         np.testing.assert_allclose(fl, np.asarray(locs, np.float64).reshape(-1, 2), rtol=0, atol=0)
         np.testing.assert_allclose(fo, np.asarray(oris, np.float64), rtol=0, atol=1e-15)
+
+
+def test_direct_plan_is_chosen_where_it_was_measured_faster():
+    """Host-side plan choice (no GPU): small ResNet maps and the mid-size BEV layers take the direct kernel
+    (info[0] == 0, info[1] waves, info[2] cout blocks, info[6] split-K); 7x7 stems, the deep 2x2-tiled head convolution,
+    transposed and ragged-channel layers stay on the tiled kernel; every direct plan keeps a whole number of 8-channel
+    groups per wave and a reduction scratch within the LDS."""
+    lib = _lib.load()
+    info = (C.c_int * 9)()
+
+    def plan(B, cin, cout, k, s, p, H, W, tr=False):
+        d = Conv(B, cin, 0, cin, H, W, cout, k, k, s, p, p, 1, 1, int(tr), 0, cout, 0, 0, 0, 0)
+        assert lib.lav_conv_tile_info(C.byref(d), info) == 0, lib.lav_last_error().decode()
+        return list(info)
+
+    direct = [(1, 64, 64, 3, 1, 1, 24, 24), (7, 64, 64, 3, 1, 1, 24, 24), (1, 128, 128, 3, 1, 1, 12, 12), (7, 256, 256, 3, 1, 1, 6, 6),
+              (1, 512, 512, 3, 1, 1, 3, 3), (15, 512, 512, 3, 1, 1, 3, 3), (1, 256, 512, 1, 2, 0, 6, 6), (1, 64, 64, 3, 1, 1, 160, 160),
+              (1, 128, 128, 3, 1, 1, 80, 80), (1, 64, 128, 3, 2, 1, 160, 160), (3, 16, 48, 3, 2, 1, 144, 128)]
+    for shp in direct:
+        i = plan(*shp)
+        cin = shp[1]
+        assert i[0] == 0, f"{shp}: expected the direct kernel, got tile {i[0]}x{i[1]}"
+        waves, mc, ks = i[1], i[2], i[6]
+        assert waves in (1, 2, 4, 8, 16) and mc in (1, 2) and cin % (8 * waves * ks) == 0
+        assert i[5] == waves * mc * 32 * 33 * 4 <= 160 * 1024
+        assert mc == 1 or shp[2] >= 64
+    tiled = [(1, 384, 64, 7, 2, 3, 96, 96), (7, 384, 64, 7, 2, 3, 96, 96), (1, 384, 256, 3, 1, 1, 160, 160), (1, 3, 64, 7, 2, 3, 288, 768),
+             (1, 13, 48, 3, 1, 1, 20, 33)]
+    for shp in tiled:
+        assert plan(*shp)[0] >= 1, f"{shp}: expected a tiled plan"
+    assert plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)[0] >= 1
+
+
+def test_grouped_deconv_rejects_unsupported_geometry_before_any_launch():
+    lib = _lib.load()
+    outs = (C.c_int * 2)(3, 9)
+    dummy = C.c_void_p(64)   # never dereferenced: argument checks come first
+    assert lib.lav_deconv_grouped(1, 64, 8, 8, 2, outs, 3, 2, 1, 1, dummy, dummy, None, -1, dummy, None) != 0   # 9 couts in a group
+    assert b"output channels" in lib.lav_last_error()
+    outs = (C.c_int * 2)(3, 4)
+    assert lib.lav_deconv_grouped(1, 64, 8, 8, 2, outs, 4, 2, 1, 0, dummy, dummy, None, -1, dummy, None) != 0   # 4x4 kernel
+    assert lib.lav_deconv_grouped(1, 65, 8, 8, 2, outs, 3, 2, 1, 1, dummy, dummy, None, -1, dummy, None) != 0   # 65 % 2
