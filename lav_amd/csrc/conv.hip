@@ -722,7 +722,8 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
     const int mode = env_int("LAV_CONV_DIRECT", 1), force_w = env_int("LAV_CONV_DIRECT_WAVES", 0), force_k = env_int("LAV_CONV_DIRECT_KS", 0);
     if (!mode || c.transposed || c.cin % 16 != 0) return d;
     const long M = (long)c.batch * p.OH * p.OW;
-    if (M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 31)) return d;
+    // the kernel addresses activations with 32-bit BYTE offsets from the tensor base
+    if (M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 30)) return d;
     const int taps = c.kh * c.kw;
     if (taps > 9 && mode != 2) return d;   // 7x7 stems re-read too much without an LDS tile (measured 93 vs 86 us, 475 vs 416)
     const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
