@@ -575,8 +575,13 @@ struct DirectArgs {
     float *y, *partial;
     int in_c_total, in_c_offset, H, W;
     int cout, out_c_total, out_c_offset, OH, OW;
-    int cin_pad, cout_pad, kh, kw, stride, pad_h, pad_w, dil_h, dil_w;
-    int M;        // batch * OH * OW
+    int cin_pad, cout_pad, dil_h, dil_w;
+    // output-grid geometry (Plan): a Conv2d is ONE class over its output pixels; a ConvTranspose2d of stride s is s*s parity
+    // classes over the grid (QH, QW), class c reading input (q*in_s + in_o + tap*dil) and writing output (q*out_s + out_o)
+    int QH, QW, in_s, out_s, nclasses;
+    int cls_nty[MAX_CLASSES], cls_ntx[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES];
+    int cls_out_oy[MAX_CLASSES], cls_out_ox[MAX_CLASSES], cls_woff[MAX_CLASSES];
+    int M;        // batch * QH * QW
     int cw;       // input channels per wave (even)
     int cks;      // input channels per split-K slice (= waves * cw)
     int ksplit;
@@ -593,12 +598,13 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
     extern __shared__ __attribute__((aligned(16))) float s_red[];   // [waves][MC * 32][33]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
-    const int ks = blockIdx.z;
-    const int plane_o = a.OH * a.OW;
+    const int ks = blockIdx.z % a.ksplit, cls = blockIdx.z / a.ksplit;
+    const int plane_o = a.OH * a.OW, plane_q = a.QH * a.QW;
+    const int nty = a.cls_nty[cls], ntx = a.cls_ntx[cls];
     const int m = blockIdx.x * 32 + l31;
     const bool mvalid = m < a.M;
     const int mcl = min(m, a.M - 1);
-    const int n = mcl / plane_o, pix = mcl - n * plane_o, oy = pix / a.OW, ox = pix - oy * a.OW;
+    const int n = mcl / plane_q, pix = mcl - n * plane_q, qy = pix / a.QW, qx = pix - qy * a.QW;
     const int cb = blockIdx.y * 32 * MC;
     const int cplane = a.H * a.W;
     const int c0 = ks * a.cks + wid * a.cw + half;   // this lane's channel of pair 0 (pair j: c0 + 2j)
@@ -611,13 +617,13 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
     const char *xbase = reinterpret_cast<const char *>(a.x);
     const int wslice = ks * a.cks + wid * a.cw;                     // first channel of this wave
     const long wtap = (long)a.cin_pad * 32;
-    const long wblk = (long)(a.kh * a.kw) * wtap;                   // floats per cout block
-    const float *wtap0 = a.w + (long)blockIdx.y * MC * wblk + (long)wslice * 32;   // scalar
+    const long wblk = (long)(nty * ntx) * wtap;                     // floats per cout block (of this class)
+    const float *wtap0 = a.w + a.cls_woff[cls] + (long)blockIdx.y * MC * wblk + (long)wslice * 32;   // scalar
     const unsigned wlane = lane * 16u;
-    const int iy0 = oy * a.stride - a.pad_h, ix0 = ox * a.stride - a.pad_w;
+    const int iy0 = qy * a.in_s + a.cls_in_oy[cls], ix0 = qx * a.in_s + a.cls_in_ox[cls];
     constexpr int PAIRS = 4;                                        // channel pairs (= MFMAs) per load batch
     const int spt = a.cw / (2 * PAIRS);                             // load batches per tap
-    const int nsteps = a.kh * a.kw * spt;
+    const int nsteps = nty * ntx * spt;
 
     // running state of the load stream: tap (ky, kx), batch j within the tap
     int ky = 0, kx = 0, j = 0;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
         xoff += PAIRS * pstride;
         if (++j == spt) {
             j = 0;
-            if (++kx == a.kw) { kx = 0; ++ky; }
+            if (++kx == ntx) { kx = 0; ++ky; }
             wp += (wtap - (long)a.cw * 32) * 4;
             enter_tap();
         }
@@ -668,18 +674,20 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
     };
     // nsteps is a multiple of DEPTH (host picks DEPTH that way), so every load / MFMA batch below is unconditional and
     // the compiler can wait for exactly the oldest batch (s_waitcnt vmcnt(n)) instead of draining the queue
-    Ops ring[DEPTH];
+    if (nsteps > 0) {   // (a parity class of a transposed convolution can be without taps: its pixels are bias only)
+        Ops ring[DEPTH];
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) load(ring[i]);
-    for (int s = DEPTH; s < nsteps; s += DEPTH) {
+        for (int i = 0; i < DEPTH; ++i) load(ring[i]);
+        for (int s = DEPTH; s < nsteps; s += DEPTH) {
 #pragma unroll
-        for (int i = 0; i < DEPTH; ++i) {
-            mma(ring[i]);
-            load(ring[i]);
+            for (int i = 0; i < DEPTH; ++i) {
+                mma(ring[i]);
+                load(ring[i]);
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) mma(ring[i]);
+        for (int i = 0; i < DEPTH; ++i) mma(ring[i]);
+    }
 
     float *mine = s_red + wid * (MC * 32 * 33);
 #pragma unroll
@@ -695,9 +703,12 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
         float v = 0.f;
         for (int w = 0; w < nw; ++w) v += s_red[(w * (MC * 32) + i) * 33 + col];
         if (co >= a.cout || mm >= a.M) continue;
-        const int on = mm / plane_o, opix = mm - on * plane_o;
+        const int on = mm / plane_q, oq = mm - on * plane_q, oqy = oq / a.QW, oqx = oq - oqy * a.QW;
+        const int oy = oqy * a.out_s + a.cls_out_oy[cls], ox = oqx * a.out_s + a.cls_out_ox[cls];
+        if (oy < 0 || oy >= a.OH || ox < 0 || ox >= a.OW) continue;
+        const int opix = oy * a.OW + ox;
         if (a.ksplit > 1) {   // raw partial sums in k_conv_reduce's layout [ks][n][cout][OH][OW]
-            a.partial[((long)ks * (a.M / plane_o) + on) * a.cout * plane_o + (long)co * plane_o + opix] = v;
+            a.partial[((long)ks * (a.M / plane_q) + on) * a.cout * plane_o + (long)co * plane_o + opix] = v;
             continue;
         }
         if (a.bias) v += a.bias[co];
@@ -720,21 +731,23 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
     // LAV_CONV_DIRECT_WAVES and LAV_CONV_DIRECT_KS pin the workgroup size and the split
     auto env_int = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
     const int mode = env_int("LAV_CONV_DIRECT", 1), force_w = env_int("LAV_CONV_DIRECT_WAVES", 0), force_k = env_int("LAV_CONV_DIRECT_KS", 0);
-    if (!mode || c.transposed || c.cin % 16 != 0) return d;
-    const long M = (long)c.batch * p.OH * p.OW;
+    if (!mode || c.cin % 16 != 0 || (c.transposed && !env_int("LAV_CONV_DIRECT_TR", 1))) return d;
+    const long M = (long)c.batch * p.QH * p.QW;   // per class
     // the kernel addresses activations with 32-bit BYTE offsets from the tensor base
     if (M * c.cout >= (1l << 31) || (long)c.batch * c.in_c_total * c.h * c.w >= (1l << 30)) return d;
-    const int taps = c.kh * c.kw;
+    const int taps = p.taps_per_class;   // the largest class
     if (taps > 9 && mode != 2) return d;   // 7x7 stems re-read too much without an LDS tile (measured 93 vs 86 us, 475 vs 416)
     const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
     const int force_mc = env_int("LAV_CONV_DIRECT_MC", 0);
     for (int mc = 1; mc <= 2; ++mc) {
         if ((mc == 2 && c.cout < 64) || (force_mc && mc != force_mc)) continue;
-        const long tiles = (M + 31) / 32 * ((c.cout + 32 * mc - 1) / (32 * mc));
+        // transposed: measured a gain only for 4-tap classes with >= 128 couts (4x4 s2 up-convolution 53.7 -> 49.8 us)
+        if (mc == 2 && !force_mc && c.transposed && (p.taps_per_class < 4 || c.cout < 128)) continue;
+        const long tiles = (M + 31) / 32 * ((c.cout + 32 * mc - 1) / (32 * mc)) * p.nclasses;
         if (tiles > 8192) continue;
         // sharing a gather between two cout blocks pays once the layer is a few workgroups per CU deep (measured: 8-12 % at
         // >= 400 tiles, a loss on the small ResNet maps)
-        if (mc == 2 && !force_mc && (M + 31) / 32 * ((c.cout + 31) / 32) < 512) continue;
+        if (mc == 2 && !force_mc && (M + 31) / 32 * ((c.cout + 31) / 32) * p.nclasses < 512) continue;
         for (int ks = 1; ks <= 16; ks *= 2) {
             if (c.cin % (ks * 8) != 0) break;
             if (force_k && ks != force_k) continue;
@@ -947,17 +960,32 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         d.x = x; d.w = w_packed; d.bias = bias; d.scale = scale; d.shift = shift; d.res = residual; d.y = y; d.partial = a.partial;
         d.in_c_total = c->in_c_total; d.in_c_offset = c->in_c_offset; d.H = c->h; d.W = c->w;
         d.cout = c->cout; d.out_c_total = c->out_c_total; d.out_c_offset = c->out_c_offset; d.OH = p.OH; d.OW = p.OW;
-        d.cin_pad = p.cin_pad; d.cout_pad = p.cout_pad; d.kh = c->kh; d.kw = c->kw; d.stride = c->stride;
-        d.pad_h = c->pad_h; d.pad_w = c->pad_w; d.dil_h = c->dil_h; d.dil_w = c->dil_w;
-        d.M = c->batch * p.OH * p.OW; d.cw = dp.cw; d.cks = dp.cw * dp.waves; d.ksplit = dp.ksplit;
+        d.cin_pad = p.cin_pad; d.cout_pad = p.cout_pad; d.dil_h = c->dil_h; d.dil_w = c->dil_w;
+        d.QH = p.QH; d.QW = p.QW; d.in_s = p.in_s; d.out_s = p.out_s; d.nclasses = p.nclasses;
+        int steps_gcd = 0;   // the load ring's depth must divide every class's step count
+        for (int i = 0; i < MAX_CLASSES; ++i) {
+            const bool live = i < p.nclasses;
+            int nty = 0, ntx = 0;
+            if (live && !p.taps[i].empty()) {
+                ntx = 1;
+                while (ntx < (int)p.taps[i].size() && p.taps[i][ntx].dy == p.taps[i][0].dy) ++ntx;   // taps are dy-major
+                nty = (int)p.taps[i].size() / ntx;
+            }
+            d.cls_nty[i] = nty; d.cls_ntx[i] = ntx;
+            d.cls_in_oy[i] = live ? p.in_oy[i] : 0; d.cls_in_ox[i] = live ? p.in_ox[i] : 0;
+            d.cls_out_oy[i] = live ? p.out_oy[i] : 0; d.cls_out_ox[i] = live ? p.out_ox[i] : 0;
+            d.cls_woff[i] = live ? (int)p.woff[i] : 0;
+            const int st = nty * ntx * (dp.cw / 8);
+            for (int x = st, y = steps_gcd; ; ) { if (!y) { steps_gcd = x; break; } const int t = x % y; x = y; y = t; }
+        }
+        d.M = c->batch * p.QH * p.QW; d.cw = dp.cw; d.cks = dp.cw * dp.waves; d.ksplit = dp.ksplit;
         d.relu_pre = c->relu_pre; d.relu_post = c->relu_post; d.sigmoid = c->sigmoid; d.pad_value = c->pad_value;
         const int tok = timer_begin("conv2d", st);
-        dim3 grid((d.M + 31) / 32, (c->cout + 32 * dp.mc - 1) / (32 * dp.mc), dp.ksplit);
+        dim3 grid((d.M + 31) / 32, (c->cout + 32 * dp.mc - 1) / (32 * dp.mc), dp.ksplit * p.nclasses);
         const dim3 block(64 * dp.waves);
         const size_t lds_red = (size_t)dp.waves * dp.mc * 32 * 33 * 4;   // <= 66 KB
-        const int nsteps = c->kh * c->kw * (dp.cw / 8);
         int depth = dp.mc == 1 ? 9 : 6;   // ring registers: DEPTH * (4 * MC + 4)
-        while (nsteps % depth) --depth;
+        while (steps_gcd % depth) --depth;
         switch (depth * 10 + dp.mc) {
 #define LAV_DIRECT_CASE(D, MC_) case D * 10 + MC_: { \
             static bool attr = false; \

@@ -235,8 +235,8 @@ def test_vectorised_detection_decode_equals_the_loops():
 
 def test_direct_plan_is_chosen_where_it_was_measured_faster():
     """Host-side plan choice (no GPU): small ResNet maps and the mid-size BEV layers take the direct kernel
-    (info[0] == 0, info[1] waves, info[2] cout blocks, info[6] split-K); 7x7 stems, the deep 2x2-tiled head convolution,
-    transposed and ragged-channel layers stay on the tiled kernel; every direct plan keeps a whole number of 8-channel
+    (info[0] == 0, info[1] waves, info[2] cout blocks, info[6] split-K); 7x7 stems, the deep 2x2-tiled head convolution
+    and ragged-channel layers stay on the tiled kernel; every direct plan keeps a whole number of 8-channel
     groups per wave and a reduction scratch within the LDS."""
     lib = _lib.load()
     info = (C.c_int * 9)()
@@ -261,7 +261,10 @@ def test_direct_plan_is_chosen_where_it_was_measured_faster():
              (1, 13, 48, 3, 1, 1, 20, 33)]
     for shp in tiled:
         assert plan(*shp)[0] >= 1, f"{shp}: expected a tiled plan"
-    assert plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)[0] >= 1
+    # transposed convolutions run on the direct kernel too (one launch, output-parity classes in grid.z)
+    i = plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)
+    assert i[0] == 0 and i[2] == 2
+    assert plan(1, 128, 128, 4, 4, 0, 40, 40, tr=True)[:3] == [0, 4, 1]
 
 
 def test_grouped_deconv_rejects_unsupported_geometry_before_any_launch():

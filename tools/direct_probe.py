@@ -39,6 +39,12 @@ SHAPES = [
     ("bev 64->128 s2 160", 64, 128, 3, 2, 1, 160, 160),
     ("brake l1 64 72x192", 64, 64, 3, 1, 1, 72, 192),
     ("head 64->64 1x1 160", 64, 64, 1, 1, 0, 160, 160),
+    # transposed (name starts with T): k, stride, pad as for ConvTranspose2d, output_padding 1 for the 3x3 ones
+    ("T bev 1x1 64->128 160", 64, 128, 1, 1, 0, 160, 160),
+    ("T bev 4x4 s2 128 80", 128, 128, 4, 2, 1, 80, 80),
+    ("T bev 4x4 s4 128 40", 128, 128, 4, 4, 0, 40, 40),
+    ("T erf 3x3 s2 128->64", 128, 64, 3, 2, 1, 36, 32),
+    ("T erf 3x3 s2 64->16", 64, 16, 3, 2, 1, 72, 64),
 ]
 dev = torch.device("cuda")
 
@@ -63,7 +69,8 @@ def main():
     for name, cin, cout, k, s, p, H, W in SHAPES:
         if sel and not any(t in name for t in sel):
             continue
-        w = torch.randn((cout, cin, k, k)) * 0.05
+        tr = name.startswith("T ")
+        w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k)) * 0.05
         for B in batches:
             x = torch.randn((B, cin, H, W), device=dev)
             res = {}
@@ -79,7 +86,7 @@ def main():
                     if cin % (8 * int(wv) * int(ks)) or (mc == "2" and (cout < 64 or int(wv) > 8)):
                         continue
                     os.environ.update(LAV_CONV_DIRECT="2", LAV_CONV_DIRECT_WAVES=wv, LAV_CONV_DIRECT_KS=ks, LAV_CONV_DIRECT_MC=mc)
-                layer = ConvLayer(w, stride=s, padding=p, relu_post=True, device=dev)
+                layer = ConvLayer(w, stride=s, padding=p, relu_post=True, transposed=tr, output_padding=1 if (tr and k == 3) else 0, device=dev)
                 try:
                     res[cfg] = timed(layer, x)
                 except RuntimeError as e:
