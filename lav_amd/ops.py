@@ -383,7 +383,7 @@ class Conv1dPair:
 
     def supported(self, x: torch.Tensor) -> bool:
         w = x.shape[3]
-        return (w in (32, 64, 128) and self.ch % 16 == 0 and (self.ch + 31) // 32 <= 128 // w
+        return (w in (32, 64, 128) and self.ch % 16 == 0 and (self.ch + 31) // 32 <= 128 // w and self.db <= 16
                 and _lib.load().lav_conv1d_pair_lds_bytes(self.ch, w, self.db) <= 160 * 1024)
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
