@@ -57,6 +57,12 @@ for name, conv, shp in todo:
     s = conv.stride[0]
     QH, QW = (shp[2], shp[3]) if tr else (oh.value, ow.value)
     ncls = s * s if tr else 1
+    if MP == 0:   # direct kernel: info = {0, waves, cout blocks per workgroup, -, -, LDS, split-K, ...}
+        waves, mcb = MCt, rb
+        nwg = -(-(shp[0] * QH * QW) // 32) * (-(-cout // (32 * mcb))) * ncls * ks
+        print(f"{name:10s} {'T' if tr else 'C'} {cin:4d}->{cout:4d} k{conv.kernel_size[0]}x{conv.kernel_size[1]} s{s} d{conv.dilation[0]},{conv.dilation[1]} "
+              f"in {shp[0]}x{shp[2]}x{shp[3]:<4d} direct waves={waves:2d} cout-blocks={mcb} lds={lds // 1024:3d}K ks={ks:2d} wgs={nwg:5d} rounds={-(-nwg // 256)}")
+        continue
     PIXW = 128 * MP
     xt = QH * ((QW + PIXW - 1) // PIXW) if rb else (QH * QW + PIXW - 1) // PIXW
     nwg = xt * ((cout + 32 * MCt - 1) // (32 * MCt)) * shp[0] * ncls * ks
