@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 8
+#define LAV_ABI_VERSION 9
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -69,8 +69,16 @@ typedef struct lav_pointnet {
     int channels;  /* C (64) */
 } lav_pointnet;
 
-/* Bytes of scratch lav_pillar_scatter needs for `batch` clouds of at most `max_points` points. */
+/* Bytes of scratch lav_pillar_scatter needs for `batch` clouds of at most `max_points` points.
+ *
+ * Workspace contract: the head of a pillar workspace holds state that is ZERO AT REST (two sets of arrival counters
+ * used alternately and two epoch words), which is what lets a call run as two launches with no memset.  Zero-fill a
+ * workspace ONCE after allocating it (lav_pillar_workspace_init, or any memset), keep it for ONE (batch, grid) geometry
+ * (max_points may vary up to the size it was allocated for) and do not write to it between calls; every call leaves it
+ * clean for the next one.  Re-run lav_pillar_workspace_init to reuse the memory for another geometry or after a
+ * failed launch.  Calls sharing a workspace must be ordered on one stream. */
 size_t lav_pillar_workspace_bytes(int batch, int max_points, const lav_grid *grid);
+int lav_pillar_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * points      [batch][max_points][D]   (a single cloud: batch=1, max_points=N)
@@ -265,12 +273,14 @@ int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max
  *    point; kept_src [N_kept] flat index (cloud*max_points + row) of each kept point - kept points stay in input
  *    order; decorated [N_kept][D+5] = (point, xyz - pillar mean, x - cell_x, y - cell_y) with the reference's swapped
  *    cell origin; counts [2] (device) = {P, N_kept}.  Pillar means are the same order-independent fixed-point sums as
- *    in lav_pillar_scatter.  Workspace: lav_pillar_workspace_bytes.  Any output except decorated/counts may be NULL.
+ *    in lav_pillar_scatter.  Workspace: lav_pillar_decorate_workspace_bytes (no at-rest state; a lav_pillar_scatter workspace of
+ *    the same geometry also serves and stays valid).  Any output except decorated/counts may be NULL.
  *
  * lav_scatter_max: out[s][c] = max over rows i with index[i] == s of src[i][c]; argmax[s][c] = the lowest such row
  *    (n for an empty segment, whose out is 0 - torch_scatter's convention).  src [n][channels], index [n] int32.
  * lav_scatter_max_backward: grad_src[argmax[s][c]][c] = grad_out[s][c], zero elsewhere.
  * ------------------------------------------------------------------------------------------ */
+size_t lav_pillar_decorate_workspace_bytes(int batch, int max_points, const lav_grid *grid);
 int lav_pillar_decorate(const float *points, const int *h_num_points, int batch, int max_points, int D,
                         const lav_grid *grid, int *unique_coords, int *inverse, int *kept_src, float *decorated,
                         int *counts, void *workspace, size_t workspace_bytes, void *stream);

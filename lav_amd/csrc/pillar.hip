@@ -3,30 +3,37 @@
 // Replaces PointPillarNet.forward of the reference (lav/models/point_pillar.py:92-116) including the two
 // torch_scatter calls (:33, :62) and coords.unique(dim=0) (:82).  gfx950 only.
 //
-// Data flow of the canvas path (all buffers in HBM; v2 agent: N ~ 196k points x 11 floats, 320x320 cells, C = 64).
-// Points are binned by CANVAS TILE (one canvas row x 160 columns = the unit one workgroup writes), not by cell:
+// Canvas path = TWO launches (v2 agent: N ~ 196k points x 11 floats, 320x320 cells, C = 64):
 //
-//   k_tile_count   1 thread / point : float32 cell id exactly as the reference, tile id, slot = arrival number
-//                                     inside the tile (int atomic on 640 counters; order is irrelevant, see below)
-//   k_tile_scan    1 workgroup      : exclusive prefix of the tile counters
-//   k_tile_place   1 thread / point : writes a contiguous 48-byte record {11 floats, cell key} at
-//                                     rec[tile_offset + slot]  -> the big kernel never chases indices
-//   k_tile_pointnet  one workgroup per (cloud, canvas row, column tile):
-//        (a) per-cell xyz sums and counts in LDS (64-bit fixed-point atomics: order independent, so the result
-//            is bit-identical for ANY arrival order / input permutation; exact to 2^-32 m), means
-//        (b) every wave takes passes of 32 records and runs BOTH PointNet layers on the matrix cores with all
-//            activations in registers (v_mfma_f32_32x32x2_f32, exact fp32):
+//   k_bin   1 thread / point.  float32 cell id exactly as the reference; the UNIT the cell lands on = one canvas row
+//           x 32 columns (one 128-byte line of every channel plane); arrival slot by one integer atomic on the unit's
+//           counter (2 sub-counters on different cache lines); the point is written ONCE as a 48-byte record
+//           {11 floats, packed cell} into the unit's fixed-capacity bucket, or appended to an overflow list when the
+//           bucket is full (adversarial clouds only).  No scan, no second pass over the cloud.
+//   k_rows  persistent workgroups, two per CU.  Every workgroup reads all unit counters once (25 KB, L2),
+//           prices a unit at COST_UNIT + points, and takes the contiguous run of units holding its 1/W share of the
+//           total - a static, deterministic partition with no queue and no inter-workgroup traffic.  The run is
+//           processed in GROUPS of up to 5 units of one canvas row (160 columns):
+//        (a) per-cell xyz sums and counts in LDS (64-bit fixed point: order independent, so the canvas is
+//            bit-identical for ANY arrival order / input permutation; exact to 2^-32 m);
+//        (b) JOBS of 16 points, dealt round-robin to the 4 waves, run BOTH PointNet layers on the matrix cores
+//            with every weight fragment and all activations in registers (v_mfma_f32_16x16x4_f32, exact fp32):
 //              layer 1 (transposed)  D1[c][p]  = sum_k W1[k][c] * F[k][p]     A = weights, B = point features
-//                 lane l supplies feature 2s+(l>>5) of point l&31 at k-step s; the bias rides as feature 16 (=1).
-//                 D1 leaves lane (p, half) holding channels c = 32*mt + (r&3) + 8*(r>>2) + 4*half  (r = 0..15)
+//                 lane (p = l&15, g = l>>4) supplies feature 4s+g of point p at k-step s; the bias rides as
+//                 feature K1 (= 1).  D1 leaves lane (p, g) holding channels 16*ct + 4*g + r  (r = 0..3).
 //              layer 2               D2[p][c2] = sum_c H1[p][c] * W2[c][c2]   A = relu(D1) AS IT SITS, B = weights
-//                 k-step (mt, r) uses k = 32*mt + (r&3) + 8*(r>>2) + 4*half - a permutation of 0..63, which a
-//                 sum does not care about - so no lane shuffles or LDS round trip between the layers.
-//        (c) unsigned-integer max of the float bits (values >= 0 after ReLU) into an LDS tile [C][tile_w|1]
-//            (odd stride: conflict-free)
-//        (d) the tile - zeros for empty cells included - streams to the NCHW canvas, 256 B per wave-instruction.
-//            The canvas is written exactly once and never read or memset: algorithmic traffic
-//            4*(N*D + C*ny*nx) bytes.  Tiles without points skip (a)-(c) and stream zeros.
+//                 k-step (ct, r) covers k = 16*ct + 4*g + r over the four lane groups - a permutation of 0..63,
+//                 which a sum does not care about - so no shuffles or LDS round trip between the layers;
+//        (c) unsigned-integer max of the float bits (values >= 0 after ReLU) into an LDS tile [C][164];
+//        (d) the tile - zeros for empty cells included - streams to the NCHW canvas with 16-byte stores, and
+//            is cleared by the same pass (read-and-clear), so it is zero again for the next group.
+//           Groups without points write zeros straight from registers.  The canvas is written exactly once and
+//           never read or memset: algorithmic traffic 4*(N*D + C*ny*nx) bytes.  Records of the next group are
+//           requested while the current one is on the matrix cores.
+//
+// Workspace contract: the first bytes of the workspace hold state that is ZERO AT REST (two sets of unit counters
+// used alternately, two epoch words).  The caller zero-fills a workspace once (lav_pillar_workspace_init) and keeps it
+// for one (batch, grid) geometry; every call leaves it clean for the next one without a memset launch.
 //
 // Index outputs (unique_coords / inverse, the "bit-exact pillar indices" of the parity contract) come from a
 // separate per-cell occupancy path (count, two scans) that only runs when they are requested.
@@ -38,6 +45,7 @@
 // order win, by processing such "overflow" cells as extra layers after the regular ones.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -51,24 +59,58 @@ using namespace lav;
 
 constexpr int C = 64;            // PointNet width (config num_features [64,64])
 constexpr int MAX_BATCH = 64;    // per-call limit on clouds (kernel-argument table)
-constexpr int TILE_MAX_W = 80;   // canvas columns per workgroup tile (LDS tile [64][tile_w|1] floats): 4 workgroups per CU
-constexpr int NSUB = 8;          // arrival counters per tile, on different cache lines, to spread the atomic traffic
-constexpr int MAX_LAYERS = 64;   // regular + overflow layers a tile may have (2-4 for square grids)
-constexpr int REC_MAX = 16;      // dwords per point record the workspace is sized for (D <= 15)
+constexpr int UW = 32;           // canvas columns per unit
+constexpr int NSUB = 2;          // arrival counters per unit, on different cache lines
+constexpr int GMAX = 8;          // units per group (consecutive units, whatever canvas rows they are on)
+constexpr int GW = GMAX * UW;    // canvas columns per group (LDS tile width)
+constexpr int TS = GW + 4;       // LDS tile row stride in floats (16-byte aligned rows)
+constexpr int WIN = 64;          // unit counters cached in LDS at a time
+constexpr int COST_UNIT = 24;    // price of streaming one unit out, in points (partition of k_rows)
+constexpr int CAP_MIN = 16, CAP_MAX = 256;  // records per (unit, sub) bucket
+constexpr int MAX_LAYERS = 64;   // regular + overflow layers a group may have (2-4 for square grids)
 constexpr double FIX_SCALE = 4294967296.0;  // 2^32 fixed-point scale of the per-cell coordinate sums
 
-struct PillarArgs {
+// zero at rest (see the workspace contract above)
+struct State {
+    unsigned epoch_bin;   // written by k_bin, read by k_rows of the same call
+    unsigned epoch_rows;  // written by k_rows, read by k_bin of the next call
+    int n_ovf[2];         // overflow records appended by k_bin, per counter set
+    int pad[60];
+};
+static_assert(sizeof(State) == 256, "State is 256 bytes");
+
+struct PillarArgs {   // scalars first: they share the first cache line of the kernel-argument segment
     const float *points;
     int batch, max_points, D;
-    int n[MAX_BATCH];
     float min_x, max_x, min_y, max_y, ppm;
     int nx, ny;  // nx = number of xi cells = canvas columns; ny = number of yi cells = canvas rows
     int KX, KY;  // key space (nx+1) x (ny+1)
-    int T, TW;   // column tiles per canvas row, columns per tile
-    unsigned long long *trace;  // debug (LAV_PILLAR_TRACE): [ntiles][8] wall-clock stamps of thread 0, else null
+    int UPR;     // units per canvas row
+    int NUP;     // stride of one sub-counter array = number of units rounded up to 4 (16-byte loads)
+    int cap;     // records per (unit, sub) bucket
+    unsigned long long *trace;  // debug (LAV_PILLAR_TRACE): [workgroups][16] wall-clock stamps of thread 0, else null
+    int n[MAX_BATCH];
 };
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+// What k_rows needs of the above: small enough to arrive with the first kernel-argument fetch.
+struct RowsArgs {
+    int batch, nx, ny, UPR, NUP, cap, cost_unit;
+    float min_x, min_y, ppm;
+    unsigned long long *trace;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int rec_size(int D) { return D + 1 <= 8 ? 8 : 12; }  // dwords per record; the last one is the packed cell
+
+// PointNet weights in the order the matrix instructions of k_rows consume them, one float4 per lane and fragment row:
+//   rows 0 .. KS1-1      layer-1 A operand of k-step s, the four 16-channel tiles:  W1[4s + lg][16 ct + lp]  (bias at k = K1)
+//   rows KS1 .. KS1+15   layer-2 B operand of k-step (ct, r), the four output tiles:  W2[16 ct + 4 lg + r][16 ct2 + lp]
+//   row  KS1+16          layer-2 bias b2[16 ct2 + lp]
+// k_bin writes them into the workspace on every call (5.6 k floats), so that every wave of k_rows gets its 88 weight
+// registers with 22 coalesced 16-byte loads instead of 88 scattered 4-byte ones.
+constexpr int layer1_ksteps(int D) { return (D + 5 + 4) / 4; }
+constexpr int packed_weight_floats(int D) { return (layer1_ksteps(D) + 17) * 64 * 4; }
 
 // cell key of a point, or -1 (grid_locations, point_pillar.py:70-79)
 __device__ __forceinline__ int cell_key(const PillarArgs &a, int b, float x, float y) {
@@ -80,412 +122,721 @@ __device__ __forceinline__ int cell_key(const PillarArgs &a, int b, float x, flo
     return (b * a.KX + xi) * a.KY + yi;
 }
 
-// canvas tile that cell (b, xi, yi) lands on (scatter_points clamp, point_pillar.py:89)
-__device__ __forceinline__ int tile_of(const PillarArgs &a, int b, int xi, int yi) {
+// unit that cell (b, xi, yi) lands on (scatter_points clamp, point_pillar.py:89)
+__device__ __forceinline__ int unit_of(const PillarArgs &a, int b, int xi, int yi) {
     const int r = min(max(a.ny - 1 - xi, 0), a.ny - 1);
     const int col = min(yi, a.nx - 1);
-    return (b * a.ny + r) * a.T + col / a.TW;
+    return (b * a.ny + r) * a.UPR + col / UW;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_count(PillarArgs a, int *__restrict__ key, int *__restrict__ slot,
-                                                    int *__restrict__ tile_count) {
+template <int D>
+__global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ st, int *__restrict__ counters,
+                                             float *__restrict__ buckets, float *__restrict__ ovf, int *__restrict__ key_out,
+                                             const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                                             const float *__restrict__ b2, float *__restrict__ wpack) {
+    constexpr int RS = rec_size(D);
+    // fetch both cache lines of the kernel-argument segment at once (taken in turn, each is a microsecond-scale miss)
+    asm volatile("" ::"s"(a.max_points), "s"(key_out));
     const long total = (long)a.batch * a.max_points;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned e = st->epoch_rows;
+    if (gid == 0) {
+        st->epoch_bin = e;
+        st->n_ovf[(e & 1u) ^ 1u] = 0;
+    }
+    {   // The counter set of the previous call was consumed by its k_rows: clean it here, so that k_rows can read "both sets
+        // added up" without first waiting for the epoch word to learn which one is live.
+        int *cz = counters + (size_t)((e & 1u) ^ 1u) * NSUB * a.NUP;
+        for (long i = gid; i < (long)NSUB * a.NUP; i += (long)gridDim.x * 256) cz[i] = 0;
+    }
+    {   // PointNet weights in fragment order (see packed_weight_floats)
+        constexpr int K1 = D + 5, KS1 = layer1_ksteps(D);
+        for (long i = gid; i < packed_weight_floats(D); i += (long)gridDim.x * 256) {
+            const int c4 = (int)i & 3, l = ((int)i >> 2) & 63, row = (int)i >> 8, lp = l & 15, lg = l >> 4;
+            float v;
+            if (row < KS1) {
+                const int k = 4 * row + lg, c = 16 * c4 + lp;
+                v = k < K1 ? w1[k * C + c] : (k == K1 ? b1[c] : 0.f);
+            } else if (row < KS1 + 16) {
+                const int ct = (row - KS1) >> 2, r = (row - KS1) & 3;
+                v = w2[(16 * ct + 4 * lg + r) * C + 16 * c4 + lp];
+            } else {
+                v = b2[16 * c4 + lp];
+            }
+            wpack[i] = v;
+        }
+    }
     if (gid >= total) return;
     const int b = (int)(gid / a.max_points);
     const int i = (int)(gid - (long)b * a.max_points);
     int k = -1;
-    if (i < a.n[b]) {
-        const float *pt = a.points + gid * a.D;
-        k = cell_key(a, b, pt[0], pt[1]);
-    }
-    key[gid] = k;
-    if (k >= 0) {
-        const int cellk = k - b * a.KX * a.KY;
-        // counters are laid out [sub][tile]; the sub-bucket only decorrelates concurrent arrivals
-        const int sub = (threadIdx.x ^ (threadIdx.x >> 6) ^ blockIdx.x) & (NSUB - 1);
-        const int ntiles = a.batch * a.ny * a.T;
-        slot[gid] = sub | (atomicAdd(&tile_count[sub * ntiles + tile_of(a, b, cellk / a.KY, cellk % a.KY)], 1) << 3);
-    }
-}
-
-// Exclusive prefix of the arrival counters in (tile, sub) order - a tile's NSUB buckets end up contiguous - read from
-// their [sub][tile] layout, and re-zeroing of nothing: n = ntiles*NSUB is a few thousand, so one workgroup does it with
-// a serial run of ceil(n/1024) items per thread and a single 1024-wide block scan.
-__global__ __launch_bounds__(1024) void k_tile_scan(const int *__restrict__ count, int n, int *__restrict__ offset,
-                                                    int4 *__restrict__ order, int *__restrict__ g_tmp) {
-    __shared__ int wsum[16];
-    __shared__ int bucket[33];
-    extern __shared__ int s_tile[];  // [ntiles] points per tile, then [ntiles] first-record offset per tile
-    const int ntiles = n / NSUB;
-    // per-tile scratch: LDS for the usual few clouds, the workspace for large batches (one workgroup either way)
-    int *s_tot = g_tmp ? g_tmp : s_tile, *s_p0 = s_tot + ntiles;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int t = tid; t < ntiles; t += 1024) s_tot[t] = 0;
-    if (tid < 33) bucket[tid] = 0;
-    __syncthreads();
-    const int per = (n + 1023) / 1024;
-    const int i0 = tid * per;
-    int sum = 0;
-    for (int j = 0; j < per; ++j) {
-        const int i = i0 + j;
-        if (i < n) {
-            const int c = count[(i % NSUB) * ntiles + i / NSUB];
-            sum += c;
-            if (c) atomicAdd(&s_tot[i / NSUB], c);
-        }
-    }
-    int inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    int run = inc - sum;
-#pragma unroll
-    for (int w = 0; w < 16; ++w)
-        if (w < wid) run += wsum[w];
-    for (int j = 0; j < per; ++j) {
-        const int i = i0 + j;
-        if (i < n) {
-            offset[i] = run;
-            if (i % NSUB == 0) s_p0[i / NSUB] = run;
-            run += count[(i % NSUB) * ntiles + i / NSUB];
-        }
-    }
-    if (i0 < n && i0 + per >= n) offset[n] = run;  // the thread owning the last item writes the grand total
-    // Dispatch order of the PointNet kernel's tiles: heaviest first (32 buckets of 32 points), so that the second round of
-    // workgroups on the chip is made of the light tiles.  Order inside a bucket is arbitrary - tiles are independent.
-    // Each entry carries the tile's record range, so a workgroup needs ONE 16-byte load to know its work.
-    __syncthreads();   // s_p0 / s_tot complete
-    int total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) total += wsum[w];
-    if (total < 65536) {   // light clouds (config #2: 32 768 points): every tile is about one pass - keep the canvas order,
-                           // which measured 2.4 us faster there (adjacent workgroups write adjacent canvas rows)
-        for (int t = tid; t < ntiles; t += 1024) order[t] = make_int4(t, s_p0[t], s_p0[t] + s_tot[t], 0);
-        return;
-    }
-    for (int t = tid; t < ntiles; t += 1024) atomicAdd(&bucket[31 - min(s_tot[t] >> 5, 31)], 1);
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int b = 0; b < 32; ++b) { const int c = bucket[b]; bucket[b] = acc; acc += c; }
-    }
-    __syncthreads();
-    for (int t = tid; t < ntiles; t += 1024)
-        order[atomicAdd(&bucket[31 - min(s_tot[t] >> 5, 31)], 1)] = make_int4(t, s_p0[t], s_p0[t] + s_tot[t], 0);
-}
-
-__global__ __launch_bounds__(256) void k_zero_ints(int *__restrict__ p, int n) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0;
-}
-
-template <int D>
-__global__ __launch_bounds__(256) void k_tile_place(PillarArgs a, const int *__restrict__ key, const int *__restrict__ slot,
-                                                    const int *__restrict__ tile_offset, float *__restrict__ rec) {
-    constexpr int RS = D + 1;
-    const long total = (long)a.batch * a.max_points;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int k = key[gid];
-    if (k < 0) return;
-    const int b = (int)(gid / a.max_points);
-    const int cellk = k - b * a.KX * a.KY;
-    const int sl = slot[gid];
-    const long j = tile_offset[tile_of(a, b, cellk / a.KY, cellk % a.KY) * NSUB + (sl & (NSUB - 1))] + (sl >> 3);
     const float *pt = a.points + gid * D;
     float v[RS];
-#pragma unroll
-    for (int d = 0; d < D; ++d) v[d] = pt[d];
-    v[D] = __int_as_float(k);
-    float *o = rec + j * RS;
-    if constexpr (RS % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < RS / 4; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int d = 0; d < RS; ++d) o[d] = v[d];
+    if (i < a.n[b]) {
+        v[0] = pt[0];
+        v[1] = pt[1];
+        k = cell_key(a, b, v[0], v[1]);
     }
+    if (key_out) key_out[gid] = k;
+    if (k < 0) return;
+    const int cellk = k - b * a.KX * a.KY;
+    const int xi = cellk / a.KY, yi = cellk - xi * a.KY;
+    const int unit = unit_of(a, b, xi, yi);
+    const int set = (int)(e & 1u);
+    // the sub-counter only decorrelates concurrent arrivals
+    const int sub = (threadIdx.x ^ (threadIdx.x >> 6) ^ blockIdx.x) & (NSUB - 1);
+    const int slot = atomicAdd(&counters[((size_t)set * NSUB + sub) * a.NUP + unit], 1);
+#pragma unroll
+    for (int d = 2; d < D; ++d) v[d] = pt[d];
+#pragma unroll
+    for (int d = D; d < RS - 1; ++d) v[d] = 0.f;
+    v[RS - 1] = __int_as_float((b << 24) | (xi << 12) | yi);
+    float *o;
+    if (slot < a.cap) {
+        o = buckets + (((size_t)unit * NSUB + sub) * a.cap + slot) * RS;
+    } else {
+        o = ovf + (size_t)atomicAdd(&st->n_ovf[set], 1) * RS;
+    }
+#pragma unroll
+    for (int q = 0; q < RS / 4; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-template <int D>
-__device__ __forceinline__ void load_record(const float *__restrict__ rec, long j, float (&v)[D + 1]) {
-    constexpr int RS = D + 1;
-    const float *p = rec + j * RS;
-    if constexpr (RS % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < RS / 4; ++q) {
-            const float4 t = reinterpret_cast<const float4 *>(p)[q];
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < RS; ++d) v[d] = p[d];
-    }
-}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)), which would serialise the record prefetches and the canvas stores of
+// k_rows behind each barrier; the waves of k_rows exchange data through LDS only.
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int D>
-__device__ __forceinline__ void decorate(const PillarArgs &a, const float *pt, const float *mean3, int xi, int yi, float *f) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) f[d] = pt[d];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) f[D + d] = pt[d] - mean3[d];
-    // reference decorate(): x - (yi/ppm + min_x), y - (xi/ppm + min_y)  (sic: swapped, un-centred; :57-58)
-    f[D + 3] = pt[0] - ((float)yi / a.ppm + a.min_x);
-    f[D + 4] = pt[1] - ((float)xi / a.ppm + a.min_y);
+// Inclusive prefix sum inside every row of 16 lanes (DPP row shifts: no LDS round trip, unlike __shfl_up).
+__device__ __forceinline__ int row_scan16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1, lanes shifted in read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    return v;
+}
+// Inclusive prefix sum over the 64 lanes of a wave.
+__device__ __forceinline__ int wave_scan64(int v) {
+    v = row_scan16(v);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int D, bool USE_MFMA, bool TRACE = false>
-__global__ __launch_bounds__(256, 3) void k_tile_pointnet(PillarArgs a, const float *__restrict__ rec,
-                                                          const int *__restrict__ tile_offset, const int4 *__restrict__ tile_order,
-                                                          const float *__restrict__ w1, const float *__restrict__ b1,
-                                                          const float *__restrict__ w2, const float *__restrict__ b2,
-                                                          float *__restrict__ canvas) {
-    constexpr int K1 = D + 5;          // decorated features
-    constexpr int KS1 = (K1 + 2) / 2;  // layer-1 k-steps incl. the bias feature (K1=16 -> 9)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int TW = a.TW, TWP = TW | 1;
-    float *tile = reinterpret_cast<float *>(smem);                                                        // [C][TWP]
-    unsigned long long *sums = reinterpret_cast<unsigned long long *>(smem + ((C * TWP * 4 + 15) & ~15));  // [TW][3]
-    float *means = reinterpret_cast<float *>(sums + TW * 3);                                              // [TW][3]
-    int *cnt = reinterpret_cast<int *>(means + TW * 3);                                                   // [TW]
-    int *nl = cnt + ((TW + 3) & ~3);                                                                      // [MAX_LAYERS]
-    float *w2s = reinterpret_cast<float *>(nl + MAX_LAYERS);                                              // [C][C]
+// One group of consecutive units, as every thread of the workgroup sees it (all values workgroup-uniform).
+struct Group {
+    int u, ue;      // units [u, ue)
+    int n;          // records in the buckets of the group
+    bool has_ovf;   // some bucket of the group overflowed into the overflow list
+    int slot;       // which of the wave's two prefix tables (gpre) describes its buckets
+    unsigned mask;  // bit NSUB*k + s: bucket (unit k, sub s) holds records
+};
+constexpr int NBKT = GMAX * NSUB;  // buckets of a group
 
-    // Workgroups are dispatched in blockIdx order and the 1280 tiles need two rounds on the chip: k_tile_scan sorted the
-    // tiles heaviest-first, so the second round (and the tail) is made of the sparse far field.
-    const int4 work = tile_order[blockIdx.x];   // (tile, first record, end record)
-    const int wg = work.x;
-    const int t = wg % a.T;
-    const int r = (wg / a.T) % a.ny;  // canvas row
-    const int b = wg / (a.T * a.ny);
-    const int c0 = t * TW;
-    const int c1 = min(a.nx, c0 + TW);
-    const int tw = c1 - c0;  // live columns in this tile
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-#define LAV_STAMP(i) do { if constexpr (TRACE) { if (tid == 0) a.trace[(long)wg * 8 + (i)] = wall_clock64(); } } while (0)
+template <int D, bool USE_MFMA, bool VEC4, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__ st, int *__restrict__ counters,
+                                                 const float *__restrict__ buckets, const float *__restrict__ ovf,
+                                                 const float *__restrict__ w1, const float *__restrict__ b1,
+                                                 const float *__restrict__ w2, const float *__restrict__ b2,
+                                                 const float *__restrict__ wpack, float *__restrict__ canvas) {
+    constexpr int K1 = D + 5;              // decorated features
+    constexpr int KS1 = layer1_ksteps(D);  // layer-1 k-steps of 4 incl. the bias feature (K1 = 16 -> 5)
+    constexpr int RS = rec_size(D), RQ = RS / 4;
+    __shared__ __attribute__((aligned(16))) float tile[C * TS];  // [C][TS]
+    __shared__ unsigned long long sums[GW * 3];                  // [col][3]
+    __shared__ int cnt[GW];
+    __shared__ int nl[MAX_LAYERS];
+    __shared__ int occ4[GW / 4];   // group number (+1) of the last group that put a point on this quad of columns
+    __shared__ int newq[GW / 4];   // quads a layer's sweep touched for the first time in this group: their tile columns get zeroed
+    __shared__ int win[NSUB][WIN];
+    __shared__ __attribute__((aligned(16))) int gpre[4][2][NBKT + 4];  // per wave, two slots: first record index of every bucket of a group
+    __shared__ __attribute__((aligned(16))) int red[32];
+
+    // fetch both cache lines of the kernel-argument segment at once (taken in turn, each is a microsecond-scale miss)
+    asm volatile("" ::"s"(a.batch), "s"(canvas));
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lp = lane & 15, lg = lane >> 4;
+#define LAV_STAMP(i) do { if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + (i)] = wall_clock64(); } } while (0)
     LAV_STAMP(0);
-    const int p0 = work.y, p1 = work.z;
-    if constexpr (TRACE) { if (tid == 0) a.trace[(long)wg * 8 + 7] = (unsigned long long)(p1 - p0); }
-    float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
-    const long cstride = (long)a.ny * a.nx;
+    long long cyc0 = 0;
+    if constexpr (TRACE) cyc0 = clock64();
+    const int nunits = a.batch * a.ny * a.UPR;
+    // Two counter sets are used by alternate calls and k_bin has cleaned the one it did not fill: every counter is read
+    // as the sum over both sets, which needs no knowledge of the epoch.
+    const int *__restrict__ cn = counters;
 
-    if (p0 == p1) {  // empty tile: stream zeros (workgroup-uniform)
-        for (int ch = wid; ch < C; ch += 4)
-            for (int j = lane; j < tw; j += 64) dst[ch * cstride + j] = 0.f;
-        LAV_STAMP(6);
-        return;
-    }
-    LAV_STAMP(1);
-    // Issue every global load that depends only on (p0, p1) before touching LDS, so the workgroup pays ONE memory
-    // round trip here instead of one per phase: layer-2 weights, layer-1 weights, this thread's record for the
-    // sums sweep and this lane's record for the wave's first PointNet pass.
-    constexpr int W2R = C * C / 256;
-    float w2r[W2R];
-    if (USE_MFMA) {
+    // ---- static partition: this workgroup's run of units [u0, u1) -------------------------------------
+    // The counters of a chunk of 4096 units arrive as 4 x 4 fully coalesced 16-byte loads per thread (two sets x two
+    // sub-arrays, 4 loads each), issued before anything else.  Wave w owns units [1024 w, 1024 w + 1024) of the chunk;
+    // load j of lane l covers units 1024 w + 4 (64 j + l) .. + 3, so a wave's unit order is (j, l, q).
+    constexpr int PER = 16, CH = 256 * PER;
+    constexpr unsigned NO_UNIT = 0xffffffffu;
+    auto unit_index = [&](int base, int k) { return base + 1024 * wid + 4 * (64 * (k >> 2) + lane) + (k & 3); };
+    // pk = the two sub-counters of a unit, 16 bits each (clamped: only the comparison with the bucket capacity and the
+    // price need them), or NO_UNIT
+    auto load_chunk = [&](int base, unsigned (&pk)[PER]) {
 #pragma unroll
-        for (int i = 0; i < W2R; ++i) w2r[i] = w2[tid + 256 * i];
-    }
-    float a1[2][KS1];  // layer-1 A operand: W1[2s+half][32*mt + l31], bias as k = K1
-    float b2v[2];
-    const int npass = (p1 - p0 + 31) >> 5;
-    if (USE_MFMA && wid < npass) {
+        for (int j = 0; j < PER / 4; ++j) {
+            const int ub = unit_index(base, 4 * j);
+            // unconditional loads from a clamped address (a load under an exec-mask branch is waited for inside its branch:
+            // serial round trips instead of one); entries of units that do not exist are masked below
+            const int o = min(ub, a.NUP - 4);
+            const int4 x0 = *reinterpret_cast<const int4 *>(cn + o);
+            const int4 x1 = *reinterpret_cast<const int4 *>(cn + a.NUP + o);
+            const int4 y0 = *reinterpret_cast<const int4 *>(cn + 2 * a.NUP + o);
+            const int4 y1 = *reinterpret_cast<const int4 *>(cn + 3 * a.NUP + o);
+            static_assert(NSUB == 2, "load_chunk reads two sub-counter arrays");
+            const int v0[4] = {x0.x + y0.x, x0.y + y0.y, x0.z + y0.z, x0.w + y0.w};
+            const int v1[4] = {x1.x + y1.x, x1.y + y1.y, x1.z + y1.z, x1.w + y1.w};
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int q = 0; q < 4; ++q)
+                pk[4 * j + q] = ub + q < nunits ? (unsigned)min(v0[q], 0xfffe) | ((unsigned)min(v1[q], 0xfffe) << 16) : NO_UNIT;
+        }
+    };
+    auto price = [&](unsigned p) { return p == NO_UNIT ? 0 : a.cost_unit + (int)(p & 0xffffu) + (int)(p >> 16); };
+    unsigned pk[PER];
+    load_chunk(0, pk);
+
+    if (blockIdx.x == 0 && tid == 0) st->epoch_rows = st->epoch_bin + 1u;   // the next call fills the other counter set
+
+    // weight fragments, once per workgroup (fragment order written by k_bin: 22 coalesced loads)
+    float a1[4][KS1], w2f[4][4][4], b2v[4];
+    if constexpr (USE_MFMA) {
+        const float4 *wp = reinterpret_cast<const float4 *>(wpack) + lane;
 #pragma unroll
-            for (int s = 0; s < KS1; ++s) {
-                const int k = 2 * s + half;
-                const int c = 32 * mt + l31;
-                a1[mt][s] = k < K1 ? w1[k * C + c] : (k == K1 ? b1[c] : 0.f);
+        for (int s = 0; s < KS1; ++s) {
+            const float4 t = wp[s * 64];
+            a1[0][s] = t.x; a1[1][s] = t.y; a1[2][s] = t.z; a1[3][s] = t.w;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 t = wp[(KS1 + 4 * ct + r) * 64];
+                w2f[ct][r][0] = t.x; w2f[ct][r][1] = t.y; w2f[ct][r][2] = t.z; w2f[ct][r][3] = t.w;
             }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b2v[nt] = b2[32 * nt + l31];
+        const float4 t = wp[(KS1 + 16) * 64];
+        b2v[0] = t.x; b2v[1] = t.y; b2v[2] = t.z; b2v[3] = t.w;
     }
-    float srec[4];  // x, y, z, key of record p0 + tid (first chunk of the sums sweep)
+    if (tid < 32) red[tid] = 0;
+    LAV_STAMP(1);
+
+    int u0, u1, wu0;
     {
-        const float *rp = rec + (long)min(p0 + tid, p1 - 1) * (D + 1);
-        srec[0] = rp[0]; srec[1] = rp[1]; srec[2] = rp[2]; srec[3] = rp[D];
-    }
-    float prec[D + 1];  // record of this lane for the wave's first pass
-    if (USE_MFMA) load_record<D>(rec, min(p0 + wid * 32 + l31, p1 - 1), prec);
-
-    for (int i = tid; i < C * TWP; i += 256) tile[i] = 0.f;
-    if (tid < MAX_LAYERS) nl[tid] = 0;
-    if (USE_MFMA) {
+        // scan of one chunk inside a wave: exclusive prefix of each of the lane's 4 runs (rex) and the wave's total
+        auto wave_prefix = [&](const unsigned (&p)[PER], int (&rex)[4]) {
+            int before = 0;
 #pragma unroll
-        for (int i = 0; i < W2R; ++i) w2s[tid + 256 * i] = w2r[i];
+            for (int j = 0; j < 4; ++j) {
+                const int rs = price(p[4 * j]) + price(p[4 * j + 1]) + price(p[4 * j + 2]) + price(p[4 * j + 3]);
+                const int inc = wave_scan64(rs);
+                rex[j] = before + inc - rs;
+                before += __builtin_amdgcn_readlane(inc, 63);
+            }
+            return before;
+        };
+        // units of a chunk whose prefix is below lo / hi
+        auto count_below = [&](int base, const unsigned (&p)[PER], const int (&rex)[4], unsigned before, unsigned lo, unsigned hi,
+                               int &c_lo, int &c_hi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned run = before + (unsigned)rex[j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (p[4 * j + q] != NO_UNIT) {
+                        c_lo += run < lo;
+                        c_hi += run < hi;
+                        run += (unsigned)price(p[4 * j + q]);
+                    }
+            }
+        };
+        int rex[4];
+        const int wtot = wave_prefix(pk, rex);
+        int tsum = wtot;
+        for (int base = CH; base < nunits; base += CH) {   // several chunks (several clouds): the grand total first
+            unsigned p2[PER];
+            int r2[4];
+            load_chunk(base, p2);
+            tsum += wave_prefix(p2, r2);
+        }
+        barrier_lds();   // red[] zeroed
+        if (lane == 0) {
+            red[wid] = wtot;
+            red[4 + wid] = tsum;
+        }
+        barrier_lds();
+        const unsigned total = (unsigned)(red[4] + red[5] + red[6] + red[7]);
+        // share of workgroup w = [lo(w), lo(w+1)),  lo(w) = w q + min(w, rem): lo(0) = 0, lo(W) = total
+        const unsigned W = gridDim.x, qq = total / W, rem = total - qq * W;
+        const unsigned lo = blockIdx.x * qq + min(blockIdx.x, rem), hi = (blockIdx.x + 1) * qq + min(blockIdx.x + 1, rem);
+        int c_lo = 0, c_hi = 0;
+        unsigned before = 0;
+        for (int base = 0; base < nunits; base += CH) {
+            if (base > 0) {   // (rare) the next chunk: its wave totals go through red[0..3] again
+                load_chunk(base, pk);
+                const int wt = wave_prefix(pk, rex);
+                barrier_lds();
+                if (lane == 0) red[wid] = wt;
+                barrier_lds();
+            }
+            unsigned mine = before;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w < wid) mine += (unsigned)red[w];
+                before += (unsigned)red[w];
+            }
+            count_below(base, pk, rex, mine, lo, hi, c_lo, c_hi);
+        }
+        // one LDS atomic per wave: same-address atomics of a wave are served lane by lane
+        c_lo = wave_scan64(c_lo);
+        c_hi = wave_scan64(c_hi);
+        if (lane == 63) {
+            atomicAdd(&red[8], c_lo);
+            atomicAdd(&red[9], c_hi);
+        }
+        barrier_lds();
+        u0 = red[8];
+        u1 = red[9];
+        // first window of unit counters: straight from the registers that hold them
+        wu0 = u0;
+        if (nunits <= CH) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int u = unit_index(0, k);
+                if (u >= u0 && u < min(u1, u0 + WIN)) {
+                    win[0][u - u0] = (int)(pk[k] & 0xffffu);
+                    win[1][u - u0] = (int)(pk[k] >> 16);
+                }
+            }
+        } else if (tid < NSUB * WIN) {
+            const int sb = tid / WIN, i = tid - sb * WIN;
+            win[sb][i] = wu0 + i < u1 ? cn[sb * a.NUP + wu0 + i] + cn[(NSUB + sb) * a.NUP + wu0 + i] : 0;
+        }
+        barrier_lds();
     }
-
-    // key rows that land on canvas row r, and overflow columns of the last tile (reference clamp, :89)
-    const int xi_lo = r > 0 ? a.ny - 1 - r : max(a.ny - 1, 0);
-    const int xi_hi = r > 0 ? xi_lo : a.nx;
-    const int n_over = (c1 == a.nx) ? max(0, a.ny - a.nx + 1) : 0;
-    const int nlay_y = n_over + 1;
-    const int nlayers = (xi_hi - xi_lo + 1) * nlay_y;
-    const int cellbase = b * a.KX * a.KY;
-    // record -> (layer, tile column, xi, yi).  Layers are ordered like the reference's sorted unique rows.
-    auto classify = [&](int k, int &layer, int &col, int &xi, int &yi) {
-        const int cellk = k - cellbase;
-        xi = cellk / a.KY;
-        yi = cellk - xi * a.KY;
-        const int over = yi >= a.nx ? yi - a.nx + 1 : 0;
-        layer = (xi - xi_lo) * nlay_y + over;
-        col = min(yi, a.nx - 1) - c0;
+    LAV_STAMP(2);
+    if constexpr (TRACE) { if (tid == 0) { a.trace[(long)blockIdx.x * 16 + 14] = (unsigned long long)(u1 - u0); a.trace[(long)blockIdx.x * 16 + 15] = 0; } }
+    if (u0 >= u1) return;
+    auto load_window = [&]() {
+        if (tid < NSUB * WIN) {
+            const int sb = tid / WIN, i = tid - sb * WIN;
+            win[sb][i] = wu0 + i < u1 ? cn[sb * a.NUP + wu0 + i] + cn[(NSUB + sb) * a.NUP + wu0 + i] : 0;
+        }
     };
 
-    for (int L = 0; L < min(nlayers, MAX_LAYERS); ++L) {
-        if (L > 0 && nl[L] == 0) continue;  // workgroup-uniform; nl[] is complete after layer 0's first barrier pair
-        __syncthreads();
-        for (int j = tid; j < TW * 3; j += 256) sums[j] = 0ull;
-        for (int j = tid; j < TW; j += 256) cnt[j] = 0;
-        __syncthreads();
-        if (L == 0) LAV_STAMP(2);
-        // (a) per-cell coordinate sums and counts of this layer (first 256 records were prefetched)
-        for (int j = p0 + tid; j < p1; j += 256) {
-            float x, y, z;
-            int k;
-            if (j == p0 + tid) {
-                x = srec[0]; y = srec[1]; z = srec[2]; k = __float_as_int(srec[3]);
-            } else {
-                const float *rp = rec + (long)j * (D + 1);
-                x = rp[0]; y = rp[1]; z = rp[2]; k = __float_as_int(rp[D]);
-            }
-            int layer, col, xi, yi;
-            classify(k, layer, col, xi, yi);
-            if (L == 0 && layer != 0) atomicAdd(&nl[min(layer, MAX_LAYERS - 1)], 1);
-            if (layer == L) {
-                const float xyz[3] = {x, y, z};
+    // Every wave keeps its own copy of a group's bucket prefix in LDS (written and read by the same wave: the LDS
+    // queue of a wave is in order, so no barrier is involved and groups without points need none either).
+    auto describe = [&](int u, int slot) {  // u must lie inside the window
+        Group g;
+        g.u = u;
+        g.slot = slot;
+        g.ue = min(u1, u + GMAX);
+        const int k = lane / NSUB, sb = lane % NSUB;
+        const int c = (lane < NBKT && u + k < g.ue && u + k - wu0 < WIN) ? win[sb][u + k - wu0] : 0;
+        g.has_ovf = __ballot(c > a.cap) != 0ull;
+        g.mask = (unsigned)__ballot(c > 0);
+        const int cc = min(c, a.cap);
+        const int inc = row_scan16(cc);
+        static_assert(NBKT == 16, "one DPP row of 16 lanes scans the buckets of a group");
+        if (lane < NBKT) gpre[wid][slot][lane] = inc - cc;   // exclusive
+        if (lane == NBKT - 1) gpre[wid][slot][NBKT] = inc;   // total
+        g.n = __builtin_amdgcn_readlane(inc, NBKT - 1);
+        return g;
+    };
+    // address of record i (< g.n) of a group
+    auto rec_ptr = [&](const Group &g, int i) {
+        const int4 *pp = reinterpret_cast<const int4 *>(gpre[wid][g.slot]);
+        const int4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+        const int q = (i >= p0.y) + (i >= p0.z) + (i >= p0.w) + (i >= p1.x) + (i >= p1.y) + (i >= p1.z) + (i >= p1.w) + (i >= p2.x) +
+                      (i >= p2.y) + (i >= p2.z) + (i >= p2.w) + (i >= p3.x) + (i >= p3.y) + (i >= p3.z) + (i >= p3.w);
+        return buckets + (((size_t)g.u * NSUB + q) * a.cap + (i - gpre[wid][g.slot][q])) * RS;
+    };
+    auto load_rec = [&](const float *p, float4 (&r)[RQ]) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const long long q = __double2ll_rn((double)xyz[d] * FIX_SCALE);
-                    atomicAdd(&sums[col * 3 + d], (unsigned long long)q);
-                }
-                atomicAdd(&cnt[col], 1);
-            }
-        }
-        __syncthreads();
-        for (int j = tid; j < tw; j += 256) {
-            const int n = cnt[j];
-            if (n > 0) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    means[j * 3 + d] = (float)((double)(long long)sums[j * 3 + d] / ((double)n * FIX_SCALE));
-            }
-        }
-        if (L > 0) {  // a later pillar replaces whatever an earlier one put on the same canvas cell
-            for (int i = tid; i < C * tw; i += 256) {
-                const int ch = i / tw, j = i - ch * tw;
-                if (cnt[j] > 0) tile[ch * TWP + j] = 0.f;
-            }
-        }
-        __syncthreads();
-        if (L == 0) LAV_STAMP(3);
+        for (int q = 0; q < RQ; ++q) r[q] = reinterpret_cast<const float4 *>(p)[q];
+    };
 
-        if constexpr (!USE_MFMA) {
-            // cross-check path: one point per thread, plain fp32 FMAs (slow; selected by LAV_PILLAR_IMPL=valu)
-            for (int j = p0 + tid; j < p1; j += 256) {
-                float v[D + 1];
-                load_record<D>(rec, j, v);
-                int layer, col, xi, yi;
-                classify(__float_as_int(v[D]), layer, col, xi, yi);
-                if (layer != L) continue;
-                float f[K1];
-                decorate<D>(a, v, means + col * 3, xi, yi, f);
-                float h1[C];
+    // The next job record of this wave: the next job of the current group, or - requested while the last job of a
+    // group is on the matrix cores - the wave's first job of the following group.
+    float4 nxt[RQ];
+    // A group of one job is split four ways over the waves (each runs layer 1 and one 16-channel slice of layer 2:
+    // 36 instead of 84 matrix instructions in the group's critical path), a group of two jobs two ways.
+    auto split_shift = [&](const Group &gg) {
+        const int ja = (gg.n + 15) >> 4;
+        return gg.has_ovf ? 0 : (ja == 1 ? 2 : (ja == 2 ? 1 : 0));
+    };
+    auto request_first_job = [&](const Group &gg, int rot_) {
+        if (gg.n > 0) load_rec(rec_ptr(gg, min(16 * (((wid - rot_) & 3) >> split_shift(gg)) + lp, gg.n - 1)), nxt);
+    };
+
+    int gi = 0;
+    Group g = describe(u0, 0);
+    request_first_job(g, 0);
+    // LDS state every group starts from: sums, counts, layer counts and markers zero.  The tile itself is NOT cleared:
+    // only the quads of columns that points touch are zeroed (after the sums sweep) and read back.
+    for (int i = tid; i < GW * 3; i += 256) sums[i] = 0ull;
+    if (tid < GW) cnt[tid] = 0;
+    if (tid < MAX_LAYERS) nl[tid] = 0;
+    if (tid < GW / 4) { occ4[tid] = 0; newq[tid] = 0; }
+    barrier_lds();
+    const long cstride = (long)a.ny * a.nx;
+    const int xi_row0 = max(a.ny - 1, 0);                       // first key row that lands on canvas row 0
+    const int nlay_over = max(0, a.ny - a.nx + 1) + 1;          // layers of a unit that holds the last canvas column
+    const int nlay_max = min(MAX_LAYERS, max(a.nx - xi_row0 + 1, 1) * nlay_over);
+
+    while (true) {
+        const int rot = gi & 3;
+        const int gn = g.ue - g.u;   // units of the group; its tile column of (unit k, column c of the unit) is 32 k + c
+        // what comes after this group (workgroup-uniform); its records are requested while this one computes
+        const bool more = g.ue < u1;
+        if (gi == 0) LAV_STAMP(3);
+        if (gi == 1) LAV_STAMP(11);
+        if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + 15] += (unsigned long long)g.n; }
+        const bool next_in_window = more && g.ue + GMAX <= wu0 + WIN;
+        bool prefetched = false;
+        auto prefetch_next = [&]() {
+            if (next_in_window && !prefetched) request_first_job(describe(g.ue, g.slot ^ 1), (gi + 1) & 3);
+            prefetched = true;
+        };
+        // Streams units of the group to the canvas [B][C][ny][nx]: zeros from registers (FROM_LDS false) for the units
+        // without points, the tile for the others.  A unit is one 128-byte line of every channel plane (less at the right
+        // border); the walk over the units needs one division per group.
+        auto store_units = [&](auto FROM_LDS_) {
+            constexpr bool FROM_LDS = decltype(FROM_LDS_)::value;
+            int rb = g.u / a.UPR, cu = g.u - rb * a.UPR;
+            int b = rb / a.ny, r = rb - b * a.ny;
+            const int j4 = tid & 7, ch0 = tid >> 3;
+            int flags = 0;   // bit k: quad (unit k, j4) holds data in the tile
+            if constexpr (FROM_LDS && VEC4) {
+                int f[GMAX];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float acc = b1[c];
+                for (int k = 0; k < GMAX; ++k) f[k] = occ4[k * (UW / 4) + j4];
 #pragma unroll
-                    for (int k = 0; k < K1; ++k) acc = fmaf(f[k], w1[k * C + c], acc);
-                    h1[c] = acc > 0.f ? acc : 0.f;
+                for (int k = 0; k < GMAX; ++k) flags |= (f[k] == gi + 1) << k;
+            }
+            for (int k = 0; k < gn; ++k) {
+                const bool has = ((g.mask >> (NSUB * k)) & ((1u << NSUB) - 1)) != 0;
+                if (has == FROM_LDS) {
+                    const int c0 = cu * UW, w = min(a.nx, c0 + UW) - c0;
+                    float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
+                    if constexpr (VEC4) {
+                        float4 val[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+                        if constexpr (FROM_LDS) {
+                            if ((flags >> k) & 1) {   // quads no point of this group touched hold garbage in LDS and zeros on the canvas
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) val[h] = *reinterpret_cast<const float4 *>(tile + (ch0 + 32 * h) * TS + k * UW + 4 * j4);
+                            }
+                        }
+                        if (4 * j4 < w) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                __builtin_nontemporal_store(f32x4{val[h].x, val[h].y, val[h].z, val[h].w},
+                                                            reinterpret_cast<f32x4 *>(dst + (ch0 + 32 * h) * cstride + 4 * j4));
+                        }
+                    } else {
+                        for (int idx = tid; idx < C * w; idx += 256) {
+                            const int ch = idx / w, j = idx - ch * w;
+                            float val = 0.f;
+                            if constexpr (FROM_LDS) {
+                                if (occ4[(k * UW + j) >> 2] == gi + 1) val = tile[ch * TS + k * UW + j];
+                            }
+                            dst[ch * cstride + j] = val;
+                        }
+                    }
                 }
-                for (int c = 0; c < C; ++c) {
-                    float acc = b2[c];
-#pragma unroll
-                    for (int k = 0; k < C; ++k) acc = fmaf(h1[k], w2[k * C + c], acc);
-                    const float o = acc > 0.f ? acc : 0.f;
-                    atomicMax(reinterpret_cast<unsigned *>(&tile[c * TWP + col]), __float_as_uint(o));
+                if (++cu == a.UPR) {
+                    cu = 0;
+                    if (++r == a.ny) { r = 0; ++b; }
                 }
             }
+        };
+        using std::false_type;
+        using std::true_type;
+
+        if (g.n == 0 && !g.has_ovf) {
+            prefetch_next();
+            store_units(false_type{});   // no point lands here: zeros straight from registers
         } else {
-            for (int pass = wid; pass < npass; pass += 4) {
-                const int j = p0 + pass * 32 + l31;
-                bool live = j < p1;
-                float v[D + 1];
-                if (pass == wid) {
-#pragma unroll
-                    for (int d = 0; d <= D; ++d) v[d] = prec[d];
-                } else {
-                    load_record<D>(rec, live ? j : p0, v);
+            // units of the group without points: their zeros leave while the records of the others are still in flight
+            store_units(false_type{});
+            if (gi == 0) LAV_STAMP(5);
+            // packed cell -> (layer, tile column, xi, yi, member of this group).  Layers order the pillars that the
+            // reference's clamp (:89) sends to one canvas cell like its sorted unique rows: later layers replace earlier.
+            auto classify = [&](int packed, int &layer, int &col, int &xi, int &yi) {
+                xi = (packed >> 12) & 0xfff;
+                yi = packed & 0xfff;
+                const int r_ = min(max(a.ny - 1 - xi, 0), a.ny - 1);
+                const int colc = min(yi, a.nx - 1), cu_ = colc / UW;
+                const int k = ((packed >> 24) * a.ny + r_) * a.UPR + cu_ - g.u;
+                col = k * UW + (colc - cu_ * UW);
+                const int over = yi >= a.nx ? yi - a.nx + 1 : 0;
+                layer = (r_ > 0 ? 0 : xi - xi_row0) * (cu_ == a.UPR - 1 ? nlay_over : 1) + over;
+                return (unsigned)k < (unsigned)gn;
+            };
+            const int n_ovf = g.has_ovf ? st->n_ovf[0] + st->n_ovf[1] : 0;   // (one of the two is zero, like the counters)
+            const int JA = (g.n + 15) >> 4;
+            const int JB = (n_ovf + 15) >> 4;
+            const int J = JA + JB;
+            const int sh = split_shift(g), VJ = J << sh;   // virtual jobs = (job, slice of the output channels)
+            const int v0 = (wid - rot) & 3;                // this wave's first virtual job
+
+            for (int L = 0; L < nlay_max; ++L) {
+                if (L > 0) {
+                    if (nl[L] == 0) continue;  // workgroup-uniform; nl[] is complete after layer 0's sums sweep
+                    barrier_lds();
+                    for (int j = tid; j < GW * 3; j += 256) sums[j] = 0ull;
+                    if (tid < GW) cnt[tid] = 0;
+                    barrier_lds();
                 }
-                int layer, col, xi, yi;
-                classify(__float_as_int(v[D]), layer, col, xi, yi);
-                live = live && layer == L;
-                const int mycol = live ? col : -1;
-                float f[K1];
-                decorate<D>(a, v, means + (live ? col : 0) * 3, xi, yi, f);
-                float fe[KS1];
+                // (a) per-cell coordinate sums and counts of this layer.  `part` = which of the four atomics of a point
+                // this lane issues (0-2 = x, y, z sums, 3 = count and markers), or -1 = all of them.
+                auto add_point = [&](float x, float y, float z, int packed, bool member_known, int part) {
+                    int layer, col, xi, yi;
+                    const bool member = classify(packed, layer, col, xi, yi);
+                    if (!member_known && !member) return;
+                    if ((part < 0 || part == 3) && L == 0 && layer != 0) atomicAdd(&nl[min(layer, MAX_LAYERS - 1)], 1);
+                    if (layer == L) {
+                        const float xyz[3] = {x, y, z};
 #pragma unroll
-                for (int s = 0; s < KS1; ++s) {
-                    const float ev = 2 * s < K1 ? f[2 * s < K1 ? 2 * s : 0] : (2 * s == K1 ? 1.f : 0.f);
-                    const float od = 2 * s + 1 < K1 ? f[2 * s + 1 < K1 ? 2 * s + 1 : 0] : (2 * s + 1 == K1 ? 1.f : 0.f);
-                    fe[s] = live ? (half ? od : ev) : 0.f;
-                }
-                // layer 1
-                f32x16 d1[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) d1[mt][q] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < KS1; ++s) d1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][s], fe[s], d1[mt], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) d1[mt][q] = d1[mt][q] > 0.f ? d1[mt][q] : 0.f;
-                }
-                // after layer 2 this lane holds channel c2 of the 16 points in MFMA rows (q&3)+8*(q>>2)+4*half;
-                // their tile columns come from the lanes that loaded them
-                int cols[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) cols[q] = __shfl(mycol, (q & 3) + 8 * (q >> 2) + 4 * half, 64);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    f32x16 d2;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) d2[q] = b2v[nt];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int rr = 0; rr < 16; ++rr) {
-                            // B operand: W2[k][32*nt + l31] with k = 32*mt + (rr&3) + 8*(rr>>2) + 4*half
-                            const float wv = w2s[(32 * mt + (rr & 3) + 8 * (rr >> 2) + 4 * half) * C + 32 * nt + l31];
-                            d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[mt][rr], wv, d2, 0, 0, 0);
+                        for (int d = 0; d < 3; ++d)
+                            if (part < 0 || part == d) {
+                                const long long q = __double2ll_rn((double)xyz[d] * FIX_SCALE);
+                                atomicAdd(&sums[col * 3 + d], (unsigned long long)q);
+                            }
+                        if (part < 0 || part == 3) {
+                            atomicAdd(&cnt[col], 1);
+                            if (occ4[col >> 2] != gi + 1) {   // (benign race: every racer writes the same values)
+                                occ4[col >> 2] = gi + 1;
+                                newq[col >> 2] = 1;
+                            }
                         }
-                    unsigned *trow = reinterpret_cast<unsigned *>(tile + (32 * nt + l31) * TWP);
+                    }
+                };
+                // the first 64 records are the waves' first jobs, already requested: the four lane groups hold one copy each
+                // and share the point's four atomics
+                if (L == 0 && (v0 & ((1 << sh) - 1)) == 0 && 16 * (v0 >> sh) + lp < g.n)
+                    add_point(nxt[0].x, nxt[0].y, nxt[0].z, __float_as_int(nxt[RQ - 1].w), true, lg);
+                for (int i = (L == 0 ? 64 : 0) + tid; i < g.n; i += 256) {
+                    const float *p = rec_ptr(g, i);
+                    const float4 s0 = reinterpret_cast<const float4 *>(p)[0];
+                    const float4 s1 = reinterpret_cast<const float4 *>(p)[RQ - 1];
+                    add_point(s0.x, s0.y, s0.z, __float_as_int(s1.w), true, -1);
+                }
+                for (int i = tid; i < n_ovf; i += 256) {
+                    const float *p = ovf + (size_t)i * RS;
+                    const float4 s0 = reinterpret_cast<const float4 *>(p)[0];
+                    const float4 s1 = reinterpret_cast<const float4 *>(p)[RQ - 1];
+                    add_point(s0.x, s0.y, s0.z, __float_as_int(s1.w), false, -1);
+                }
+                if (gi == 0 && L == 0) LAV_STAMP(6);
+                barrier_lds();
+                if (gi == 0 && L == 0) LAV_STAMP(4);
+                {   // zero the tile columns of the quads this sweep touched first (wave w takes quads w, w + 4, ...: one 16-byte
+                    // store per channel), and - layers after the first - the cells a later pillar replaces
+                    const unsigned long long fresh = __ballot(lane < GW / 16 && newq[wid + 4 * lane] != 0);
+                    for (unsigned long long m = fresh; m; m &= m - 1) {
+                        const int q = wid + 4 * (__ffsll((long long)m) - 1);
+                        *reinterpret_cast<float4 *>(tile + lane * TS + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    if (lane < GW / 16) newq[wid + 4 * lane] = 0;
+                    if (L > 0) {
+                        barrier_lds();
+                        for (int i = tid; i < C * GW; i += 256) {
+                            const int ch = i / GW, j = i - ch * GW;
+                            if (cnt[j] > 0 && occ4[j >> 2] == gi + 1) tile[ch * TS + j] = 0.f;
+                        }
+                    }
+                    barrier_lds();
+                }
+                bool last_layer = true;
+                for (int L2 = L + 1; L2 < nlay_max; ++L2) last_layer = last_layer && nl[L2] == 0;
+
+                // decorated features of one record (decorate(), point_pillar.py:55-68)
+                auto decorated = [&](const float (&v)[RS], int col, int xi, int yi, float (&f)[K1]) {
+                    float mean[3];
+                    const int n = cnt[col];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float o = d2[q] > 0.f ? d2[q] : 0.f;  // also maps -0 and NaN to +0
-                        if (cols[q] >= 0) atomicMax(trow + cols[q], __float_as_uint(o));
+                    for (int d = 0; d < 3; ++d)
+                        mean[d] = (float)((double)(long long)sums[col * 3 + d] / ((double)n * FIX_SCALE));
+#pragma unroll
+                    for (int d = 0; d < D; ++d) f[d] = v[d];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) f[D + d] = v[d] - mean[d];
+                    // reference decorate(): x - (yi/ppm + min_x), y - (xi/ppm + min_y)  (sic: swapped, un-centred; :57-58)
+                    f[D + 3] = v[0] - ((float)yi / a.ppm + a.min_x);
+                    f[D + 4] = v[1] - ((float)xi / a.ppm + a.min_y);
+                };
+
+                if constexpr (!USE_MFMA) {
+                    // cross-check path: one point per thread, plain fp32 FMAs (slow; selected by LAV_PILLAR_IMPL=valu)
+                    if (last_layer) prefetch_next();
+                    for (int i = tid; i < g.n + n_ovf; i += 256) {
+                        float4 rq[RQ];
+                        load_rec(i < g.n ? rec_ptr(g, i) : ovf + (size_t)(i - g.n) * RS, rq);
+                        float v[RS];
+#pragma unroll
+                        for (int q = 0; q < RQ; ++q) { v[4 * q] = rq[q].x; v[4 * q + 1] = rq[q].y; v[4 * q + 2] = rq[q].z; v[4 * q + 3] = rq[q].w; }
+                        int layer, col, xi, yi;
+                        const bool member = classify(__float_as_int(v[RS - 1]), layer, col, xi, yi);
+                        if (!member || layer != L) continue;
+                        float f[K1];
+                        decorated(v, col, xi, yi, f);
+                        float h1[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            float acc = b1[c];
+#pragma unroll
+                            for (int k = 0; k < K1; ++k) acc = fmaf(f[k], w1[k * C + c], acc);
+                            h1[c] = acc > 0.f ? acc : 0.f;
+                        }
+                        for (int c = 0; c < C; ++c) {
+                            float acc = b2[c];
+#pragma unroll
+                            for (int k = 0; k < C; ++k) acc = fmaf(h1[k], w2[k * C + c], acc);
+                            const float o = acc > 0.f ? acc : 0.f;
+                            atomicMax(reinterpret_cast<unsigned *>(&tile[c * TS + col]), __float_as_uint(o));
+                        }
+                    }
+                } else {
+                    // (b) jobs of 16 records; virtual job v runs on wave (v + rot) & 3
+                    auto job_ptr = [&](int j) {
+                        return j < JA ? rec_ptr(g, min(16 * j + lp, g.n - 1)) : ovf + (size_t)min(16 * (j - JA) + lp, n_ovf - 1) * RS;
+                    };
+                    int v = v0;
+                    float4 cur[RQ];
+                    if (v < VJ) {
+                        if ((v >> sh) < JA && L == 0) {
+#pragma unroll
+                            for (int q = 0; q < RQ; ++q) cur[q] = nxt[q];
+                        } else {
+                            load_rec(job_ptr(v >> sh), cur);
+                        }
+                    } else if (last_layer) {
+                        prefetch_next();
+                    }
+                    for (; v < VJ; v += 4) {
+                        const int j = v >> sh, part = v & ((1 << sh) - 1);
+                        // the next record of this wave (next job of the group, or first job of the next group) is requested
+                        // once this job's matrix instructions are queued: the request's own LDS latency then overlaps them
+                        auto request_next = [&]() {
+                            if (v + 4 < VJ) load_rec(job_ptr((v + 4) >> sh), nxt);
+                            else if (last_layer) prefetch_next();
+                        };
+                        float v_[RS];
+#pragma unroll
+                        for (int q = 0; q < RQ; ++q) { v_[4 * q] = cur[q].x; v_[4 * q + 1] = cur[q].y; v_[4 * q + 2] = cur[q].z; v_[4 * q + 3] = cur[q].w; }
+                        const int i = j < JA ? 16 * j + lp : 16 * (j - JA) + lp;
+                        bool live = i < (j < JA ? g.n : n_ovf);
+                        int layer, col, xi, yi;
+                        const bool member = classify(__float_as_int(v_[RS - 1]), layer, col, xi, yi);
+                        live = live && member && layer == L;
+                        if (__ballot(live) != 0ull) {
+                            const int mycol = live ? col : -1;
+                            float f[K1];
+                            decorated(v_, live ? col : 0, xi, yi, f);
+                            float fe[KS1];
+#pragma unroll
+                            for (int s = 0; s < KS1; ++s) {
+                                float t[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int k = 4 * s + q;
+                                    t[q] = k < K1 ? f[k < K1 ? k : 0] : (k == K1 ? 1.f : 0.f);
+                                }
+                                const float lo = (lg & 1) ? t[1] : t[0], hi = (lg & 1) ? t[3] : t[2];
+                                fe[s] = live ? ((lg & 2) ? hi : lo) : 0.f;
+                            }
+                            // layer 1
+                            f32x4 d1[4];
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) d1[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int s = 0; s < KS1; ++s)
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct) d1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ct][s], fe[s], d1[ct], 0, 0, 0);
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) d1[ct][q] = d1[ct][q] > 0.f ? d1[ct][q] : 0.f;
+                            if (gi == 0 && v == v0) LAV_STAMP(7);
+                            // the tile columns of the 4 points this lane gets results for come from the lanes that loaded them
+                            int cols[4];
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) cols[rr] = __shfl(mycol, 4 * lg + rr, 64);
+                            // layer 2 for output channels 16*LO .. 16*(LO+CNT): this lane ends up with channel 16*ct2 + lp of
+                            // points 4*lg + r; every accumulator is one chain in the same k order whatever the split, so a
+                            // point's features do not depend on how many neighbours its group has.  (c) max into the tile.
+                            auto layer2 = [&](auto LO_, auto CNT_) {
+                                constexpr int LO = decltype(LO_)::value, CNT = decltype(CNT_)::value;
+                                f32x4 d2[CNT];
+#pragma unroll
+                                for (int c = 0; c < CNT; ++c) d2[c] = f32x4{b2v[LO + c], b2v[LO + c], b2v[LO + c], b2v[LO + c]};
+#pragma unroll
+                                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                                        for (int c = 0; c < CNT; ++c)
+                                            d2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[ct][rr], w2f[ct][rr][LO + c], d2[c], 0, 0, 0);
+                                request_next();
+#pragma unroll
+                                for (int c = 0; c < CNT; ++c) {
+                                    unsigned *trow = reinterpret_cast<unsigned *>(tile + (16 * (LO + c) + lp) * TS);
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr) {
+                                        const float o = d2[c][rr] > 0.f ? d2[c][rr] : 0.f;  // also maps -0 and NaN to +0
+                                        if (cols[rr] >= 0) atomicMax(trow + cols[rr], __float_as_uint(o));
+                                    }
+                                }
+                            };
+                            using std::integral_constant;
+                            if (sh == 0) {
+                                layer2(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+                            } else if (sh == 1) {
+                                if (part == 0) layer2(integral_constant<int, 0>{}, integral_constant<int, 2>{});
+                                else layer2(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+                            } else {
+                                if (part == 0) layer2(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+                                else if (part == 1) layer2(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+                                else if (part == 2) layer2(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+                                else layer2(integral_constant<int, 3>{}, integral_constant<int, 1>{});
+                            }
+                            if (gi == 0 && v == v0) LAV_STAMP(8);
+                        } else {
+                            request_next();
+                        }
+#pragma unroll
+                        for (int q = 0; q < RQ; ++q) cur[q] = nxt[q];
                     }
                 }
             }
+            prefetch_next();   // (no-op when a wave already did it)
+            barrier_lds();
+            if (gi == 0) LAV_STAMP(9);
+            // (d) stream the units that hold points out of the tile
+            store_units(true_type{});
+            for (int i = tid; i < GW * 3; i += 256) sums[i] = 0ull;
+            if (tid < GW) cnt[tid] = 0;
+            if (tid < MAX_LAYERS) nl[tid] = 0;
+            barrier_lds();
+        }
+
+        if (gi == 0) LAV_STAMP(10);
+        if (!more) break;
+        ++gi;
+        if (next_in_window) {
+            g = describe(g.ue, g.slot ^ 1);
+        } else {   // the counter window is used up: move it (rare: a run longer than WIN units)
+            barrier_lds();
+            wu0 = g.ue;
+            load_window();
+            barrier_lds();
+            g = describe(wu0, 0);
+            request_first_job(g, gi & 3);
         }
     }
-    LAV_STAMP(4);
-    __syncthreads();
-    LAV_STAMP(5);
-    // (d) stream the tile out; canvas [B][C][ny][nx]
-#pragma unroll 4
-    for (int ch = wid; ch < C; ch += 4) {
-        const float *src = tile + ch * TWP;
-        float *d = dst + ch * cstride;
-        for (int j = lane; j < tw; j += 64) d[j] = src[j];
-    }
-    LAV_STAMP(6);
+    LAV_STAMP(12);
+    if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + 13] = (unsigned long long)(clock64() - cyc0); }
 #undef LAV_STAMP
 }
 
@@ -617,46 +968,52 @@ __global__ void k_counts(const int *p_total, const int *kept_total, int *counts)
     counts[1] = *kept_total;
 }
 
-void tile_geometry(int nx, int &T, int &TW) {
-    static const int max_w = [] {  // experiment knob: LAV_PILLAR_TW=<columns per tile>
-        const char *e = getenv("LAV_PILLAR_TW");
-        const int v = e ? atoi(e) : 0;
-        return v >= 4 && v <= 320 ? v : TILE_MAX_W;
-    }();
-    T = (nx + max_w - 1) / max_w;
-    const int tw = (nx + T - 1) / T;
-    TW = (tw + 3) / 4 * 4;
-}
 
 struct Workspace {
-    int *tile_count, *tile_offset, *key, *slot;
-    int4 *tile_order;
-    int *tile_tmp;
-    float *rec;
+    State *state;      // zero at rest
+    int *counters;     // [2 sets][NSUB][nunits rounded up to 4], zero at rest
+    int *key;
+    float *buckets;    // [nunits][NSUB][cap] records
+    float *ovf;        // [batch * max_points] records (overflow list)
+    float *wpack;      // PointNet weights in fragment order, rewritten by every call
     int *cell_count, *cell_rank, *kept_rank, *block_sums, *totals;
     unsigned long long *cell_sums;  // [min(ncells, points)][3] fixed-point coordinate sums (training entry lav_pillar_decorate)
+    int cap, upr;
 };
 
-size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid *g) {
-    int T, TW;
-    tile_geometry(g->nx, T, TW);
-    const size_t ntiles = (size_t)batch * g->ny * T;
+int bucket_capacity(int max_points, int units_per_cloud) {
+    // room for 8x the mean load of a (unit, sub) bucket: the densest unit of a LiDAR-like cloud (the ego vehicle's
+    // surroundings) holds about 20x the mean of a unit, spread over NSUB buckets
+    const long want = 8l * max_points / ((long)units_per_cloud * NSUB) + 1;
+    int cap = CAP_MIN;
+    while (cap < want && cap < CAP_MAX) cap *= 2;
+    return cap;
+}
+
+size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid *g, bool with_buckets) {
+    const int upr = (g->nx + UW - 1) / UW;
+    const size_t nunits = (size_t)batch * g->ny * upr;
     const size_t ncells = (size_t)batch * (g->nx + 1) * (g->ny + 1);
     const size_t total = (size_t)batch * max_points;
     const size_t nmax = ncells > total ? ncells : total;
-    w.tile_count = ar.take<int>(ntiles * NSUB + 1);
-    w.tile_offset = ar.take<int>(ntiles * NSUB + 1);
-    w.tile_order = ar.take<int4>(ntiles);
-    w.tile_tmp = ar.take<int>(2 * ntiles);
+    w.upr = upr;
+    w.cap = bucket_capacity(max_points, g->ny * upr);
+    w.state = ar.take<State>(1);
+    w.counters = ar.take<int>(2 * NSUB * align_up(nunits, 4));
+    w.wpack = ar.take<float>(packed_weight_floats(15));
     w.key = ar.take<int>(total);
-    w.slot = ar.take<int>(total);
-    w.rec = ar.take<float>(total * REC_MAX);
     w.cell_count = ar.take<int>(ncells);
     w.cell_rank = ar.take<int>(ncells + 1);
     w.kept_rank = ar.take<int>(total + 1);
     w.block_sums = ar.take<int>((nmax + SCAN_TILE - 1) / SCAN_TILE + 1);
     w.totals = ar.take<int>(4);
     w.cell_sums = ar.take<unsigned long long>((ncells < total ? ncells : total) * 3 + 3);
+    if (with_buckets) {
+        w.buckets = ar.take<float>(nunits * NSUB * w.cap * 12);
+        w.ovf = ar.take<float>(total * 12 + 12);
+    } else {
+        w.buckets = w.ovf = nullptr;
+    }
     return align_up(ar.used, 256);
 }
 
@@ -665,93 +1022,120 @@ bool use_valu_impl() {
     return e && e[0] == 'v';
 }
 
-// debug: per-workgroup phase times of one k_tile_pointnet launch (100 MHz wall clock -> us)
-void dump_trace(const unsigned long long *d_trace, int ntiles, hipStream_t st) {
-    std::vector<unsigned long long> h((size_t)ntiles * 8);
+int persistent_workgroups() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        const char *e = getenv("LAV_PILLAR_WG_PER_CU");  // experiment knob
+        const int per = e ? atoi(e) : 2;
+        return cus * (per >= 1 && per <= 2 ? per : 2);
+    }();
+    return n;
+}
+
+// debug: per-workgroup phase times of one k_rows launch (100 MHz wall clock -> us)
+void dump_trace(const unsigned long long *d_trace, int nwg, hipStream_t st) {
+    std::vector<unsigned long long> h((size_t)nwg * 16);
     if (hipStreamSynchronize(st) != hipSuccess) return;
     if (hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
     unsigned long long t0 = ~0ull, tend = 0;
-    for (int i = 0; i < ntiles; ++i) { t0 = std::min(t0, h[i * 8]); tend = std::max(tend, h[i * 8 + 6]); }
-    auto us = [&](unsigned long long t) { return (double)(t - t0) / 100.0; };
-    fprintf(stderr, "[pillar trace] %d tiles, span %.1f us\n", ntiles, us(tend));
-    int nempty = 0; double e_start = 0, e_dur = 0, e_last = 0;
-    double ph[6] = {0, 0, 0, 0, 0, 0}, n_start_max = 0, n_end_max = 0; int nn = 0;
-    struct Row { double start, end; unsigned long long n; double p[6]; };
-    std::vector<Row> rows;
-    for (int i = 0; i < ntiles; ++i) {
-        const unsigned long long *r = &h[i * 8];
-        if (r[7] == 0) { ++nempty; e_start += us(r[0]); e_dur += (double)(r[6] - r[0]) / 100.0; e_last = std::max(e_last, us(r[6])); continue; }
-        Row w; w.start = us(r[0]); w.end = us(r[6]); w.n = r[7];
-        for (int k = 0; k < 6; ++k) { w.p[k] = (double)(r[k + 1] - r[k]) / 100.0; ph[k] += w.p[k]; }
-        n_start_max = std::max(n_start_max, w.start); n_end_max = std::max(n_end_max, w.end); ++nn; rows.push_back(w);
+    for (int i = 0; i < nwg; ++i) { t0 = std::min(t0, h[i * 16]); tend = std::max(tend, h[i * 16 + 12]); }
+    auto us = [&](unsigned long long t) { return t ? (double)(t - t0) / 100.0 : -1.0; };
+    fprintf(stderr, "[pillar trace] %d workgroups, span %.1f us\n", nwg, us(tend));
+    double acc[13] = {0}; int cntv[13] = {0};
+    for (int i = 0; i < nwg; ++i)
+        for (int k = 0; k < 13; ++k) if (h[i * 16 + k]) { acc[k] += us(h[i * 16 + k]); ++cntv[k]; }
+    const char *nm[13] = {"start", "prologue issued", "partition", "g0 start", "g0 sums", "g0 empties out", "g0 sweep", "j0 layer1", "j0 layer2+max", "g0 jobs", "g0 out", "g1 start", "end"};
+    for (int k = 0; k < 13; ++k) fprintf(stderr, "  mean %-15s %7.2f us (%d wgs)\n", nm[k], cntv[k] ? acc[k] / cntv[k] : 0.0, cntv[k]);
+    {   // shader clock: s_memtime cycles over the wall-clock span of each workgroup
+        double f = 0; int nf = 0;
+        for (int i = 0; i < nwg; ++i) if (h[i * 16 + 12] > h[i * 16]) { f += (double)h[i * 16 + 13] / ((double)(h[i * 16 + 12] - h[i * 16]) / 100.0); ++nf; }
+        fprintf(stderr, "  mean shader clock %.0f MHz\n", nf ? f / nf : 0.0);
     }
-    fprintf(stderr, "  empty tiles %d: mean start %.1f us, mean duration %.2f us, last end %.1f us\n", nempty, nempty ? e_start / nempty : 0, nempty ? e_dur / nempty : 0, e_last);
-    fprintf(stderr, "  tiles with points %d: last start %.1f us, last end %.1f us; mean phase us: offsets %.2f | prefetch+init %.2f | sums+means %.2f | pointnet %.2f | barrier %.2f | stream-out issue %.2f\n",
-            nn, n_start_max, n_end_max, ph[0] / std::max(nn, 1), ph[1] / std::max(nn, 1), ph[2] / std::max(nn, 1), ph[3] / std::max(nn, 1), ph[4] / std::max(nn, 1), ph[5] / std::max(nn, 1));
+    struct Row { double end; int i; };
+    std::vector<Row> rows;
+    for (int i = 0; i < nwg; ++i) rows.push_back({us(h[i * 16 + 12]), i});
     std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.end > y.end; });
-    for (size_t i = 0; i < std::min<size_t>(rows.size(), 8); ++i)
-        fprintf(stderr, "  late tile: n=%llu start %.1f end %.1f | %.2f %.2f %.2f %.2f %.2f %.2f\n", rows[i].n, rows[i].start, rows[i].end, rows[i].p[0], rows[i].p[1], rows[i].p[2], rows[i].p[3], rows[i].p[4], rows[i].p[5]);
-    // start-time histogram (2 us bins)
-    std::vector<int> hist(40, 0);
-    for (int i = 0; i < ntiles; ++i) hist[std::min<size_t>(39, (size_t)(us(h[i * 8]) / 2.0))]++;
-    fprintf(stderr, "  starts per 2 us:");
-    for (int i = 0; i < 40; ++i) if (hist[i]) fprintf(stderr, " [%d]=%d", i * 2, hist[i]);
-    fprintf(stderr, "\n");
+    for (size_t k = 0; k < std::min<size_t>(rows.size(), 6); ++k) {
+        const unsigned long long *r = &h[(size_t)rows[k].i * 16];
+        fprintf(stderr, "  late wg %4d: units %llu points %llu |", rows[k].i, r[14], r[15]);
+        for (int q = 0; q < 13; ++q) fprintf(stderr, " %.1f", us(r[q]));
+        fprintf(stderr, "\n");
+    }
 }
 
 template <int D>
-int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, hipStream_t st) {
+int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, bool want_keys, hipStream_t st) {
     const long total = (long)a.batch * a.max_points;
-    const int ntiles = a.batch * a.ny * a.T;
+    const int nunits = a.batch * a.ny * a.UPR;
     const int tok_prep = timer_begin("pillar_prep", st);
-    hipLaunchKernelGGL(k_zero_ints, dim3((ntiles * NSUB + 255) / 256), dim3(256), 0, st, w.tile_count, ntiles * NSUB + 1);
-    LAV_LAUNCH_CHECK();
-    if (total > 0) {
-        hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_count);
-        LAV_LAUNCH_CHECK();
-    }
-    const bool scan_lds = 2 * (size_t)ntiles * sizeof(int) <= 48 * 1024;
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), scan_lds ? 2 * (size_t)ntiles * sizeof(int) : 0, st, w.tile_count, ntiles * NSUB,
-                       w.tile_offset, w.tile_order, scan_lds ? nullptr : w.tile_tmp);
-    LAV_LAUNCH_CHECK();
-    if (total > 0) {
-        hipLaunchKernelGGL((k_tile_place<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, w.key, w.slot, w.tile_offset, w.rec);
-        LAV_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL((k_bin<D>), dim3((unsigned)std::max(1l, (total + 255) / 256)), dim3(256), 0, st, a, w.state, w.counters, w.buckets,
+                       w.ovf, want_keys ? w.key : nullptr, net->w1, net->b1, net->w2, net->b2, w.wpack);
     timer_end(tok_prep, st);
-    const int TWP = a.TW | 1;
-    const size_t lds = (((size_t)C * TWP * 4 + 15) & ~(size_t)15) + (size_t)a.TW * 3 * 8 + (size_t)a.TW * 3 * 4 +
-                       (size_t)((a.TW + 3) & ~3) * 4 + (size_t)MAX_LAYERS * 4 + (size_t)C * C * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_pointnet<D, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
-    }
+    LAV_LAUNCH_CHECK();
+    const int W = std::min(persistent_workgroups(), nunits);
+    const bool vec4 = a.nx % 4 == 0 && reinterpret_cast<uintptr_t>(canvas) % 16 == 0;
     static const bool want_trace = getenv("LAV_PILLAR_TRACE") != nullptr;
     static unsigned long long *d_trace = nullptr;
     static int trace_runs = 0;
-    PillarArgs at = a;
-    if (want_trace) {
-        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)ntiles * 8 * sizeof(unsigned long long)));
-        LAV_HIP(hipMemsetAsync(d_trace, 0, (size_t)ntiles * 8 * sizeof(unsigned long long), st));
+    RowsArgs at;
+    at.batch = a.batch; at.nx = a.nx; at.ny = a.ny; at.UPR = a.UPR; at.NUP = a.NUP; at.cap = a.cap;
+    at.min_x = a.min_x; at.min_y = a.min_y; at.ppm = a.ppm; at.trace = nullptr;
+    static const int cost_unit = [] { const char *e = getenv("LAV_PILLAR_COST_UNIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : COST_UNIT; }();
+    at.cost_unit = cost_unit;
+    if (want_trace && vec4) {
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)persistent_workgroups() * 16 * sizeof(unsigned long long)));
+        LAV_HIP(hipMemsetAsync(d_trace, 0, (size_t)persistent_workgroups() * 16 * sizeof(unsigned long long), st));
         at.trace = d_trace;
     }
     const int tok = timer_begin("pointnet_scatter", st);
-    if (want_trace) {
-        hipLaunchKernelGGL((k_tile_pointnet<D, true, true>), dim3(ntiles), dim3(256), lds, st, at, w.rec, w.tile_offset, w.tile_order, net->w1, net->b1, net->w2, net->b2, canvas);
-        timer_end(tok, st);
-        LAV_LAUNCH_CHECK();
-        if (++trace_runs == 20) dump_trace(d_trace, ntiles, st);
-        return LAV_OK;
+#define LAV_ROWS(MFMA, VEC, TR)                                                                                                 \
+    hipLaunchKernelGGL((k_rows<D, MFMA, VEC, TR>), dim3(W), dim3(256), 0, st, at, w.state, w.counters, w.buckets, w.ovf, net->w1, \
+                       net->b1, net->w2, net->b2, w.wpack, canvas)
+    if constexpr (D == 11) {   // debug variants exist for the v2 agent's point width only
+        if (want_trace && vec4) {
+            LAV_ROWS(true, true, true);
+            timer_end(tok, st);
+            LAV_LAUNCH_CHECK();
+            if (++trace_runs == 20) dump_trace(d_trace, W, st);
+            return LAV_OK;
+        }
+        if (use_valu_impl()) {
+            if (vec4) LAV_ROWS(false, true, false); else LAV_ROWS(false, false, false);
+            timer_end(tok, st);
+            LAV_LAUNCH_CHECK();
+            return LAV_OK;
+        }
     }
-    if (use_valu_impl())
-        hipLaunchKernelGGL((k_tile_pointnet<D, false>), dim3(ntiles), dim3(256), lds, st, a, w.rec, w.tile_offset, w.tile_order, net->w1, net->b1, net->w2, net->b2, canvas);
-    else
-        hipLaunchKernelGGL((k_tile_pointnet<D, true>), dim3(ntiles), dim3(256), lds, st, a, w.rec, w.tile_offset, w.tile_order, net->w1, net->b1, net->w2, net->b2, canvas);
+    {
+        if (vec4) LAV_ROWS(true, true, false); else LAV_ROWS(true, false, false);
+    }
+#undef LAV_ROWS
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+int fill_args(PillarArgs &a, const float *points, const int *h_num_points, int batch, int max_points, int D, const lav_grid *grid,
+              const Workspace &w, const char *who) {
+    a.points = points;
+    a.batch = batch;
+    a.max_points = max_points;
+    a.D = D;
+    for (int b = 0; b < batch; ++b) {
+        LAV_REQUIRE(h_num_points[b] >= 0, "%s: negative num_points", who);
+        a.n[b] = h_num_points[b] < max_points ? h_num_points[b] : max_points;
+    }
+    for (int b = batch; b < MAX_BATCH; ++b) a.n[b] = 0;
+    a.min_x = grid->min_x; a.max_x = grid->max_x; a.min_y = grid->min_y; a.max_y = grid->max_y; a.ppm = grid->ppm;
+    a.nx = grid->nx; a.ny = grid->ny; a.KX = grid->nx + 1; a.KY = grid->ny + 1;
+    a.UPR = w.upr;
+    a.NUP = (int)align_up((size_t)batch * grid->ny * w.upr, 4);
+    a.cap = w.cap;
+    a.trace = nullptr;
     return LAV_OK;
 }
 
@@ -761,7 +1145,20 @@ extern "C" size_t lav_pillar_workspace_bytes(int batch, int max_points, const la
     if (!grid || batch <= 0 || max_points < 0) return 0;
     Arena ar(nullptr, 0);
     Workspace w;
-    return carve(ar, w, batch, max_points, grid);
+    return carve(ar, w, batch, max_points, grid, true);
+}
+
+extern "C" size_t lav_pillar_decorate_workspace_bytes(int batch, int max_points, const lav_grid *grid) {
+    if (!grid || batch <= 0 || max_points < 0) return 0;
+    Arena ar(nullptr, 0);
+    Workspace w;
+    return carve(ar, w, batch, max_points, grid, false);
+}
+
+extern "C" int lav_pillar_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+    LAV_REQUIRE(workspace || workspace_bytes == 0, "lav_pillar_workspace_init: null workspace");
+    if (workspace_bytes) LAV_HIP(hipMemsetAsync(workspace, 0, workspace_bytes, static_cast<hipStream_t>(stream)));
+    return LAV_OK;
 }
 
 extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, int batch, int max_points, int D,
@@ -773,46 +1170,33 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
     LAV_REQUIRE(net->channels == C, "lav_pillar_scatter: PointNet width %d unsupported (built for %d)", net->channels, C);
     LAV_REQUIRE(net->num_input == D + 5, "lav_pillar_scatter: num_input %d != D+5 (D=%d)", net->num_input, D);
     LAV_REQUIRE(grid->nx > 0 && grid->ny > 0, "lav_pillar_scatter: empty grid");
+    LAV_REQUIRE(grid->nx < 4096 && grid->ny < 4096, "lav_pillar_scatter: grid %dx%d too large (12-bit cell coordinates)", grid->nx, grid->ny);
     LAV_REQUIRE((long)batch * (grid->nx + 1) * (grid->ny + 1) < (1l << 30) && (long)batch * max_points < (1l << 30),
                 "lav_pillar_scatter: problem too large for 32-bit indices");
-    LAV_REQUIRE(D + 1 <= REC_MAX, "lav_pillar_scatter: point width %d too large", D);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
     Arena ar(workspace, workspace_bytes);
     Workspace w;
-    carve(ar, w, batch, max_points, grid);
+    carve(ar, w, batch, max_points, grid, true);
     if (!workspace || !ar.ok()) return fail(LAV_EWORKSPACE, "lav_pillar_scatter: workspace %zu < %zu bytes", workspace_bytes, ar.used);
 
     PillarArgs a;
-    a.trace = nullptr;
-    a.points = points;
-    a.batch = batch;
-    a.max_points = max_points;
-    a.D = D;
-    for (int b = 0; b < batch; ++b) {
-        LAV_REQUIRE(h_num_points[b] >= 0, "lav_pillar_scatter: negative num_points");
-        a.n[b] = h_num_points[b] < max_points ? h_num_points[b] : max_points;
-    }
-    for (int b = batch; b < MAX_BATCH; ++b) a.n[b] = 0;
-    a.min_x = grid->min_x; a.max_x = grid->max_x; a.min_y = grid->min_y; a.max_y = grid->max_y; a.ppm = grid->ppm;
-    a.nx = grid->nx; a.ny = grid->ny; a.KX = grid->nx + 1; a.KY = grid->ny + 1;
-    tile_geometry(a.nx, a.T, a.TW);
-    {   // canvas row 0 collects key rows ny-1..nx, the last column tile collects key columns nx-1..ny (reference clamp)
+    int rc = fill_args(a, points, h_num_points, batch, max_points, D, grid, w, "lav_pillar_scatter");
+    if (rc) return rc;
+    {   // canvas row 0 collects key rows ny-1..nx, the last column collects key columns nx-1..ny (reference clamp)
         const long lay = (long)(a.nx - (a.ny - 1) + 1 > 1 ? a.nx - (a.ny - 1) + 1 : 1) * ((a.ny - a.nx + 1 > 0 ? a.ny - a.nx + 1 : 0) + 1);
         LAV_REQUIRE(lay <= MAX_LAYERS, "lav_pillar_scatter: grid %dx%d needs %ld clamp layers (max %d)", a.nx, a.ny, lay, MAX_LAYERS);
     }
-
-    int rc;
+    const bool want_idx = unique_coords || inverse || counts;
     switch (D) {
-        case 11: rc = launch_canvas<11>(a, w, net, canvas, st); break;
-        case 4: rc = launch_canvas<4>(a, w, net, canvas, st); break;
-        case 5: rc = launch_canvas<5>(a, w, net, canvas, st); break;
-        case 8: rc = launch_canvas<8>(a, w, net, canvas, st); break;
-        default: return fail(LAV_EINVAL, "lav_pillar_scatter: point width D=%d not instantiated (4,5,8,11)", D);
+        case 11: rc = launch_canvas<11>(a, w, net, canvas, want_idx, st); break;
+        case 4: rc = launch_canvas<4>(a, w, net, canvas, want_idx, st); break;
+        case 8: rc = launch_canvas<8>(a, w, net, canvas, want_idx, st); break;
+        default: return fail(LAV_EINVAL, "lav_pillar_scatter: point width D=%d not instantiated (4,8,11)", D);
     }
     if (rc) return rc;
 
-    if (unique_coords || inverse || counts) {
+    if (want_idx) {
         const long ncells = (long)batch * a.KX * a.KY;
         const long total = (long)batch * max_points;
         LAV_HIP(hipMemsetAsync(w.cell_count, 0, ncells * sizeof(int), st));
@@ -951,20 +1335,19 @@ extern "C" int lav_pillar_decorate(const float *points, const int *h_num_points,
                                    int *counts, void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(grid && h_num_points && counts && decorated, "lav_pillar_decorate: null argument");
     LAV_REQUIRE(batch >= 1 && batch <= MAX_BATCH, "lav_pillar_decorate: batch %d outside [1,%d]", batch, MAX_BATCH);
-    LAV_REQUIRE(max_points >= 0 && (points || max_points == 0) && D >= 3 && D < REC_MAX, "lav_pillar_decorate: bad points");
+    LAV_REQUIRE(max_points >= 0 && (points || max_points == 0) && D >= 3 && D < 16, "lav_pillar_decorate: bad points");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Arena ar(workspace, workspace_bytes);
     Workspace w;
-    carve(ar, w, batch, max_points, grid);
+    carve(ar, w, batch, max_points, grid, false);
     if (!workspace || !ar.ok()) return fail(LAV_EWORKSPACE, "lav_pillar_decorate: workspace %zu < %zu bytes", workspace_bytes, ar.used);
     PillarArgs a;
-    a.trace = nullptr;
     a.points = points; a.batch = batch; a.max_points = max_points; a.D = D;
     for (int b = 0; b < MAX_BATCH; ++b) a.n[b] = b < batch ? (h_num_points[b] < max_points ? h_num_points[b] : max_points) : 0;
     for (int b = 0; b < batch; ++b) LAV_REQUIRE(h_num_points[b] >= 0, "lav_pillar_decorate: negative num_points");
     a.min_x = grid->min_x; a.max_x = grid->max_x; a.min_y = grid->min_y; a.max_y = grid->max_y; a.ppm = grid->ppm;
     a.nx = grid->nx; a.ny = grid->ny; a.KX = grid->nx + 1; a.KY = grid->ny + 1;
-    a.T = a.TW = 0;
+    a.UPR = w.upr; a.NUP = 0; a.cap = w.cap; a.trace = nullptr;
     const long ncells = (long)batch * a.KX * a.KY;
     const long total = (long)batch * max_points;
     const unsigned gp = (unsigned)((total + 255) / 256);

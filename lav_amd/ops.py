@@ -76,7 +76,9 @@ def pillar_scatter(points: torch.Tensor, num_points: Sequence[int], grid: Grid, 
     dev = points.device
     canvas = torch.empty((B, Cc, grid.ny, grid.nx), dtype=torch.float32, device=dev)
     nbytes = lib.lav_pillar_workspace_bytes(B, nmax, C.byref(grid))
-    ws = _workspace("pillar", nbytes, dev)
+    # zero-filled once and kept per geometry: the head of a pillar workspace is state that every call leaves clean
+    # (include/lav_amd.h, workspace contract)
+    ws = _workspace(("pillar", B, grid.nx, grid.ny), nbytes, dev)
     h_num = (C.c_int * B)(*[int(n) for n in num_points])
     uc = inv = cnt = None
     if want_indices:
@@ -108,8 +110,8 @@ def pillar_decorate(points: torch.Tensor, num_points: Sequence[int], grid: Grid)
     src = torch.empty((total,), dtype=torch.int32, device=dev)
     dec = torch.empty((total, D + 5), dtype=torch.float32, device=dev)
     cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
-    nbytes = lib.lav_pillar_workspace_bytes(B, nmax, C.byref(grid))
-    ws = _workspace("pillar", nbytes, dev)
+    nbytes = lib.lav_pillar_decorate_workspace_bytes(B, nmax, C.byref(grid))
+    ws = _workspace("pillar_decorate", nbytes, dev)
     h_num = (C.c_int * B)(*[int(n) for n in num_points])
     check(lib.lav_pillar_decorate(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), _ptr(uc), _ptr(inv),
                                   _ptr(src), _ptr(dec), _ptr(cnt), _ptr(ws), ws.numel(), _stream()), "lav_pillar_decorate")
