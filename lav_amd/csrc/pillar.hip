@@ -10,12 +10,14 @@
 //           counter (2 sub-counters on different cache lines); the point is written ONCE as a 48-byte record
 //           {11 floats, packed cell} into the unit's fixed-capacity bucket, or appended to an overflow list when the
 //           bucket is full (adversarial clouds only).  No scan, no second pass over the cloud.
-//   k_rows  persistent workgroups, two per CU.  Every workgroup reads all unit counters once (25 KB, L2),
-//           prices a unit at COST_UNIT + points, and takes the contiguous run of units holding its 1/W share of the
-//           total - a static, deterministic partition with no queue and no inter-workgroup traffic.  The run is
-//           processed in GROUPS of up to 5 units of one canvas row (160 columns):
+//   k_rows  persistent workgroups, two per CU (W = 512).  Workgroup w OWNS units w, w + W, w + 2 W, ...: six or seven
+//           units spread evenly over the canvas, so that the dense cells around the ego vehicle are dealt out over the
+//           whole chip without any scan, queue or inter-workgroup traffic - a workgroup reads 16 counters and knows its
+//           work.  Its units are processed as one GROUP (up to 8 units = 256 tile columns):
+//        (0) units without points stream zeros straight from registers;
 //        (a) per-cell xyz sums and counts in LDS (64-bit fixed point: order independent, so the canvas is
-//            bit-identical for ANY arrival order / input permutation; exact to 2^-32 m);
+//            bit-identical for ANY arrival order / input permutation; exact to 2^-32 m); only the tile columns that
+//            points touch are then zeroed;
 //        (b) JOBS of 16 points, dealt round-robin to the 4 waves, run BOTH PointNet layers on the matrix cores
 //            with every weight fragment and all activations in registers (v_mfma_f32_16x16x4_f32, exact fp32):
 //              layer 1 (transposed)  D1[c][p]  = sum_k W1[k][c] * F[k][p]     A = weights, B = point features
@@ -24,12 +26,14 @@
 //              layer 2               D2[p][c2] = sum_c H1[p][c] * W2[c][c2]   A = relu(D1) AS IT SITS, B = weights
 //                 k-step (ct, r) covers k = 16*ct + 4*g + r over the four lane groups - a permutation of 0..63,
 //                 which a sum does not care about - so no shuffles or LDS round trip between the layers;
-//        (c) unsigned-integer max of the float bits (values >= 0 after ReLU) into an LDS tile [C][164];
-//        (d) the tile - zeros for empty cells included - streams to the NCHW canvas with 16-byte stores, and
-//            is cleared by the same pass (read-and-clear), so it is zero again for the next group.
-//           Groups without points write zeros straight from registers.  The canvas is written exactly once and
-//           never read or memset: algorithmic traffic 4*(N*D + C*ny*nx) bytes.  Records of the next group are
-//           requested while the current one is on the matrix cores.
+//            a group of one (two) jobs is split four (two) ways over the waves by output channels;
+//        (c) unsigned-integer max of the float bits (values >= 0 after ReLU) into an LDS tile [C][260];
+//        (d) the units with points stream from the tile to the NCHW canvas with 16-byte stores (quads of columns no
+//            point touched are written as zeros without an LDS read).
+//           The canvas is written exactly once and never read or memset: algorithmic traffic 4*(N*D + C*ny*nx) bytes.
+//           Weight fragments arrive pre-ordered (k_bin re-lays the 5.6 k floats on every call): 22 coalesced loads per
+//           wave.  Barriers order LDS traffic only (s_waitcnt lgkmcnt + s_barrier), so prefetched records and canvas
+//           stores stay in flight across them.
 //
 // Workspace contract: the first bytes of the workspace hold state that is ZERO AT REST (two sets of unit counters
 // used alternately, two epoch words).  The caller zero-fills a workspace once (lav_pillar_workspace_init) and keeps it
@@ -64,8 +68,6 @@ constexpr int NSUB = 2;          // arrival counters per unit, on different cach
 constexpr int GMAX = 8;          // units per group (consecutive units, whatever canvas rows they are on)
 constexpr int GW = GMAX * UW;    // canvas columns per group (LDS tile width)
 constexpr int TS = GW + 4;       // LDS tile row stride in floats (16-byte aligned rows)
-constexpr int WIN = 64;          // unit counters cached in LDS at a time
-constexpr int COST_UNIT = 24;    // price of streaming one unit out, in points (partition of k_rows)
 constexpr int CAP_MIN = 16, CAP_MAX = 256;  // records per (unit, sub) bucket
 constexpr int MAX_LAYERS = 64;   // regular + overflow layers a group may have (2-4 for square grids)
 constexpr double FIX_SCALE = 4294967296.0;  // 2^32 fixed-point scale of the per-cell coordinate sums
@@ -94,7 +96,7 @@ struct PillarArgs {   // scalars first: they share the first cache line of the k
 
 // What k_rows needs of the above: small enough to arrive with the first kernel-argument fetch.
 struct RowsArgs {
-    int batch, nx, ny, UPR, NUP, cap, cost_unit;
+    int batch, nx, ny, UPR, NUP, cap;
     float min_x, min_y, ppm;
     unsigned long long *trace;
 };
@@ -173,11 +175,10 @@ __global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ s
     int k = -1;
     const float *pt = a.points + gid * D;
     float v[RS];
-    if (i < a.n[b]) {
-        v[0] = pt[0];
-        v[1] = pt[1];
-        k = cell_key(a, b, v[0], v[1]);
-    }
+    // the whole row is requested at once (one memory round trip before the arrival atomic, not two)
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = pt[d];
+    if (i < a.n[b]) k = cell_key(a, b, v[0], v[1]);
     if (key_out) key_out[gid] = k;
     if (k < 0) return;
     const int cellk = k - b * a.KX * a.KY;
@@ -187,8 +188,6 @@ __global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ s
     // the sub-counter only decorrelates concurrent arrivals
     const int sub = (threadIdx.x ^ (threadIdx.x >> 6) ^ blockIdx.x) & (NSUB - 1);
     const int slot = atomicAdd(&counters[((size_t)set * NSUB + sub) * a.NUP + unit], 1);
-#pragma unroll
-    for (int d = 2; d < D; ++d) v[d] = pt[d];
 #pragma unroll
     for (int d = D; d < RS - 1; ++d) v[d] = 0.f;
     v[RS - 1] = __int_as_float((b << 24) | (xi << 12) | yi);
@@ -224,13 +223,14 @@ __device__ __forceinline__ int wave_scan64(int v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One group of consecutive units, as every thread of the workgroup sees it (all values workgroup-uniform).
+// One group of units of a workgroup, as every thread of the workgroup sees it (all values workgroup-uniform).
+// Workgroup w of W owns units w, w + W, w + 2 W, ... (its "slots" 0, 1, 2, ...); a group is up to GMAX consecutive slots.
 struct Group {
-    int u, ue;      // units [u, ue)
+    int first, gn;  // slots [first, first + gn)
     int n;          // records in the buckets of the group
     bool has_ovf;   // some bucket of the group overflowed into the overflow list
     int slot;       // which of the wave's two prefix tables (gpre) describes its buckets
-    unsigned mask;  // bit NSUB*k + s: bucket (unit k, sub s) holds records
+    unsigned mask;  // bit NSUB*k + s: bucket (unit slot first + k, sub s) holds records
 };
 constexpr int NBKT = GMAX * NSUB;  // buckets of a group
 
@@ -249,9 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     __shared__ int nl[MAX_LAYERS];
     __shared__ int occ4[GW / 4];   // group number (+1) of the last group that put a point on this quad of columns
     __shared__ int newq[GW / 4];   // quads a layer's sweep touched for the first time in this group: their tile columns get zeroed
-    __shared__ int win[NSUB][WIN];
     __shared__ __attribute__((aligned(16))) int gpre[4][2][NBKT + 4];  // per wave, two slots: first record index of every bucket of a group
-    __shared__ __attribute__((aligned(16))) int red[32];
 
     // fetch both cache lines of the kernel-argument segment at once (taken in turn, each is a microsecond-scale miss)
     asm volatile("" ::"s"(a.batch), "s"(canvas));
@@ -261,43 +259,23 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     long long cyc0 = 0;
     if constexpr (TRACE) cyc0 = clock64();
     const int nunits = a.batch * a.ny * a.UPR;
+    const int W = (int)gridDim.x, w = (int)blockIdx.x;
+    const int nslots = (nunits - w + W - 1) / W;   // units of this workgroup
+    if (nslots <= 0) return;
     // Two counter sets are used by alternate calls and k_bin has cleaned the one it did not fill: every counter is read
     // as the sum over both sets, which needs no knowledge of the epoch.
     const int *__restrict__ cn = counters;
-
-    // ---- static partition: this workgroup's run of units [u0, u1) -------------------------------------
-    // The counters of a chunk of 4096 units arrive as 4 x 4 fully coalesced 16-byte loads per thread (two sets x two
-    // sub-arrays, 4 loads each), issued before anything else.  Wave w owns units [1024 w, 1024 w + 1024) of the chunk;
-    // load j of lane l covers units 1024 w + 4 (64 j + l) .. + 3, so a wave's unit order is (j, l, q).
-    constexpr int PER = 16, CH = 256 * PER;
-    constexpr unsigned NO_UNIT = 0xffffffffu;
-    auto unit_index = [&](int base, int k) { return base + 1024 * wid + 4 * (64 * (k >> 2) + lane) + (k & 3); };
-    // pk = the two sub-counters of a unit, 16 bits each (clamped: only the comparison with the bucket capacity and the
-    // price need them), or NO_UNIT
-    auto load_chunk = [&](int base, unsigned (&pk)[PER]) {
-#pragma unroll
-        for (int j = 0; j < PER / 4; ++j) {
-            const int ub = unit_index(base, 4 * j);
-            // unconditional loads from a clamped address (a load under an exec-mask branch is waited for inside its branch:
-            // serial round trips instead of one); entries of units that do not exist are masked below
-            const int o = min(ub, a.NUP - 4);
-            const int4 x0 = *reinterpret_cast<const int4 *>(cn + o);
-            const int4 x1 = *reinterpret_cast<const int4 *>(cn + a.NUP + o);
-            const int4 y0 = *reinterpret_cast<const int4 *>(cn + 2 * a.NUP + o);
-            const int4 y1 = *reinterpret_cast<const int4 *>(cn + 3 * a.NUP + o);
-            static_assert(NSUB == 2, "load_chunk reads two sub-counter arrays");
-            const int v0[4] = {x0.x + y0.x, x0.y + y0.y, x0.z + y0.z, x0.w + y0.w};
-            const int v1[4] = {x1.x + y1.x, x1.y + y1.y, x1.z + y1.z, x1.w + y1.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                pk[4 * j + q] = ub + q < nunits ? (unsigned)min(v0[q], 0xfffe) | ((unsigned)min(v1[q], 0xfffe) << 16) : NO_UNIT;
-        }
+    // bucket counts of the group that starts at slot `first`: lane l < NBKT holds bucket (unit slot first + l / NSUB, sub
+    // l % NSUB).  Unconditional load from a clamped address (a load under an exec-mask branch is waited for inside the branch).
+    auto fetch_counts = [&](int first) {
+        const int k = first + lane / NSUB, sb = lane % NSUB;
+        const int u = min(w + k * W, nunits - 1);
+        const int c = cn[sb * a.NUP + u] + cn[(NSUB + sb) * a.NUP + u];
+        return (lane < NBKT && k < nslots) ? c : 0;
     };
-    auto price = [&](unsigned p) { return p == NO_UNIT ? 0 : a.cost_unit + (int)(p & 0xffffu) + (int)(p >> 16); };
-    unsigned pk[PER];
-    load_chunk(0, pk);
+    const int c_first = fetch_counts(0);
 
-    if (blockIdx.x == 0 && tid == 0) st->epoch_rows = st->epoch_bin + 1u;   // the next call fills the other counter set
+    if (w == 0 && tid == 0) st->epoch_rows = st->epoch_bin + 1u;   // the next call fills the other counter set
 
     // weight fragments, once per workgroup (fragment order written by k_bin: 22 coalesced loads)
     float a1[4][KS1], w2f[4][4][4], b2v[4];
@@ -318,121 +296,21 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         const float4 t = wp[(KS1 + 16) * 64];
         b2v[0] = t.x; b2v[1] = t.y; b2v[2] = t.z; b2v[3] = t.w;
     }
-    if (tid < 32) red[tid] = 0;
+    // LDS state every group starts from: sums, counts, layer counts and markers zero.  The tile itself is NOT cleared:
+    // only the quads of columns that points touch are zeroed (after the sums sweep) and read back.
+    for (int i = tid; i < GW * 3; i += 256) sums[i] = 0ull;
+    if (tid < GW) cnt[tid] = 0;
+    if (tid < MAX_LAYERS) nl[tid] = 0;
+    if (tid < GW / 4) { occ4[tid] = 0; newq[tid] = 0; }
     LAV_STAMP(1);
-
-    int u0, u1, wu0;
-    {
-        // scan of one chunk inside a wave: exclusive prefix of each of the lane's 4 runs (rex) and the wave's total
-        auto wave_prefix = [&](const unsigned (&p)[PER], int (&rex)[4]) {
-            int before = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rs = price(p[4 * j]) + price(p[4 * j + 1]) + price(p[4 * j + 2]) + price(p[4 * j + 3]);
-                const int inc = wave_scan64(rs);
-                rex[j] = before + inc - rs;
-                before += __builtin_amdgcn_readlane(inc, 63);
-            }
-            return before;
-        };
-        // units of a chunk whose prefix is below lo / hi
-        auto count_below = [&](int base, const unsigned (&p)[PER], const int (&rex)[4], unsigned before, unsigned lo, unsigned hi,
-                               int &c_lo, int &c_hi) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned run = before + (unsigned)rex[j];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (p[4 * j + q] != NO_UNIT) {
-                        c_lo += run < lo;
-                        c_hi += run < hi;
-                        run += (unsigned)price(p[4 * j + q]);
-                    }
-            }
-        };
-        int rex[4];
-        const int wtot = wave_prefix(pk, rex);
-        int tsum = wtot;
-        for (int base = CH; base < nunits; base += CH) {   // several chunks (several clouds): the grand total first
-            unsigned p2[PER];
-            int r2[4];
-            load_chunk(base, p2);
-            tsum += wave_prefix(p2, r2);
-        }
-        barrier_lds();   // red[] zeroed
-        if (lane == 0) {
-            red[wid] = wtot;
-            red[4 + wid] = tsum;
-        }
-        barrier_lds();
-        const unsigned total = (unsigned)(red[4] + red[5] + red[6] + red[7]);
-        // share of workgroup w = [lo(w), lo(w+1)),  lo(w) = w q + min(w, rem): lo(0) = 0, lo(W) = total
-        const unsigned W = gridDim.x, qq = total / W, rem = total - qq * W;
-        const unsigned lo = blockIdx.x * qq + min(blockIdx.x, rem), hi = (blockIdx.x + 1) * qq + min(blockIdx.x + 1, rem);
-        int c_lo = 0, c_hi = 0;
-        unsigned before = 0;
-        for (int base = 0; base < nunits; base += CH) {
-            if (base > 0) {   // (rare) the next chunk: its wave totals go through red[0..3] again
-                load_chunk(base, pk);
-                const int wt = wave_prefix(pk, rex);
-                barrier_lds();
-                if (lane == 0) red[wid] = wt;
-                barrier_lds();
-            }
-            unsigned mine = before;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                if (w < wid) mine += (unsigned)red[w];
-                before += (unsigned)red[w];
-            }
-            count_below(base, pk, rex, mine, lo, hi, c_lo, c_hi);
-        }
-        // one LDS atomic per wave: same-address atomics of a wave are served lane by lane
-        c_lo = wave_scan64(c_lo);
-        c_hi = wave_scan64(c_hi);
-        if (lane == 63) {
-            atomicAdd(&red[8], c_lo);
-            atomicAdd(&red[9], c_hi);
-        }
-        barrier_lds();
-        u0 = red[8];
-        u1 = red[9];
-        // first window of unit counters: straight from the registers that hold them
-        wu0 = u0;
-        if (nunits <= CH) {
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int u = unit_index(0, k);
-                if (u >= u0 && u < min(u1, u0 + WIN)) {
-                    win[0][u - u0] = (int)(pk[k] & 0xffffu);
-                    win[1][u - u0] = (int)(pk[k] >> 16);
-                }
-            }
-        } else if (tid < NSUB * WIN) {
-            const int sb = tid / WIN, i = tid - sb * WIN;
-            win[sb][i] = wu0 + i < u1 ? cn[sb * a.NUP + wu0 + i] + cn[(NSUB + sb) * a.NUP + wu0 + i] : 0;
-        }
-        barrier_lds();
-    }
-    LAV_STAMP(2);
-    if constexpr (TRACE) { if (tid == 0) { a.trace[(long)blockIdx.x * 16 + 14] = (unsigned long long)(u1 - u0); a.trace[(long)blockIdx.x * 16 + 15] = 0; } }
-    if (u0 >= u1) return;
-    auto load_window = [&]() {
-        if (tid < NSUB * WIN) {
-            const int sb = tid / WIN, i = tid - sb * WIN;
-            win[sb][i] = wu0 + i < u1 ? cn[sb * a.NUP + wu0 + i] + cn[(NSUB + sb) * a.NUP + wu0 + i] : 0;
-        }
-    };
 
     // Every wave keeps its own copy of a group's bucket prefix in LDS (written and read by the same wave: the LDS
     // queue of a wave is in order, so no barrier is involved and groups without points need none either).
-    auto describe = [&](int u, int slot) {  // u must lie inside the window
+    auto describe = [&](int first, int c, int slot) {
         Group g;
-        g.u = u;
+        g.first = first;
+        g.gn = min(GMAX, nslots - first);
         g.slot = slot;
-        g.ue = min(u1, u + GMAX);
-        const int k = lane / NSUB, sb = lane % NSUB;
-        const int c = (lane < NBKT && u + k < g.ue && u + k - wu0 < WIN) ? win[sb][u + k - wu0] : 0;
         g.has_ovf = __ballot(c > a.cap) != 0ull;
         g.mask = (unsigned)__ballot(c > 0);
         const int cc = min(c, a.cap);
@@ -449,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         const int4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
         const int q = (i >= p0.y) + (i >= p0.z) + (i >= p0.w) + (i >= p1.x) + (i >= p1.y) + (i >= p1.z) + (i >= p1.w) + (i >= p2.x) +
                       (i >= p2.y) + (i >= p2.z) + (i >= p2.w) + (i >= p3.x) + (i >= p3.y) + (i >= p3.z) + (i >= p3.w);
-        return buckets + (((size_t)g.u * NSUB + q) * a.cap + (i - gpre[wid][g.slot][q])) * RS;
+        const size_t unit = (size_t)w + (size_t)(g.first + q / NSUB) * W;
+        return buckets + ((unit * NSUB + q % NSUB) * a.cap + (i - gpre[wid][g.slot][q])) * RS;
     };
     auto load_rec = [&](const float *p, float4 (&r)[RQ]) {
 #pragma unroll
@@ -470,41 +349,42 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     };
 
     int gi = 0;
-    Group g = describe(u0, 0);
+    Group g = describe(0, c_first, 0);
     request_first_job(g, 0);
-    // LDS state every group starts from: sums, counts, layer counts and markers zero.  The tile itself is NOT cleared:
-    // only the quads of columns that points touch are zeroed (after the sums sweep) and read back.
-    for (int i = tid; i < GW * 3; i += 256) sums[i] = 0ull;
-    if (tid < GW) cnt[tid] = 0;
-    if (tid < MAX_LAYERS) nl[tid] = 0;
-    if (tid < GW / 4) { occ4[tid] = 0; newq[tid] = 0; }
-    barrier_lds();
+    int c_next = nslots > GMAX ? fetch_counts(GMAX) : 0;   // counters of the following group, one group ahead
     const long cstride = (long)a.ny * a.nx;
     const int xi_row0 = max(a.ny - 1, 0);                       // first key row that lands on canvas row 0
     const int nlay_over = max(0, a.ny - a.nx + 1) + 1;          // layers of a unit that holds the last canvas column
     const int nlay_max = min(MAX_LAYERS, max(a.nx - xi_row0 + 1, 1) * nlay_over);
+    // walking this workgroup's units: one division here, carries afterwards
+    const int step_rb = W / a.UPR, step_cu = W - step_rb * a.UPR, step_b = step_rb / a.ny, step_r = step_rb - step_b * a.ny;
+    barrier_lds();   // LDS state set up
 
     while (true) {
         const int rot = gi & 3;
-        const int gn = g.ue - g.u;   // units of the group; its tile column of (unit k, column c of the unit) is 32 k + c
+        const int gn = g.gn;   // units of the group; the tile column of (unit slot k, column c of the unit) is 32 k + c
         // what comes after this group (workgroup-uniform); its records are requested while this one computes
-        const bool more = g.ue < u1;
+        const bool more = g.first + gn < nslots;
         if (gi == 0) LAV_STAMP(3);
         if (gi == 1) LAV_STAMP(11);
         if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + 15] += (unsigned long long)g.n; }
-        const bool next_in_window = more && g.ue + GMAX <= wu0 + WIN;
         bool prefetched = false;
+        Group gnext;
         auto prefetch_next = [&]() {
-            if (next_in_window && !prefetched) request_first_job(describe(g.ue, g.slot ^ 1), (gi + 1) & 3);
+            if (more && !prefetched) {
+                gnext = describe(g.first + gn, c_next, g.slot ^ 1);
+                request_first_job(gnext, (gi + 1) & 3);
+            }
             prefetched = true;
         };
         // Streams units of the group to the canvas [B][C][ny][nx]: zeros from registers (FROM_LDS false) for the units
         // without points, the tile for the others.  A unit is one 128-byte line of every channel plane (less at the right
-        // border); the walk over the units needs one division per group.
+        // border).
         auto store_units = [&](auto FROM_LDS_) {
             constexpr bool FROM_LDS = decltype(FROM_LDS_)::value;
-            int rb = g.u / a.UPR, cu = g.u - rb * a.UPR;
-            int b = rb / a.ny, r = rb - b * a.ny;
+            const int un0 = w + g.first * W;
+            const int rb0 = un0 / a.UPR;
+            int cu = un0 - rb0 * a.UPR, b = rb0 / a.ny, r = rb0 - b * a.ny;
             const int j4 = tid & 7, ch0 = tid >> 3;
             int flags = 0;   // bit k: quad (unit k, j4) holds data in the tile
             if constexpr (FROM_LDS && VEC4) {
@@ -517,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
             for (int k = 0; k < gn; ++k) {
                 const bool has = ((g.mask >> (NSUB * k)) & ((1u << NSUB) - 1)) != 0;
                 if (has == FROM_LDS) {
-                    const int c0 = cu * UW, w = min(a.nx, c0 + UW) - c0;
+                    const int c0 = cu * UW, wd = min(a.nx, c0 + UW) - c0;
                     float *dst = canvas + ((long)b * C * a.ny + r) * a.nx + c0;
                     if constexpr (VEC4) {
                         float4 val[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
@@ -527,15 +407,15 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                                 for (int h = 0; h < 2; ++h) val[h] = *reinterpret_cast<const float4 *>(tile + (ch0 + 32 * h) * TS + k * UW + 4 * j4);
                             }
                         }
-                        if (4 * j4 < w) {
+                        if (4 * j4 < wd) {
 #pragma unroll
                             for (int h = 0; h < 2; ++h)
                                 __builtin_nontemporal_store(f32x4{val[h].x, val[h].y, val[h].z, val[h].w},
                                                             reinterpret_cast<f32x4 *>(dst + (ch0 + 32 * h) * cstride + 4 * j4));
                         }
                     } else {
-                        for (int idx = tid; idx < C * w; idx += 256) {
-                            const int ch = idx / w, j = idx - ch * w;
+                        for (int idx = tid; idx < C * wd; idx += 256) {
+                            const int ch = idx / wd, j = idx - ch * wd;
                             float val = 0.f;
                             if constexpr (FROM_LDS) {
                                 if (occ4[(k * UW + j) >> 2] == gi + 1) val = tile[ch * TS + k * UW + j];
@@ -544,10 +424,11 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                         }
                     }
                 }
-                if (++cu == a.UPR) {
-                    cu = 0;
-                    if (++r == a.ny) { r = 0; ++b; }
-                }
+                cu += step_cu;
+                r += step_r + (cu >= a.UPR);
+                b += step_b;
+                if (cu >= a.UPR) cu -= a.UPR;
+                if (r >= a.ny) { r -= a.ny; ++b; }
             }
         };
         using std::false_type;
@@ -557,9 +438,12 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
             prefetch_next();
             store_units(false_type{});   // no point lands here: zeros straight from registers
         } else {
-            // units of the group without points: their zeros leave while the records of the others are still in flight
-            store_units(false_type{});
-            if (gi == 0) LAV_STAMP(5);
+            // Units of the group without points: a store only leaves the wave once the memory pipeline accepts it, and the
+            // whole chip is streaming the canvas, so these zeros cost their share of the HBM time wherever they are put.  The
+            // two workgroups of a CU put them at opposite ends - before the sums sweep (while the records are in flight) or
+            // after the PointNet - so that one's stores run beside the other's latency-bound compute.
+            const bool zeros_first = (blockIdx.x / 8) & 1;   // (workgroups b and b + 8 x #XCDs... share a CU: b % 8 picks the XCD)
+            if (zeros_first) store_units(false_type{});
             // packed cell -> (layer, tile column, xi, yi, member of this group).  Layers order the pillars that the
             // reference's clamp (:89) sends to one canvas cell like its sorted unique rows: later layers replace earlier.
             auto classify = [&](int packed, int &layer, int &col, int &xi, int &yi) {
@@ -567,11 +451,14 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                 yi = packed & 0xfff;
                 const int r_ = min(max(a.ny - 1 - xi, 0), a.ny - 1);
                 const int colc = min(yi, a.nx - 1), cu_ = colc / UW;
-                const int k = ((packed >> 24) * a.ny + r_) * a.UPR + cu_ - g.u;
+                // units of this workgroup are w, w + W, w + 2 W, ...: slot of the record's unit inside the group
+                const int un = ((packed >> 24) * a.ny + r_) * a.UPR + cu_ - (int)blockIdx.x;
+                const int ks = un / (int)gridDim.x;
+                const int k = ks - g.first;
                 col = k * UW + (colc - cu_ * UW);
                 const int over = yi >= a.nx ? yi - a.nx + 1 : 0;
                 layer = (r_ > 0 ? 0 : xi - xi_row0) * (cu_ == a.UPR - 1 ? nlay_over : 1) + over;
-                return (unsigned)k < (unsigned)gn;
+                return un >= 0 && ks * (int)gridDim.x == un && (unsigned)k < (unsigned)gn;
             };
             const int n_ovf = g.has_ovf ? st->n_ovf[0] + st->n_ovf[1] : 0;   // (one of the two is zero, like the counters)
             const int JA = (g.n + 15) >> 4;
@@ -815,6 +702,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
             if (gi == 0) LAV_STAMP(9);
             // (d) stream the units that hold points out of the tile
             store_units(true_type{});
+            if (!zeros_first) store_units(false_type{});
             for (int i = tid; i < GW * 3; i += 256) sums[i] = 0ull;
             if (tid < GW) cnt[tid] = 0;
             if (tid < MAX_LAYERS) nl[tid] = 0;
@@ -824,16 +712,8 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         if (gi == 0) LAV_STAMP(10);
         if (!more) break;
         ++gi;
-        if (next_in_window) {
-            g = describe(g.ue, g.slot ^ 1);
-        } else {   // the counter window is used up: move it (rare: a run longer than WIN units)
-            barrier_lds();
-            wu0 = g.ue;
-            load_window();
-            barrier_lds();
-            g = describe(wu0, 0);
-            request_first_job(g, gi & 3);
-        }
+        g = gnext;
+        c_next = g.first + g.gn < nslots ? fetch_counts(g.first + g.gn) : 0;
     }
     LAV_STAMP(12);
     if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + 13] = (unsigned long long)(clock64() - cyc0); }
@@ -1084,8 +964,7 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     RowsArgs at;
     at.batch = a.batch; at.nx = a.nx; at.ny = a.ny; at.UPR = a.UPR; at.NUP = a.NUP; at.cap = a.cap;
     at.min_x = a.min_x; at.min_y = a.min_y; at.ppm = a.ppm; at.trace = nullptr;
-    static const int cost_unit = [] { const char *e = getenv("LAV_PILLAR_COST_UNIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : COST_UNIT; }();
-    at.cost_unit = cost_unit;
+
     if (want_trace && vec4) {
         if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)persistent_workgroups() * 16 * sizeof(unsigned long long)));
         LAV_HIP(hipMemsetAsync(d_trace, 0, (size_t)persistent_workgroups() * 16 * sizeof(unsigned long long), st));

@@ -20,3 +20,5 @@ for name, did, cname, val in db.execute(q):
 for name, cs in per.items():
     short = name.replace('(anonymous namespace)::', '')[:70]
     print(short, {c: round(sum(v[-3:]) / len(v[-3:]), 1) for c, v in cs.items()}, f"n={len(next(iter(cs.values())))}")
+    if "k_rows" in name or "k_bin" in name:   # tools/pmc_pillar.py: the first half of the dispatches is the 32 769-point cloud
+        print("    first cloud:", {c: round(sum(v[2:len(v) // 2]) / max(len(v[2:len(v) // 2]), 1), 1) for c, v in cs.items()})
