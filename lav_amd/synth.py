@@ -103,6 +103,7 @@ GAINS = (
     ("backbone.conv1.0.weight", 0.6),
     ("backbone", 0.72),
     ("head.net.0.weight", 0.5),
+    ("bra.classifier.0.weight", 0.003),   # keeps the brake logit O(1): a saturated sigmoid would pin nothing
 )
 
 

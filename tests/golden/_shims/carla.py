@@ -59,3 +59,11 @@ class Transform:
              [r2[0], r2[1], r2[2], tz],
              [f32(0), f32(0), f32(0), f32(1)]]
         return [[float(v) for v in row] for row in m]
+
+
+class VehicleControl:
+    """carla.VehicleControl: the return type of run_step (lav_agent_fast.py:232,360)."""
+
+    def __init__(self, throttle=0.0, steer=0.0, brake=0.0, hand_brake=False, reverse=False, manual_gear_shift=False, gear=0):
+        self.throttle, self.steer, self.brake = float(throttle), float(steer), float(brake)
+        self.hand_brake, self.reverse, self.manual_gear_shift, self.gear = hand_brake, reverse, manual_gear_shift, gear

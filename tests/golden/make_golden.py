@@ -204,10 +204,11 @@ def gold_planner(lm, up, feat):
 def gold_e2e(lm, up):
     im = ref_mi.InferModel(lm, up, 1.5, 2.4, device=torch.device("cpu"))
     out = {}
-    for name, n, kind in (("a", 32768, "lidar"), ("b", 16384, "uniform")):
+    # "c" is the agent's own cloud size: 3 sweeps x 65 536 points = 196 608 (lav_agent_fast.py:240-245, 363-383)
+    for name, n, kind in (("a", 32768, "lidar"), ("b", 16384, "uniform"), ("c", 65536, "lidar")):
         pts = synth.stacked_lidar(n, kind=kind)
-        nxp = torch.tensor([0.0, -10.0]) if name == "a" else torch.tensor([2.5, -14.0])
-        cmd = 3 if name == "a" else 1
+        nxp = {"a": torch.tensor([0.0, -10.0]), "b": torch.tensor([2.5, -14.0]), "c": torch.tensor([-1.5, -12.0])}[name]
+        cmd = {"a": 3, "b": 1, "c": 0}[name]
         e, p, c, oc, om, bev, det = im(torch.from_numpy(pts), nxp, cmd)
         out.update({f"{name}/in_crc": np.array([crc(pts)], np.int64), f"{name}/nxp": t2n(nxp),
                     f"{name}/cmd": np.array([cmd]), f"{name}/ego_embd": t2n(e), f"{name}/ego_plan": t2n(p),
@@ -230,9 +231,17 @@ def gold_rgb():
     sem = torch.softmax(logits, dim=1)
     rgb = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float()
     tel_rgb = tel[..., :3][..., ::-1][:-96].copy()
-    pred_bra = bra(rgb, torch.tensor(tel_rgb[None]).permute(0, 3, 1, 2).float())
+    tel_t = torch.tensor(tel_rgb[None]).permute(0, 3, 1, 2).float()
+    pred_bra = bra(rgb, tel_t)
+    # the brake net stage by stage (team_code_v2/models/rgb.py:66-74, lav/models/attention.py:21-38)
+    x1 = bra.conv_backbone(bra.normalize(rgb / 255.))
+    x2 = bra.conv_backbone(bra.normalize(tel_t / 255.))
+    h1, h2 = bra.attn1(x1), bra.attn2(x2)
+    logit = bra.classifier[0](torch.cat([h1, h2], dim=1))
+    assert torch.equal(torch.sigmoid(logit)[:, 0], pred_bra)
     save("rgb", logits_s=t2n(logits[:, :, ::4, ::4]), sem_s=t2n(sem[:, :, ::4, ::4]),
-         logits_sum=t2n(logits.double().sum((2, 3))), pred_bra=t2n(pred_bra))
+         logits_sum=t2n(logits.double().sum((2, 3))), pred_bra=t2n(pred_bra), bra_logit=t2n(logit),
+         bra_x1_s=t2n(x1[:, ::8]), bra_x2_s=t2n(x2[:, ::8]), bra_h1=t2n(h1), bra_h2=t2n(h2))
 
 
 def gold_agent():
@@ -264,6 +273,125 @@ def gold_agent():
         dx, dy, c = wp2.tick(g); w2_out.append([dx, dy, c.value])
     save("agent", ekf_x=np.array(xs), pid_a=np.array(pa), pid_b=np.array(pb), route=np.array(r_out),
          waypointer=np.array(w_out), waypointer_turn=np.array(w2_out), gps_crc=np.array([crc(sc["gps"])]))
+
+
+def gold_agent_fast(lm, up, ticks=24, n_points=8192):
+    """The REFERENCE AGENT ITSELF (team_code_v2/lav_agent_fast.py) driven over `ticks` leaderboard ticks of
+    synth.agent_scenario() on CPU: run_step's controls, the ego-box filter (`preprocess`, :450-457), the temporal
+    stacking (`get_stacked_lidar` / `move_lidar_points`, :363-383, 547-565) and what InferModel receives.
+    Stand-ins: carla / leaderboard / wandb / cv2 (tests/golden/_shims), the two torch.jit traces and the four
+    checkpoints (seeded state_dicts of the reference's own modules), cuda -> cpu, visualize() (debug video only)."""
+    import types
+    import lav_agent_fast as ref_agent  # noqa: E402  (reference)
+    from agents.navigation.local_planner import RoadOption
+
+    seg = RGBSegmentationModel([4, 6, 7, 10]).eval()
+    seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg."))
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]).eval()
+    bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra."))
+    cpu = torch.device("cpu")
+
+    class TorchProxy:
+        """`torch` as lav_agent_fast sees it: device('cuda') -> cpu, load / jit.load -> seeded weights."""
+        jit = types.SimpleNamespace(load=lambda path, *a, **k: bra if "bra" in str(path) else seg)
+        cuda = types.SimpleNamespace(empty_cache=lambda: None)
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*a, **k):
+            return cpu
+
+        @staticmethod
+        def load(path, *a, **k):
+            m = lm if "lidar" in str(path) else up
+            return {k2: v.clone() for k2, v in m.state_dict().items()}
+
+    ref_agent.torch = TorchProxy()
+    ref_agent.InferModel = lambda l, u, cx, cz: ref_mi.InferModel(l, u, cx, cz, device=cpu)
+    rec = {}
+
+    class Agent(ref_agent.LAVAgent):
+        def visualize(self, *a, **k):                      # debug video (OpenCV): not part of the path
+            return np.zeros((1, 1, 3), np.uint8)
+
+        def preprocess(self, lidar_xyzr, lidar_painted=None):
+            out = super().preprocess(lidar_xyzr, lidar_painted)
+            rec["pre_in"], rec["pre_out"] = t2n(lidar_xyzr), t2n(out)
+            return out
+
+        def get_stacked_lidar(self):
+            out = super().get_stacked_lidar()
+            rec["stacked"] = t2n(out)
+            rec["pose"] = (np.array(self.locs[-1], np.float64), float(self.oris[-1]))
+            return out
+
+    agent = Agent(os.path.join(REF, "team_code_v2", "config.yaml"))
+    sc = synth.agent_scenario()
+    agent.set_global_plan([({"lat": la, "lon": lo, "z": 0.0}, RoadOption(int(c)))
+                           for la, lo, c in zip(sc["lat"], sc["lon"], sc["cmds"])])
+    real_infer = agent.infer_model.forward
+
+    def infer(lidar_points, nxps, cmd_value):
+        res = real_infer(lidar_points, nxps, cmd_value)
+        rec["nxp"], rec["cmd"] = t2n(nxps), int(cmd_value)
+        rec["ego_plan"], rec["ego_cast"] = t2n(res[1]), t2n(res[2])
+        rec["other_cast"], rec["other_cmds"] = t2n(res[3]), t2n(res[4])
+        rec["det1"] = np.array(res[6][1], np.float64).reshape(-1, 6)
+        return res
+    agent.infer_model.forward = infer
+    real_bra = agent.bra_model
+
+    def bra_hook(rgbs, tel):
+        out = real_bra(rgbs, tel)
+        rec["pred_bra"] = float(out)
+        return out
+    agent.bra_model = bra_hook
+
+    out = {"ticks": np.array([ticks]), "n_points": np.array([n_points])}
+    controls, poses, nxps, cmds, pred_bras, stack_rows, kept_rows = [], [], [], [], [], [], []
+    detail = {12, ticks - 1}        # ticks whose full tensors are stored (the stack holds 3 sweeps from tick 11 on)
+    for i in range(ticks):
+        rec.clear()
+        data = synth.agent_inputs(i, sc, n_points=n_points)
+        c = agent.run_step(data, i * 0.05)
+        controls.append([c.steer, c.throttle, c.brake])
+        if "stacked" not in rec:          # first tick: no inference (lav_agent_fast.py:230-232)
+            poses.append([np.nan] * 3); nxps.append([np.nan] * 2); cmds.append(-1); pred_bras.append(np.nan)
+            stack_rows.append(0); kept_rows.append(0)
+            continue
+        poses.append([rec["pose"][0][0], rec["pose"][0][1], rec["pose"][1]])
+        nxps.append(rec["nxp"]); cmds.append(rec["cmd"]); pred_bras.append(rec["pred_bra"])
+        stack_rows.append(len(rec["stacked"])); kept_rows.append(len(rec["pre_out"]))
+        out[f"t{i}/stacked_sum"] = rec["stacked"].astype(np.float64).sum(0)      # every tick: a cheap fingerprint
+        out[f"t{i}/ego_plan"] = rec["ego_plan"]
+        out[f"t{i}/ego_cast"] = rec["ego_cast"]
+        out[f"t{i}/det1"] = rec["det1"]
+        if i in detail:
+            out[f"t{i}/pre_in_crc"] = np.array([crc(rec["pre_in"])], np.int64)
+            out[f"t{i}/pre_keep"] = np.packbits(np.isin(np.arange(len(rec["pre_in"])), _kept_index(rec["pre_in"], rec["pre_out"])))
+            out[f"t{i}/stacked"] = rec["stacked"].astype(np.float32)
+            out[f"t{i}/other_cast"] = rec["other_cast"]
+            out[f"t{i}/other_cmds"] = rec["other_cmds"]
+        print(f"agent tick {i}: controls {controls[-1]}, stacked {stack_rows[-1]} rows, cmd {cmds[-1]}", flush=True)
+    out.update(controls=np.array(controls, np.float64), poses=np.array(poses, np.float64), nxps=np.array(nxps, np.float64),
+               cmds=np.array(cmds), pred_bra=np.array(pred_bras, np.float64), stack_rows=np.array(stack_rows),
+               kept_rows=np.array(kept_rows))
+    # move_lidar_points on its own (lav_agent_fast.py:547-565)
+    xyz = torch.from_numpy(synth.lidar_sweep(2000, name="mlp")[:, :3].copy())
+    out["mlp_out"] = t2n(ref_agent.move_lidar_points(xyz, np.array([1.25, -0.4]) - np.array([0.5, 0.3]), 0.31, 0.27))
+    save("agent_fast", **out)
+
+
+def _kept_index(full, kept):
+    """Row indices of `full` that `kept` (an order-preserving sub-sequence of it) consists of."""
+    idx, j = [], 0
+    for i in range(len(full)):
+        if j < len(kept) and np.array_equal(full[i], kept[j]):
+            idx.append(i); j += 1
+    assert j == len(kept)
+    return np.array(idx)
 
 
 def gold_train():
@@ -342,6 +470,17 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["agent"]:     # only the host-glue fixture
         gold_agent()
         sys.exit(0)
+    if sys.argv[1:] == ["e2e"]:     # only the end-to-end fixture
+        lm, up = build_reference()
+        gold_e2e(lm, up)
+        sys.exit(0)
+    if sys.argv[1:] == ["rgb"]:     # only the camera-net fixture
+        gold_rgb()
+        sys.exit(0)
+    if sys.argv[1:] == ["agent_fast"]:     # only the reference-agent fixture
+        lm, up = build_reference()
+        gold_agent_fast(lm, up)
+        sys.exit(0)
     if sys.argv[1:] == ["train"]:     # only the training fixture
         gold_train()
         sys.exit(0)
@@ -354,3 +493,4 @@ if __name__ == "__main__":
     gold_e2e(lm, up)
     gold_rgb()
     gold_agent()
+    gold_agent_fast(lm, up)

@@ -78,3 +78,47 @@ def test_tick_larger_than_static_buffers_is_rejected(tmp_path):
     data = synth.agent_inputs(0, sc, n_points=9000)
     with pytest.raises(RuntimeError, match="exceeds the static graph buffers"):
         a.run_step(data, 0.0)
+
+
+@pytest.mark.parametrize("hip_graphs", [True, False])
+def test_agent_vs_reference_agent_golden(golden, tmp_path, hip_graphs):
+    """The REFERENCE AGENT (team_code_v2/lav_agent_fast.py, run on CPU by tests/golden/make_golden.py:gold_agent_fast)
+    and this agent drive the same 24 leaderboard ticks: run_step's controls, the stacked cloud handed to InferModel
+    (ego-box filter :450-457, stacking :363-383, move_lidar_points :547-565), the brake prediction, the detections and
+    both ego trajectories of every tick."""
+    g = golden["agent_fast"]
+    a, sc = _make(tmp_path, hip_graphs=hip_graphs)
+    ticks, npts = int(g["ticks"][0]), int(g["n_points"][0])
+    for i in range(ticks):
+        ctl = a.run_step(synth.agent_inputs(i, sc, n_points=npts), i * 0.05)
+        want = g["controls"][i]
+        assert abs(ctl.steer - want[0]) < 1e-3 and ctl.throttle == want[1] and ctl.brake == want[2], (i, ctl, want)
+        if i == 0:
+            continue
+        out = a.last_outputs
+        # pose handed to the stacking = the reference's EKF state before the tick
+        pose = a.pipeline.poses[-1] if hip_graphs else (a.pipeline.locs[-1], a.pipeline.oris[-1])
+        np.testing.assert_allclose(np.r_[pose[0], pose[1]], g["poses"][i], rtol=0, atol=1e-6)
+        if hip_graphs:
+            np.testing.assert_allclose(a.pipeline.b_nxp.cpu().numpy(), g["nxps"][i], rtol=1e-5, atol=1e-4)
+        assert abs(float(out["pred_bra"]) - g["pred_bra"][i]) < 1e-5
+        pts = out["lidar_points"].cpu().numpy()
+        pts = pts[~np.isnan(pts[:, 0])]                       # static graph buffers mark dropped rows with NaN
+        assert len(pts) == int(g["stack_rows"][i])
+        np.testing.assert_allclose(pts.astype(np.float64).sum(0), g[f"t{i}/stacked_sum"], rtol=2e-5, atol=0.5)
+        if f"t{i}/stacked" in g:
+            ref = g[f"t{i}/stacked"]
+            np.testing.assert_array_equal(pts[:, 3:4], ref[:, 3:4])
+            np.testing.assert_array_equal(pts[:, 8:], ref[:, 8:])
+            np.testing.assert_allclose(pts[:, :3], ref[:, :3], rtol=0, atol=2e-5)
+            # painted classes: softmax(ERFNet) values within float noise of the reference's; rows that differ by more are
+            # pixel-boundary flips of the projection (sgemm association, see oracle/paint.py)
+            flips = np.abs(pts[:, 4:8] - ref[:, 4:8]).max(1) > 1e-4
+            assert flips.mean() < 2e-3, f"tick {i}: {flips.sum()} painted rows differ"
+            np.testing.assert_allclose(out["other_cast_locs"].cpu().numpy(), g[f"t{i}/other_cast"], rtol=0, atol=2e-4)
+            np.testing.assert_allclose(out["other_cast_cmds"].cpu().numpy(), g[f"t{i}/other_cmds"], rtol=0, atol=1e-5)
+        ref_det = g[f"t{i}/det1"]
+        assert [tuple(d[:2]) for d in out["det"][1]] == [tuple(r[:2]) for r in ref_det], f"tick {i}: vehicle detections"
+        np.testing.assert_allclose(out["ego_plan_locs"].cpu().numpy(), g[f"t{i}/ego_plan"], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(out["ego_cast_locs"].cpu().numpy(), g[f"t{i}/ego_cast"], rtol=0, atol=2e-4)
+    a.destroy()

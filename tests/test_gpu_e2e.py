@@ -61,7 +61,7 @@ def test_planner_stages_vs_reference_golden(golden, models):
         assert_close(embd2.cpu().numpy(), g["embd2"], atol=3e-5, rtol=1e-4, what="ResNet-18 embeddings")
 
 
-@pytest.mark.parametrize("name,n,kind", [("a", 32768, "lidar"), ("b", 16384, "uniform")])
+@pytest.mark.parametrize("name,n,kind", [("a", 32768, "lidar"), ("b", 16384, "uniform"), ("c", 65536, "lidar")])
 def test_infer_model_forward_vs_reference_golden(golden, models, name, n, kind):
     """Full InferModel.forward: waypoints within 1e-4 of the reference PyTorch path (BASELINE.json)."""
     g = golden["e2e"]
@@ -86,8 +86,10 @@ def test_infer_model_forward_vs_reference_golden(golden, models, name, n, kind):
         assert oc.device.type == "cpu" and om.device.type == "cpu"   # reference returns CPU zeros (model_inference.py:167-168)
 
 
-def test_camera_nets_vs_reference_golden_and_torch_cpu(golden):
-    """ERFNet on the MFMA convolution vs the reference's logits; brake ResNet trunk vs the same module on torch CPU."""
+def test_camera_nets_vs_reference_golden(golden):
+    """ERFNet (logits and softmax) and the brake net stage by stage - both ResNet-18 trunks, both attention poolings,
+    the logit and the sigmoid - against the REFERENCE's modules (tests/golden/rgb.npz; team_code_v2/models/rgb.py:36-83,
+    lav/models/attention.py:21-38)."""
     from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
     g = golden["rgb"]
     seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval()
@@ -98,15 +100,26 @@ def test_camera_nets_vs_reference_golden_and_torch_cpu(golden):
     wide = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float()
     tel_rgb = torch.tensor(tel[..., :3][..., ::-1][:-96][None].copy()).permute(0, 3, 1, 2).float()
     with torch.no_grad():
-        cpu_trunk = bra.conv_backbone(bra.normalize(wide / 255.))
-        cpu_bra = bra(wide, tel_rgb)
         seg.to(DEV); bra.to(DEV)
         logits = seg(all_rgb.to(DEV))
         assert_close(logits[:, :, ::4, ::4].cpu().numpy(), g["logits_s"], atol=1e-5 * float(np.abs(g["logits_s"]).max()), rtol=1e-4, what="ERFNet logits")  # seeded weights give |logit| ~ 2e3
         assert_close(logits.double().sum((2, 3)).cpu().numpy(), g["logits_sum"], atol=0.5, rtol=1e-4, what="ERFNet logit sums")
-        gpu_trunk = bra.conv_backbone(bra.normalize(wide.to(DEV) / 255.))
-        assert_close(gpu_trunk.cpu().numpy(), cpu_trunk.numpy(), atol=1e-3, rtol=1e-4, what="brake ResNet-18 trunk")
-        assert_close(bra(wide.to(DEV), tel_rgb.to(DEV)).cpu().numpy(), cpu_bra.numpy(), atol=1e-5, what="pred_bra")
+        sem = torch.softmax(logits, dim=1)
+        # softmax is 1/2-Lipschitz in the max norm of the logits: with the seeded weights' |logit| ~ 2e3 the logit bar above
+        # (1e-5 relative) allows half that much here
+        assert_close(sem[:, :, ::4, ::4].cpu().numpy(), g["sem_s"], atol=0.5e-5 * float(np.abs(g["logits_s"]).max()), what="softmax(ERFNet)")
+        x1 = bra.conv_backbone(bra.normalize(wide.to(DEV) / 255.))
+        x2 = bra.conv_backbone(bra.normalize(tel_rgb.to(DEV) / 255.))
+        scale = float(np.abs(g["bra_x1_s"]).max())
+        assert_close(x1[:, ::8].cpu().numpy(), g["bra_x1_s"], atol=1e-5 * scale, rtol=1e-4, what="brake trunk (3 views)")
+        assert_close(x2[:, ::8].cpu().numpy(), g["bra_x2_s"], atol=1e-5 * scale, rtol=1e-4, what="brake trunk (tele)")
+        h1, h2 = bra.attn1(x1), bra.attn2(x2)
+        hs = float(np.abs(g["bra_h1"]).max())
+        assert_close(h1.cpu().numpy(), g["bra_h1"], atol=1e-5 * hs, rtol=1e-4, what="attention pooling 1")
+        assert_close(h2.cpu().numpy(), g["bra_h2"], atol=1e-5 * hs, rtol=1e-4, what="attention pooling 2")
+        logit = bra.classifier[0](torch.cat([h1, h2], dim=1))
+        assert_close(logit.cpu().numpy(), g["bra_logit"], atol=1e-4, what="brake logit")
+        assert_close(bra(wide.to(DEV), tel_rgb.to(DEV)).cpu().numpy(), g["pred_bra"], atol=1e-5, what="pred_bra")
 
 
 def test_graphed_frame_pipeline_matches_eager(models):

@@ -149,3 +149,54 @@ def test_c_oracle_matches_reference(golden, name):
     np.testing.assert_array_equal(out["inverse"], g[f"{name}/inverse"])
     ref = opillar.scatter_points(g[f"{name}/feat"], g[f"{name}/unique_coords"].astype(np.int64), 1, 320, 320)
     assert_close(out["canvas"], ref, atol=3e-6, rtol=1e-5, what="C oracle canvas")
+
+
+def test_frame_glue_oracle_matches_reference_agent(golden):
+    """oracle/paint.preprocess, oracle/bev.move_lidar_points and oracle/frame.stack against what the REFERENCE AGENT
+    (team_code_v2/lav_agent_fast.py driven by tests/golden/make_golden.py:gold_agent_fast) computed on the same
+    ticks: the ego-box filter (:450-457) row for row, and the stacked cloud handed to InferModel (:363-383,547-565)."""
+    from oracle import frame as oframe
+    from lav_amd.rgb import RGBSegmentationModel
+    g = golden["agent_fast"]
+    sc = synth.agent_scenario()
+    npts = int(g["n_points"][0])
+    # move_lidar_points on its own
+    xyz = torch.from_numpy(synth.lidar_sweep(2000, name="mlp")[:, :3].copy())
+    out = obev.move_lidar_points(xyz, np.array([1.25, -0.4]) - np.array([0.5, 0.3]), 0.31, 0.27)
+    np.testing.assert_array_equal(out.numpy(), g["mlp_out"])
+    # the agent's history up to tick 12: ego-box filter, ERFNet + softmax, painting, stacking
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval()
+    hist = dict(lidars=[], locs=[], oris=[])
+    prev = None
+    with torch.no_grad():
+        for i in range(13):
+            data = synth.agent_inputs(i, sc, n_points=npts)
+            tick = np.asarray(data["LIDAR"][1], np.float32)
+            if prev is None:
+                prev = tick
+                continue
+            merged = np.concatenate([tick, prev])
+            prev = tick
+            cur = opaint.preprocess(merged)
+            assert len(cur) == int(g["kept_rows"][i])
+            if f"t{i}/pre_keep" in g:
+                assert crc(merged) == int(g[f"t{i}/pre_in_crc"][0])
+                keep = np.unpackbits(g[f"t{i}/pre_keep"])[: len(merged)].astype(bool)
+                np.testing.assert_array_equal(cur, merged[keep])
+            rgbs = [np.asarray(data[f"RGB_{k}"][1])[..., :3][..., ::-1] for k in range(3)]
+            all_rgbs = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float()
+            sem = torch.softmax(seg(all_rgbs), dim=1).numpy()
+            hist["lidars"].append(opaint.forward_paint(cur, sem))
+            hist["locs"].append(g["poses"][i][:2].copy()); hist["oris"].append(float(g["poses"][i][2]))
+            for k in hist:
+                del hist[k][:-15]
+            stacked = oframe.stack(hist["lidars"], hist["locs"], hist["oris"])
+            assert len(stacked) == int(g["stack_rows"][i])
+            np.testing.assert_allclose(stacked.astype(np.float64).sum(0), g[f"t{i}/stacked_sum"], rtol=2e-5, atol=0.5)
+    ref = g["t12/stacked"]
+    np.testing.assert_array_equal(stacked[:, 3:4], ref[:, 3:4])          # intensity: untouched
+    np.testing.assert_array_equal(stacked[:, 8:], ref[:, 8:])            # one-hot time
+    np.testing.assert_allclose(stacked[:, :3], ref[:, :3], rtol=0, atol=2e-5)
+    # painted classes: identical except at pixel-boundary flips of the projection (sgemm association, see oracle/paint.py)
+    diff = np.abs(stacked[:, 4:8] - ref[:, 4:8]).max(1) > 1e-6
+    assert diff.mean() < 2e-3, f"{diff.sum()} of {len(diff)} painted rows differ"
