@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 9
+#define LAV_ABI_VERSION 10
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -148,6 +148,21 @@ int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, in
                  const float *mlp_w, const float *mlp_b, float *out,
                  void *workspace, size_t workspace_bytes, void *stream);
 size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T);
+/*
+ * lav_gru_plan runs all iters*T dependent steps in ONE persistent launch when B*(1 or num_cmds) <= 6: its H/8 workgroups
+ * exchange the hidden state through HBM and must be co-resident.  Every wait is bounded; a launch that times out (the chip
+ * oversubscribed by other streams) fills the WHOLE `out` with NaN and raises the status word of its workspace:
+ *   lav_gru_plan_status  copies that word to *h_status (0 = completed, 1 = aborted) - it SYNCHRONISES `stream`;
+ *   lav_gru_plan_steps   same contract as lav_gru_plan on the step-per-launch path (no co-residency requirement, ~10 % slower):
+ *                        what a caller runs after an abort.
+ */
+int lav_gru_plan_status(const void *workspace, size_t workspace_bytes, int B, int H, int num_cmds, int cmd,
+                        int *h_status, void *stream);
+int lav_gru_plan_steps(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds, int T,
+                       int iters, int cmd, float pixels_per_meter, float crop_size,
+                       const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                       const float *mlp_w, const float *mlp_b, float *out,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. 2-D convolutions on the matrix cores (fp32-in / fp32-accumulate MFMA: exact fp32 products,

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_CAM = 4
 
 
@@ -54,6 +54,8 @@ SIGNATURES = {
     "lav_gru_cast": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_cast_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "lav_gru_plan": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_gru_plan_steps": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_gru_plan_status": (_I, [_P, _Z, _I, _I, _I, _I, C.POINTER(_I), _P]),
     "lav_gru_plan_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "lav_conv_out_hw": (_I, [C.POINTER(Conv), C.POINTER(_I), C.POINTER(_I)]),
     "lav_conv_packed_weight_floats": (_Z, [C.POINTER(Conv)]),

@@ -263,11 +263,15 @@ __global__ __launch_bounds__(64 * OUT_WAVES) void k_plan_out(PlanArgs a, int it)
 // the data is the flag, so no fences and no separate counters (MI355X guide, guideline 16 form R2).  Two granule
 // buffers alternate; a workgroup can only be one step ahead of the slowest one, so a buffer is never overwritten while
 // still being read.  Every workgroup re-derives the waypoints (Linear(512->2) + cumsum) itself because it needs them
-// as GRU inputs in the next iteration; workgroup 0 also writes them out.  Spins are bounded: on timeout the kernel
-// raises a flag, stops waiting and the host-visible status word reports it.
+// as GRU inputs in the next iteration; workgroup 0 also writes them out.  Spins are bounded: a workgroup that times out
+// (its peers are not co-resident, e.g. the chip is oversubscribed by other streams) stops waiting, sets the status word
+// of the workspace (lav_gru_plan_status) and overwrites the WHOLE output with NaN, so that a plan that was not computed
+// can never be mistaken for one: the reference agent's own rule for NaN waypoints (no steering, no throttle,
+// lav_agent_fast.py:325-328) applies, and lav_gru_plan_steps recomputes it without any co-residency requirement.
 constexpr long long PLAN_SPIN_LIMIT = 1ll << 22;
 
-__global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status) {
+__global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status,
+                                                         long long spin_limit) {
     const int H = a.H, T = a.T, R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = H / 64;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                     }
                     ok = __all(ok);
                     if (!ok) {
-                        if (++spins > PLAN_SPIN_LIMIT || *(volatile int *)&abort_s) {
+                        if (++spins > spin_limit || *(volatile int *)&abort_s) {
                             abort_s = 1;
                             if (lane == 0) atomicExch(status, 1);
                             break;
@@ -362,7 +366,11 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                         __builtin_amdgcn_s_sleep(2);
                     }
                 } while (!ok);
-                if (*(volatile int *)&abort_s) return;  // give up: never hang the device
+                if (*(volatile int *)&abort_s) {  // give up: never hang the device, never return a plan that was not computed
+                    const long n_out = (long)a.B * a.iters * a.NC * T * 2;
+                    for (long i = tid; i < n_out; i += 256) a.out[i] = __uint_as_float(0x7fc00000u);
+                    return;
+                }
                 // waypoint t-1 of this iteration from h_{t-1} (every workgroup needs it as next iteration's input)
                 if (wid == 0) {
 #pragma unroll
@@ -471,10 +479,11 @@ extern "C" size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T
     return lav::align_up(seq > gran ? seq : gran, 256);
 }
 
-extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds,
-                            int T, int iters, int cmd, float pixels_per_meter, float crop_size, const float *w_ih,
-                            const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
-                            const float *mlp_b, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+int plan_launch(bool allow_persistent, const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds,
+                int T, int iters, int cmd, float pixels_per_meter, float crop_size, const float *w_ih,
+                const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
+                const float *mlp_b, float *out, void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(B >= 0 && num_cmds > 0 && T > 0 && T <= 64 && iters > 0, "lav_gru_plan: bad sizes");
     LAV_REQUIRE(H % 64 == 0 && H <= 64 * PLAN_MAXK && H % PLAN_UNITS == 0, "lav_gru_plan: hidden size %d unsupported", H);
     LAV_REQUIRE(cmd >= -1 && cmd < num_cmds, "lav_gru_plan: cmd %d out of range", cmd);
@@ -493,14 +502,16 @@ extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *ca
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("gru_plan", st);
     const char *impl = getenv("LAV_PLAN_IMPL");
-    if (a.R <= PLAN_RC && !(impl && impl[0] == 's')) {
+    if (allow_persistent && a.R <= PLAN_RC && !(impl && impl[0] == 's')) {
         // persistent kernel: needs its H/8 workgroups co-resident (64 of 256 CUs) - always true on an MI355X
         const size_t gbytes = 2 * (size_t)a.R * H * sizeof(unsigned long long);
         LAV_REQUIRE(workspace_bytes >= gbytes + 256, "lav_gru_plan: workspace too small for the persistent kernel");
         unsigned long long *gran = static_cast<unsigned long long *>(workspace);
         int *status = reinterpret_cast<int *>(static_cast<char *>(workspace) + lav::align_up(gbytes, 256));
         LAV_HIP(hipMemsetAsync(workspace, 0, lav::align_up(gbytes, 256) + 4, st));  // tags and status start at 0
-        hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status);
+        const char *lim = getenv("LAV_PLAN_SPIN_LIMIT");   // test knob: 1 forces the time-out path
+        const long long spin_limit = lim && atoll(lim) > 0 ? atoll(lim) : PLAN_SPIN_LIMIT;
+        hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit);
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
         return LAV_OK;
@@ -513,5 +524,37 @@ extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *ca
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+}  // namespace
+
+extern "C" int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds,
+                            int T, int iters, int cmd, float pixels_per_meter, float crop_size, const float *w_ih,
+                            const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
+                            const float *mlp_b, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return plan_launch(true, embd, nxp, cast_locs, B, H, num_cmds, T, iters, cmd, pixels_per_meter, crop_size, w_ih, w_hh, b_ih, b_hh,
+                       mlp_w, mlp_b, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lav_gru_plan_steps(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds,
+                                  int T, int iters, int cmd, float pixels_per_meter, float crop_size, const float *w_ih,
+                                  const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
+                                  const float *mlp_b, float *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return plan_launch(false, embd, nxp, cast_locs, B, H, num_cmds, T, iters, cmd, pixels_per_meter, crop_size, w_ih, w_hh, b_ih, b_hh,
+                       mlp_w, mlp_b, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lav_gru_plan_status(const void *workspace, size_t workspace_bytes, int B, int H, int num_cmds, int cmd,
+                                   int *h_status, void *stream) {
+    LAV_REQUIRE(workspace && h_status, "lav_gru_plan_status: null argument");
+    LAV_REQUIRE(B >= 1 && H > 0 && num_cmds > 0 && cmd >= -1 && cmd < num_cmds, "lav_gru_plan_status: bad sizes");
+    const int R = B * (cmd >= 0 ? 1 : num_cmds);
+    *h_status = 0;
+    if (R > PLAN_RC) return LAV_OK;   // the step-per-launch path has no spin loops
+    const size_t off = lav::align_up(2 * (size_t)R * H * sizeof(unsigned long long), 256);
+    LAV_REQUIRE(workspace_bytes >= off + 4, "lav_gru_plan_status: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LAV_HIP(hipMemcpyAsync(h_status, static_cast<const char *>(workspace) + off, sizeof(int), hipMemcpyDeviceToHost, st));
+    LAV_HIP(hipStreamSynchronize(st));
     return LAV_OK;
 }

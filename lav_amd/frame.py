@@ -169,6 +169,7 @@ class GraphedFramePipeline(FramePipeline):
             trunk._drop()
         self.graphs, self.outs = {}, {}
         self.frame_no = 0
+        self.plan_aborts = 0          # frames whose persistent plan launch timed out and was recomputed (recover_plan)
         self.poses = deque()
 
     def reset(self):
@@ -321,6 +322,23 @@ class GraphedFramePipeline(FramePipeline):
         return dict(ego_embd=o_ego["ego_embd"], ego_plan_locs=o_ego["ego_plan_locs"], ego_cast_locs=o_ego["ego_cast_locs"],
                     other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=o_heads["pred_bev"],
                     det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])
+
+    @torch.no_grad()
+    def recover_plan(self, out, cmd_value):
+        """Called by the consumer of step()'s result when `ego_plan_locs` holds NaN: if the persistent plan kernel gave up
+        (its 64 workgroups were not co-resident beside the other streams' work - status word of its workspace), warn and
+        recompute this frame's plan on the step-per-launch path, which has no such requirement.  Returns the waypoints."""
+        up = self.infer_model.uniplanner
+        status = ops.gru_plan_status(1, up.plan_gru.hidden_size, up.num_cmds, int(cmd_value), self.device, stream=self.s_ego)
+        if status == 0:
+            return out["ego_plan_locs"]          # NaN from the network itself: the reference's rule for it applies
+        import warnings
+        warnings.warn("lav_gru_plan: the persistent plan kernel timed out (GPU oversubscribed); recomputing on the step path")
+        ego_cast = up.cast(out["ego_embd"], mode="ego")
+        plan = up.plan(out["ego_embd"], self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
+                       crop_size=up.crop_size * 2, cmd=int(cmd_value), impl="steps")[0, -1, 0]
+        self.plan_aborts += 1
+        return plan
 
     @torch.no_grad()
     def precapture(self, cmds=range(6), max_others=4):

@@ -198,6 +198,11 @@ class LAVAgent(AutonomousAgent):
         out = self.pipeline.step(lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value)
         self.last_outputs = out
         ego_plan_locs = out["ego_plan_locs"].cpu().numpy()
+        if np.isnan(ego_plan_locs).any() and hasattr(self.pipeline, "recover_plan"):
+            # NaN waypoints are either the network's own (then the reference's rule below applies) or the mark of a
+            # persistent plan launch that gave up waiting: that one is recomputed, loudly, on the step path
+            out["ego_plan_locs"] = self.pipeline.recover_plan(out, cmd_value)
+            ego_plan_locs = out["ego_plan_locs"].cpu().numpy()
         ego_cast_locs = out["ego_cast_locs"].cpu().numpy()
         other_cast_locs = out["other_cast_locs"].cpu().numpy()
         other_cast_cmds = out["other_cast_cmds"].cpu().numpy()

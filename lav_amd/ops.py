@@ -195,8 +195,10 @@ def gru_cast(embd, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, T: int):
 
 
 def gru_plan(embd, nxp, cast_locs, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, iters: int, cmd: int, ppm: float,
-             crop_size: float):
-    """embd (B,H), nxp (B,2), cast_locs (B,num_cmds,T,2) -> (B, iters, num_cmds or 1, T, 2)."""
+             crop_size: float, impl: str = "auto"):
+    """embd (B,H), nxp (B,2), cast_locs (B,num_cmds,T,2) -> (B, iters, num_cmds or 1, T, 2).
+    impl "auto": the persistent one-launch kernel when it applies (a launch that could not complete returns NaN and
+    raises gru_plan_status); "steps": one launch per GRU step, no co-residency requirement."""
     lib = _lib.load()
     embd = _f32c(embd, "embd")
     nxp = _f32c(nxp, "nxp")
@@ -207,10 +209,27 @@ def gru_plan(embd, nxp, cast_locs, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, iters: 
     out = torch.empty((B, iters, nc, T, 2), dtype=torch.float32, device=embd.device)
     nbytes = lib.lav_gru_plan_workspace_bytes(B, H, ncmd, T)
     ws = _workspace("plan", nbytes, embd.device)
-    check(lib.lav_gru_plan(_ptr(embd), _ptr(nxp), _ptr(cast_locs), B, H, ncmd, T, iters, cmd, float(ppm),
-                           float(crop_size), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(mlp_w), _ptr(mlp_b),
-                           _ptr(out), _ptr(ws), ws.numel(), _stream()), "lav_gru_plan")
+    fn = {"auto": lib.lav_gru_plan, "steps": lib.lav_gru_plan_steps}[impl]
+    check(fn(_ptr(embd), _ptr(nxp), _ptr(cast_locs), B, H, ncmd, T, iters, cmd, float(ppm),
+             float(crop_size), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(mlp_w), _ptr(mlp_b),
+             _ptr(out), _ptr(ws), ws.numel(), _stream()), "lav_gru_plan")
     return out
+
+
+def gru_plan_status(B: int, H: int, num_cmds: int, cmd: int, device, stream=None) -> int:
+    """Status word of the last gru_plan launch on `stream` (default: the current one) with these sizes: 0 = completed,
+    1 = the persistent kernel gave up waiting for its peers and returned NaN.  Synchronises that stream."""
+    lib = _lib.load()
+    st = stream if stream is not None else torch.cuda.current_stream()
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ws = _workspaces.get(("plan", device, st.cuda_stream))
+    if ws is None:
+        return 0
+    status = C.c_int(0)
+    check(lib.lav_gru_plan_status(_ptr(ws), ws.numel(), B, H, num_cmds, cmd, C.byref(status), st.cuda_stream), "lav_gru_plan_status")
+    return int(status.value)
 
 
 # ------------------------------------------------------------------------------------------ conv

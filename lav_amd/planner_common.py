@@ -116,16 +116,16 @@ class DecoderMixin:
         w = self._dec(embd.device)["cast"]
         return ops.gru_cast(embd, w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"], w["mlp_b"], self.num_plan)
 
-    def plan(self, embd, nxp, cast_locs=None, pixels_per_meter=4, crop_size=96, cmd: int = -1):
+    def plan(self, embd, nxp, cast_locs=None, pixels_per_meter=4, crop_size=96, cmd: int = -1, impl: str = "auto"):
         """(B,512),(B,2),(B,num_cmds,T,2) -> (B, num_plan_iter, num_cmds, T, 2)  (uniplanner.py:255-286).
-        cmd >= 0 evaluates only that command branch and returns (B, iters, 1, T, 2)."""
+        cmd >= 0 evaluates only that command branch and returns (B, iters, 1, T, 2).  impl: see ops.gru_plan."""
         if cast_locs is None:
             cast_locs = self.cast(embd)
         if self.training:
             return self._plan_torch(embd, nxp, cast_locs.detach(), pixels_per_meter, crop_size, cmd)
         w = self._dec(embd.device)["plan"]
         return ops.gru_plan(embd, nxp, cast_locs.detach(), w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"],
-                            w["mlp_b"], self.num_plan_iter, cmd, pixels_per_meter, crop_size)
+                            w["mlp_b"], self.num_plan_iter, cmd, pixels_per_meter, crop_size, impl=impl)
 
     # ---- train mode: the same decoders as differentiable torch ops (uniplanner.py:255-308) ----------------------
     def _cast_torch(self, embd):

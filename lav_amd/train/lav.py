@@ -77,11 +77,15 @@ def _scalars(loss, terms):
     return dict(loss=vals[0], **dict(zip(keys, vals[1:])))
 
 
-def _ddp(module, device):
+def _ddp(module, device, find_unused=False):
+    """find_unused: the student's autograd graph is not the same on every rank and step - a shard without an eligible
+    vehicle leaves cast_cmd_pred out of the loss (UniPlanner.forward's `pick is None` branch), --perceive-only leaves the
+    whole planner out - and DistributedDataParallel would otherwise wait for those gradients for ever."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return module
     ids = [device.index] if device.type == "cuda" else None
-    return nn.parallel.DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=32, gradient_as_bucket_view=True)
+    return nn.parallel.DistributedDataParallel(module, device_ids=ids, bucket_cap_mb=32, gradient_as_bucket_view=True,
+                                               find_unused_parameters=find_unused)
 
 
 class LAV:
@@ -148,7 +152,7 @@ class LAV:
         self.lidar_scheduler = StepLR(self.lidar_optim, step_size=4, gamma=0.5)
         self.det_criterion = DetLoss()
         self.seg_mask = build_seg_mask(h=H, w=W, cx=self.bev_center[0], cy=self.bev_center[1]).to(self.device)
-        self.student_ddp = _ddp(self.student, self.device)
+        self.student_ddp = _ddp(self.student, self.device, find_unused=True)
 
     def state_dict(self, model_name):
         return {"bev": self.bev_planner, "lidar": getattr(self, "lidar_model", None),

@@ -66,25 +66,97 @@ def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log
     return dt, info, (rank, world)
 
 
+def load_config(path, **overrides) -> TrainConfig:
+    """TrainConfig from the reference's YAML (config_v2.yaml): every key that TrainConfig has is taken from the file,
+    the others (data paths, controller gains ...) are not part of the training step.  `distill` is read by
+    lav_final_v2.py:244 but absent from config_v2.yaml (team_code_v2/config.yaml:11 says True): injected as True."""
+    import dataclasses
+    import yaml
+    fields = {f.name for f in dataclasses.fields(TrainConfig)}
+    vals = {}
+    if path:
+        with open(path, "r") as f:
+            raw = yaml.safe_load(f) or {}
+        vals = {k: v for k, v in raw.items() if k in fields}
+    vals.setdefault("distill", True)
+    vals.update({k: v for k, v in overrides.items() if v is not None})
+    return TrainConfig(**vals)
+
+
+def other_weight_schedule(it, beta=0.8):
+    """lav/train_bev_v2.py:38-39"""
+    return 1 - beta ** (it / 4000)
+
+
 def main(what):
+    """Command line of lav/train_full_v2.py:48-70 / lav/train_bev_v2.py:42-63 (same flags and defaults) plus what this
+    build adds: --synthetic / --steps-per-epoch (seeded synthetic batches stand in for the LMDB loaders, which need the
+    `lmdb` package), --save-dir, --lidar / --bev / --uniplanner (checkpoints to start from), --max-points, --log-every."""
     ap = argparse.ArgumentParser()
-    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic batches (the only data source wired up)")
-    ap.add_argument("--batch-size", type=int, default=64 if what == "bev" else 32, help="GLOBAL batch")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lr", type=float, default=3e-4)
-    ap.add_argument("--max-points", type=int, default=None)
+    ap.add_argument("--config-path", default=None, help="the reference's config_v2.yaml (training keys are read from it)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
     ap.add_argument("--perceive-only", action="store_true")
     ap.add_argument("--motion-only", action="store_true")
+    ap.add_argument("--num-epoch", type=int, default=64 if what == "lidar" else 160)
+    ap.add_argument("--num-per-log", type=int, default=100, help="log per iter")
+    ap.add_argument("--num-per-save", type=int, default=1, help="save per epoch")
+    ap.add_argument("--batch-size", type=int, default=32 if what == "lidar" else 256, help="GLOBAL batch, split over the ranks")
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--weight-decay", type=float, default=2e-4, help="accepted for command-line compatibility; the reference never passes it to Adam")
+    ap.add_argument("--num-workers", type=int, default=16, help="accepted for command-line compatibility (synthetic batches need no workers)")
     ap.add_argument("--seed", type=int, default=2021)
+    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic batches (the only data source wired up)")
+    ap.add_argument("--steps-per-epoch", type=int, default=20, help="iterations that make one epoch of synthetic data")
+    ap.add_argument("--save-dir", default="checkpoints")
+    ap.add_argument("--lidar", default=None, help="lidar_*.th to start from")
+    ap.add_argument("--bev", default=None, help="bev_*.th to start from / the teacher of train_full_v2")
+    ap.add_argument("--uniplanner", default=None, help="uniplanner_*.th to start from")
+    ap.add_argument("--max-points", type=int, default=None)
+    ap.add_argument("--log-every", type=int, default=None, help="steps between the eval-mode log inference (default: --num-per-log)")
     args = ap.parse_args()
     if not args.synthetic:
-        raise SystemExit("only --synthetic batches are available in this build (no LMDB reader yet)")
-    cfg = TrainConfig(lr=args.lr, perceive_only=args.perceive_only, motion_only=args.motion_only, seed=args.seed)
-    dt, info, (rank, world) = train_loop(what, args.batch_size, args.steps, args.warmup, cfg, args.max_points,
-                                         log=lambda i, inf: print(i, {k: round(v, 4) for k, v in inf.items() if isinstance(v, float)}, flush=True))
+        raise SystemExit("only --synthetic batches are wired up: the LMDB readers of lav/utils/datasets need the `lmdb` "
+                         "package, which this image does not have")
+    rank, world, device = setup_distributed()
+    if args.device == "cpu":
+        device = torch.device("cpu")
+    cfg = load_config(args.config_path, lr=args.lr, perceive_only=args.perceive_only, motion_only=args.motion_only, seed=args.seed,
+                      log_every=args.log_every if args.log_every is not None else args.num_per_log)
+    if args.batch_size % world:
+        raise SystemExit(f"global batch {args.batch_size} is not divisible by {world} ranks")
+    per_rank = args.batch_size // world
+    ck = {k: torch.load(v, map_location="cpu") for k, v in (("lidar", args.lidar), ("bev", args.bev), ("uniplanner", args.uniplanner)) if v}
+    torch.manual_seed(cfg.seed + rank)
+    lav = LAV(cfg, device, what=what, checkpoints=ck)
+    log = lambda it, inf: print(it, {k: round(v, 4) for k, v in inf.items() if isinstance(v, float)}, flush=True)
+    global_it, t0 = 0, time.perf_counter()
+    for epoch in range(args.num_epoch):
+        for it in range(args.steps_per_epoch):
+            seed = cfg.seed + 1000003 * epoch + 1009 * it + 100 * rank
+            if what == "bev":
+                batch = synthetic_bev_batch(per_rank, seed=seed, device=device)
+                info = lav.train_bev(*batch, other_weight=other_weight_schedule(global_it))
+            else:
+                batch = synthetic_lidar_batch(per_rank, seed=seed, max_points=args.max_points or cfg.max_lidar_points, device=device)
+                info = lav.train_lidar(*batch)
+            if global_it % args.num_per_log == 0 and rank == 0:
+                log(global_it, info)
+            global_it += 1
+        (lav.bev_scheduler if what == "bev" else lav.lidar_scheduler).step()       # once per epoch (train_full_v2.py:33)
+        if (epoch + 1) % args.num_per_save == 0 and rank == 0:
+            os.makedirs(args.save_dir, exist_ok=True)
+            for name in (("bev",) if what == "bev" else ("lidar", "uniplanner")):
+                path = os.path.join(args.save_dir, f"{name}_{epoch + 1}.th")
+                torch.save(lav.state_dict(name), path)
+                print(f"saved to {path}", flush=True)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps(dict(what=what, samples_per_s=round(args.batch_size * args.steps / dt, 2), n_gpus=world,
-                              global_batch=args.batch_size, steps=args.steps, s_per_step=round(dt / args.steps, 4))))
+        print(json.dumps(dict(what=what, samples_per_s=round(args.batch_size * global_it / dt, 2), n_gpus=world,
+                              global_batch=args.batch_size, steps=global_it, epochs=args.num_epoch,
+                              lr=(lav.bev_optim if what == "bev" else lav.lidar_optim).param_groups[0]["lr"],
+                              scheduler_epochs=(lav.bev_scheduler if what == "bev" else lav.lidar_scheduler).last_epoch)))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()

@@ -457,6 +457,58 @@ def gold_train():
         torch.set_grad_enabled(False)
 
 
+def gold_train_curve(steps=None):
+    """BASELINE.json config #5 asks for a loss-curve match over 500 steps: the REFERENCE trainer (lav/lav_final_v2.py
+    `train_lidar`, the loop of lav/train_full_v2.py:24-46) on CPU over `steps` optimisation steps, cycling through four
+    seeded synthetic batches of 2 samples (20 000-point clouds), global torch seed re-set per step like gold_train.
+    Stores every loss term of every step (tests/golden/train_curve.npz)."""
+    import types
+    sys.path.insert(0, REF)
+    import lav.lav_final_v2 as ref_final  # noqa: E402  (reference)
+    import lav_amd
+    from lav_amd.train import TrainConfig, synthetic_lidar_batch
+    from lav_amd.train.lav import LAV as OurLAV
+    steps = steps or int(os.environ.get("LAV_CURVE_STEPS", "500"))
+    torch.set_grad_enabled(True)
+    ours = OurLAV(TrainConfig(), "cpu", what="bev")
+    bev_sd = {k: v.clone() for k, v in ours.bev_planner.state_dict().items()}
+    lm = lav_amd.LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **CFG)
+    lidar_sd = synth.seeded_state_dict(lm, prefix="lidar.")
+    y_off = 1 + CFG["min_x"] / ((CFG["max_x"] - CFG["min_x"]) / 2)
+    up = lav_amd.UniPlanner(ours.bev_planner, pixels_per_meter=4, crop_size=96, feature_x_jitter=1.5, feature_angle_jitter=20,
+                            x_offset=0, y_offset=y_off, num_cmds=6, num_plan=20, num_input_feature=384, num_plan_iter=5)
+    uni_sd = synth.seeded_state_dict(up, prefix="uni.")
+    uni_sd.update({"bev_planner." + k: v for k, v in bev_sd.items()})
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):
+        path = str(path)
+        return {k2: v.clone() for k2, v in (bev_sd if "bev" in path else lidar_sd if "lidar" in path else uni_sd).items()}
+
+    args = types.SimpleNamespace(config_path=os.path.join(REF, "config_v2.yaml"), device="cpu", lr=3e-4, perceive_only=False,
+                                 motion_only=False)
+    torch.load = fake_load
+    try:
+        trainer = ref_final.LAV(args)
+        trainer.distill = True
+        batches = [synthetic_lidar_batch(2, seed=40 + i, max_points=20000, num_objs=3) for i in range(4)]
+        keys = ("hm_loss", "box_loss", "ori_loss", "seg_loss", "plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
+        rows = []
+        import time
+        t0 = time.time()
+        for step in range(steps):
+            torch.manual_seed(1000 + step)
+            info = trainer.train_lidar(*batches[step % 4])
+            rows.append([info[k] for k in keys])
+            if step % 10 == 0:
+                print(f"curve step {step}: {[round(v, 4) for v in rows[-1]]}  ({time.time() - t0:.0f} s)", flush=True)
+                save("train_curve", terms=np.array(rows), keys=np.array(keys))
+        save("train_curve", terms=np.array(rows), keys=np.array(keys))
+    finally:
+        torch.load = real_load
+        torch.set_grad_enabled(False)
+
+
 def gold_keys(lm, up):
     import json
     seg = RGBSegmentationModel([4, 6, 7, 10]); bra = RGBBrakePredictionModel([4, 6, 7, 10])
@@ -480,6 +532,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["agent_fast"]:     # only the reference-agent fixture
         lm, up = build_reference()
         gold_agent_fast(lm, up)
+        sys.exit(0)
+    if sys.argv[1:] == ["train_curve"]:     # only the loss-curve fixture (hours of CPU time)
+        gold_train_curve()
         sys.exit(0)
     if sys.argv[1:] == ["train"]:     # only the training fixture
         gold_train()

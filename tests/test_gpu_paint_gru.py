@@ -86,3 +86,29 @@ def test_gru_vs_oracle_other_batch(models):
         ref = obev.cast(embd, usd)
     assert_close(up.cast(embd.to(DEV)).cpu().numpy(), ref.numpy(), atol=2e-5, what="cast B=15")
     assert up.cast(torch.zeros((0, 512), device=DEV)).shape == (0, 6, 20, 2)
+
+
+def test_plan_timeout_is_loud_and_recoverable(golden, monkeypatch):
+    """A persistent plan launch that cannot complete (forced here by a spin limit of 1: a workgroup gives up the first time
+    a peer's hidden state has not arrived yet) must never look like a plan: the whole output is NaN, the status word of the
+    workspace says so, and the step-per-launch entry point recomputes the reference's waypoints."""
+    g = golden["planner"]
+    _, up = build_models(DEV)
+    embd = torch.from_numpy(g["ego_embd"]).to(DEV).view(1, -1)
+    nxp = torch.from_numpy(g["nxp"]).to(DEV).view(1, 2)
+    cast = up.cast(embd, mode="ego")
+    good = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=3)
+    torch.cuda.synchronize()
+    assert ops.gru_plan_status(1, 512, 6, 3, DEV) == 0 and torch.isfinite(good).all()
+    monkeypatch.setenv("LAV_PLAN_SPIN_LIMIT", "1")
+    bad = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=3)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("LAV_PLAN_SPIN_LIMIT")
+    assert ops.gru_plan_status(1, 512, 6, 3, DEV) == 1, "a launch that gave up must raise the status word"
+    assert torch.isnan(bad).all(), "and must not return anything that could pass for waypoints"
+    again = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=3, impl="steps")
+    torch.cuda.synchronize()
+    assert_close(again.cpu().numpy(), good.cpu().numpy(), atol=2e-5, what="step path after an abort")
+    back = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=3)
+    torch.cuda.synchronize()
+    assert ops.gru_plan_status(1, 512, 6, 3, DEV) == 0 and torch.equal(back, good)

@@ -49,3 +49,36 @@ def test_world_size_2_gloo_data_parallel_train_step():
                           "127.0.0.1", "--master-port", "29617", os.path.join(REPO, "tests", "_gloo_train_worker.py")],
                          capture_output=True, text=True, timeout=600)
     assert "DDP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_world_size_2_gloo_train_lidar_student_with_unused_parameters():
+    """train_lidar through _Student + DistributedDataParallel, one rank without any vehicle (parameters that
+    take no gradient on one rank must not stall the all-reduce)."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29631", os.path.join(REPO, "tests", "_gloo_train_lidar_worker.py")],
+                         capture_output=True, text=True, timeout=900)
+    assert "DDP_LIDAR_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_train_driver_epochs_scheduler_checkpoints(tmp_path):
+    """train_bev_v2.py's loop (lav/train_bev_v2.py:18-34): epochs, StepLR stepped once per epoch, a checkpoint per
+    --num-per-save epochs under the reference's file names, --config-path, resuming from a checkpoint."""
+    import json
+    import yaml
+    cfgp = tmp_path / "config_v2.yaml"
+    cfgp.write_text(yaml.safe_dump(dict(num_plan=20, num_cmds=6, cmd_weight=0.1, branch_weights=[5, 5, 5, 1, 1, 1], camera_x=1.5)))
+    base = [sys.executable, os.path.join(REPO, "train_bev_v2.py"), "--synthetic", "--device", "cpu", "--config-path", str(cfgp),
+            "--batch-size", "1", "--steps-per-epoch", "1", "--num-per-log", "1", "--save-dir", str(tmp_path / "ck")]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    out = subprocess.run(base + ["--num-epoch", "3", "--num-per-save", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    summary = json.loads(out.stdout.strip().splitlines()[-1])
+    assert summary["epochs"] == 3 and summary["steps"] == 3
+    assert summary["scheduler_epochs"] == 3 and summary["lr"] == 3e-4     # StepLR(step_size=32) stepped once per epoch
+    assert sorted(os.listdir(tmp_path / "ck")) == ["bev_2.th"]
+    sd = torch.load(tmp_path / "ck" / "bev_2.th")
+    ref = LAV(TrainConfig(), "cpu", what="bev").bev_planner.state_dict()
+    assert list(sd) == list(ref) and any(not torch.equal(sd[k], ref[k]) for k in sd)
+    out2 = subprocess.run(base + ["--num-epoch", "1", "--bev", str(tmp_path / "ck" / "bev_2.th")], capture_output=True, text=True,
+                          timeout=900, env=env)
+    assert out2.returncode == 0, out2.stderr[-3000:]
