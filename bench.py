@@ -113,26 +113,37 @@ def cpu_baseline(sds, host, budget_s=20.0):
 
 
 def train_bench(args):
-    """BASELINE.json metric (ii): samples/s of train_full_v2 (global batch 32 at 8 GPUs = 4 per GPU) / train_bev_v2
-    (64 at 8 GPUs = 8 per GPU) on synthetic batches; weak scaling - the per-GPU batch is fixed, one process per GPU,
-    gradient all-reduce over RCCL.  One step = forward + backward + Adam (+ the reference's per-step eval inference for
-    train_full).  Dense layers run on torch autograd (MIOpen/rocBLAS) in this round: a measured baseline for the
-    training row, not a hand-kernel number."""
+    """BASELINE.json metric (ii): samples/s of train_full_v2 (config #5: batch 32) / train_bev_v2 (config #4: batch 64) on
+    synthetic batches, one process per GPU, gradient all-reduce over RCCL.  The GLOBAL batch is BASELINE's at every N
+    (strong scaling: 32 / N resp. 64 / N samples per GPU; `--batch B` fixes the per-GPU batch instead = weak scaling).
+    One step = forward + backward + Adam, plus - for train_full - the reference's eval-mode inference of sample 0 that
+    feeds its log (lav_final_v2.py:228-236) every `--log-every` steps: 1 = the reference's cadence (it runs it on every
+    step and logs every 100th), 100 = only on the steps that are logged.  Dense layers run on torch autograd
+    (MIOpen/rocBLAS): a measured baseline for the training row, not a hand-kernel number."""
+    from lav_amd.train import TrainConfig
     from lav_amd.train.run import train_loop
     what = "lidar" if args.mode == "train_full" else "bev"
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    per = args.batch or (4 if what == "lidar" else 8)
+    base = 32 if what == "lidar" else 64
+    if args.batch:
+        per, scaling = args.batch, "weak"
+    else:
+        if base % world:
+            raise SystemExit(f"BASELINE's global batch {base} does not divide over {world} ranks (use --batch)")
+        per, scaling = base // world, "strong"
     steps = args.steps if args.steps != 100 else 10
     warmup = min(args.warmup, 3)
-    dt, info, (rank, world) = train_loop(what, per * world, steps, warmup)
+    cfg = TrainConfig(log_every=args.log_every)
+    dt, info, (rank, world) = train_loop(what, per * world, steps, warmup, cfg=cfg)
     if rank == 0:
         print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
-                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
                               config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
-                                          + (", 120000-point clouds, 320x320 maps; the log-only eval inference runs on logged steps (every 100th)"
+                                          + (f", 120000-point clouds, 320x320 maps; log-only eval inference every {args.log_every} step(s)"
                                              if what == "lidar" else ", (9,320,320) BEV"),
-                                          parallelism=f"dp{world}", loss=round(info["loss"], 4)),
+                                          parallelism=f"dp{world}", global_batch=per * world, log_every=args.log_every,
+                                          loss=round(info["loss"], 4)),
                               roofline=None, cpu_baseline=None)))
     if world > 1:
         import torch.distributed as dist
@@ -148,7 +159,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     ap.add_argument("--mode", default="infer", choices=["infer", "train_full", "train_bev"],
                     help="infer: BASELINE metric (i) frames/s; train_full / train_bev: metric (ii) samples/s, data parallel")
-    ap.add_argument("--batch", type=int, default=None, help="training modes: per-GPU batch (default 4 for train_full, 8 for train_bev)")
+    ap.add_argument("--batch", type=int, default=None, help="training modes: fixed per-GPU batch (weak scaling); default: BASELINE's global batch 32 / 64 split over the ranks")
+    ap.add_argument("--log-every", type=int, default=100, help="train_full: steps between the log-only eval inference (1 = the reference's cadence)")
     args = ap.parse_args()
     if args.mode != "infer":
         return train_bench(args)
