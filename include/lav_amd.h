@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 10
+#define LAV_ABI_VERSION 11
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -275,6 +275,20 @@ size_t lav_extract_peaks_workspace_bytes(int ncls, int h, int w);
 int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max_det, int apply_sigmoid,
                       const float *size, int size_c, const float *ori, int ori_c, float *out, void *workspace,
                       size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 6b. Single-query attention pooling of the brake net.  Replaces Attention.forward, lav/models/attention.py:21-38
+ *     (called twice per frame from RGBBrakePredictionModel.forward, team_code_v2/models/rgb.py:69-70): Linear(C -> 2C) key/value
+ *     projection, positional encoding on the keys, one learned query per head, soft-max over the h*w tokens, weighted sum.
+ *     With one fixed query per head the key projection folds into the query and the value projection moves behind the
+ *     weighted sum (exact algebra, prepared once from the weights on the host):
+ *       u         [heads][C]  = scale * W_k,h^T q_h
+ *       dots_bias [heads][N]  = scale * q_h . (b_k,h + PE[n])
+ *       out[b][h*dh + d]      = W_v[h*dh + d] . (sum_n softmax_n(u_h . x[b][:, n] + dots_bias[h][n]) x[b][:, n]) + b_v[h*dh + d]
+ *     x [batch][C][N] (an NCHW map, N = h*w tokens), w_v [C][C] (rows = outputs, PyTorch Linear layout), out [batch][C].
+ * ------------------------------------------------------------------------------------------ */
+int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const float *u, const float *dots_bias,
+                  const float *w_v, const float *b_v, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7. Training-side pillar ops: what PointPillarNet needs in train mode, where BatchNorm1d uses batch

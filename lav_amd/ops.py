@@ -458,6 +458,16 @@ def crop_rotate_indexed(features, map_index, locs, oris, pixels_per_meter, crop,
     return _CropRotateIndexed.apply(features, map_index, locs, oris, pixels_per_meter, crop, offset_x, offset_y)
 
 
+def attn_pool(x: torch.Tensor, u: torch.Tensor, dots_bias: torch.Tensor, w_v: torch.Tensor, b_v: torch.Tensor, heads: int) -> torch.Tensor:
+    """x (B,C,h,w) in HBM -> (B,C): single-query multi-head attention pooling with folded projections (lav_attn_pool)."""
+    x = _f32c(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    check(_lib.load().lav_attn_pool(_ptr(x), B, Cc, H * W, int(heads), _ptr(_f32c(u, "u")), _ptr(_f32c(dots_bias, "dots_bias")),
+                                    _ptr(_f32c(w_v, "w_v")), _ptr(_f32c(b_v, "b_v")), _ptr(out), _stream()), "lav_attn_pool")
+    return out
+
+
 def pool_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out: torch.Tensor, out_c_offset: int, relu: bool = True):
     """2x2 max pooling + per-channel affine (+ ReLU) of x (B,C,H,W) into channels [out_c_offset, +C) of out (B,Ct,H/2,W/2)."""
     x = _f32c(x, "x")

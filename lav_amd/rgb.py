@@ -1,7 +1,7 @@
 """Camera-side models with the reference's state_dict keys (team_code_v2/models/rgb.py:36-83,
 lav/models/attention.py, lav/models/segmentation.py): the ERFNet segmenter that feeds point painting and the
 brake predictor.  Their convolutions run on liblav_amd's MFMA convolution in eval mode on the GPU (the brake net is called every
-frame by the agent, lav_agent_fast.py:323); the single-query attention pooling stays on torch ops.
+frame by the agent, lav_agent_fast.py:323), the single-query attention pooling on lav_attn_pool.
 """
 from __future__ import annotations
 
@@ -12,6 +12,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from .erfnet import ERFNet
+from . import ops
 from . import resnet as _hip_resnet
 
 
@@ -71,7 +72,10 @@ def positionalencoding1d(d_model, length):
 
 
 class Attention(nn.Module):
-    """Single learned query per head pooling the (h*w) tokens of the ResNet map (lav/models/attention.py:6-38)."""
+    """Single learned query per head pooling the (h*w) tokens of the ResNet map (lav/models/attention.py:6-38).
+    Eval mode on the GPU: one liblav_amd launch (lav_attn_pool) on projections folded around the query - prepared from
+    the parameters once per (device, token count) and rebuilt when a parameter changes; train mode: the reference's
+    torch ops (autograd)."""
 
     def __init__(self, dim, num_heads=8):
         super().__init__()
@@ -79,9 +83,33 @@ class Attention(nn.Module):
         self.q = nn.Parameter(torch.randn(1, num_heads, 1, self.dim_head))
         self.linear_kv = nn.Linear(dim, dim * 2)
         self.scale = self.dim_head ** -0.5
+        self._folded = {}
+
+    def _fold(self, device, n_tokens):
+        ver = (self.q._version, self.linear_kv.weight._version, self.linear_kv.bias._version,
+               self.q.data_ptr(), self.linear_kv.weight.data_ptr())
+        key = (str(device), n_tokens)
+        hit = self._folded.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        C, H, dh = self.linear_kv.in_features, self.num_heads, self.dim_head
+        W = self.linear_kv.weight.detach().double().cpu()
+        b = self.linear_kv.bias.detach().double().cpu()
+        q = self.q.detach().double().cpu().view(H, dh)
+        wk, bk = W[:C].view(H, dh, C), b[:C].view(H, dh)
+        u = self.scale * torch.einsum("hd,hdc->hc", q, wk)                                   # (heads, C)
+        pe = positionalencoding1d(dh, n_tokens).double()                                     # (N, dh), shared by the heads
+        dots_bias = self.scale * (torch.einsum("hd,hd->h", q, bk)[:, None] + q @ pe.t())     # (heads, N)
+        f32 = lambda t: t.float().contiguous().to(device)
+        folded = (f32(u), f32(dots_bias), f32(W[C:]), f32(b[C:]))
+        self._folded[key] = (ver, folded)
+        return folded
 
     def forward(self, x):
         b, d, h, w = x.shape
+        if not self.training and x.is_cuda:
+            u, dots_bias, w_v, b_v = self._fold(x.device, h * w)
+            return ops.attn_pool(x, u, dots_bias, w_v, b_v, self.num_heads)
         tok = x.flatten(2).transpose(1, 2)                                        # b (h w) d
         k, v = self.linear_kv(tok).chunk(2, dim=-1)
         k = k.view(b, h * w, self.num_heads, self.dim_head).transpose(1, 2)       # b heads n dh
