@@ -169,6 +169,7 @@ class GraphedFramePipeline(FramePipeline):
             trunk._drop()
         self.graphs, self.outs = {}, {}
         self.frame_no = 0
+        self.overflow_ticks, self._warned_overflow = 0, False   # ticks larger than the static buffers (truncated)
         self.plan_aborts = 0          # frames whose persistent plan launch timed out and was recomputed (recover_plan)
         self.poses = deque()
 
@@ -273,7 +274,16 @@ class GraphedFramePipeline(FramePipeline):
     def step(self, lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value):
         n = int(lidar.shape[0])
         if n > self.P:
-            raise RuntimeError(f"LiDAR tick of {n} points exceeds the static graph buffers (points_per_tick={self.P})")
+            # The reference takes any tick size; the graphs' buffers are static.  A route must not die on one fat tick:
+            # the surplus points are dropped (with a warning, once), the rest of the frame is unchanged.  Construct the
+            # pipeline with a larger points_per_tick (the CARLA sensor's points_per_second / 20 / 2) to avoid it.
+            if not self._warned_overflow:
+                import warnings
+                warnings.warn(f"LiDAR tick of {n} points exceeds the static graph buffers (points_per_tick={self.P}): "
+                              f"the last {n - self.P} points of such ticks are dropped")
+                self._warned_overflow = True
+            self.overflow_ticks += 1
+            n = self.P
         self.b_tick[:n].copy_(lidar[:n], non_blocking=True)
         if n < self.P:
             self.b_tick[n:].fill_(float("nan"))
@@ -341,7 +351,7 @@ class GraphedFramePipeline(FramePipeline):
         return plan
 
     @torch.no_grad()
-    def precapture(self, cmds=range(6), max_others=4):
+    def precapture(self, cmds=range(6), max_others=15):
         """Capture every graph a drive will need up front - the frame graphs, one ego graph per command value, one others
         graph per vehicle count up to `max_others` - so that no 20 Hz tick pays a capture (hundreds of ms) the first time a
         command or a vehicle count occurs.  Runs two synthetic ticks and then resets the pipeline."""

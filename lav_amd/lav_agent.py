@@ -38,7 +38,7 @@ DEFAULT_CONFIG = dict(
     speed_KD=1.0, speed_n=40, brake_speed=0.2, brake_ratio=1.1, clip_delta=0.25, max_throttle=0.8, max_speed=35,
     speed_ratio=[0.8, 0.8, 0.8, 0.6, 0.8, 0.8], lidar_model_dir="weights/lidar_v2_7.th",
     uniplanner_dir="weights/uniplanner_v2_7.th", bra_model_dir="weights/bra_v2_9.th", seg_model_dir="weights/seg_1.th",
-    synthetic_weights=False, hip_graphs=True, points_per_tick=32768, precapture=False, log_wandb=False)
+    synthetic_weights=False, hip_graphs=True, points_per_tick=32768, precapture=True, log_wandb=False)
 
 
 def get_entry_point():

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _make(tmp_path, **over):
-    cfg = dict(synthetic_weights=True, points_per_tick=8192, **over)
+    cfg = dict(dict(synthetic_weights=True, points_per_tick=8192, precapture=False), **over)
     p = tmp_path / f"cfg_{len(over)}_{over.get('hip_graphs', True)}.yaml"
     p.write_text(yaml.safe_dump(cfg))
     agent = LAVAgent(str(p))
@@ -64,20 +64,30 @@ def test_graphed_agent_equals_eager_agent_and_restated_wiring(tmp_path):
 
 
 def test_precapture_leaves_nothing_to_capture_during_the_drive(tmp_path):
-    a, sc = _make(tmp_path, hip_graphs=True, precapture=True)
+    a, sc = _make(tmp_path, hip_graphs=True, precapture=True)        # the agent's default; the other tests switch it off to start fast
     have = set(a.pipeline.graphs)
-    assert {("ego", c) for c in range(6)} <= have and {("others", n) for n in range(1, 5)} <= have and {"lidar", "heads", "brake"} <= have
+    assert {("ego", c) for c in range(6)} <= have and {("others", n) for n in range(1, 16)} <= have and {"lidar", "heads", "brake"} <= have
     for i in range(0, 40, 4):
         a.run_step(synth.agent_inputs(i, sc), i * 0.05)
-    new = {k for k in set(a.pipeline.graphs) - have if not (isinstance(k, tuple) and k[0] == "others")}
-    assert not new, new            # only an others graph for an unusually crowded frame may still be captured lazily
+    assert set(a.pipeline.graphs) == have          # the detection decode caps the vehicle count at 15: nothing left to capture
 
 
-def test_tick_larger_than_static_buffers_is_rejected(tmp_path):
-    a, sc = _make(tmp_path, hip_graphs=True)
-    data = synth.agent_inputs(0, sc, n_points=9000)
-    with pytest.raises(RuntimeError, match="exceeds the static graph buffers"):
-        a.run_step(data, 0.0)
+def test_tick_larger_than_static_buffers_is_truncated_not_fatal(tmp_path):
+    """The reference accepts any tick size; the HIP-graph agent drops the surplus points with a warning instead of
+    aborting the route from inside run_step."""
+    a, sc = _make(tmp_path, hip_graphs=True, precapture=False)
+    big = synth.agent_inputs(0, sc, n_points=9000)
+    with pytest.warns(UserWarning, match="exceeds the static graph buffers"):
+        a.run_step(big, 0.0)
+    b, _ = _make(tmp_path, hip_graphs=True, precapture=False)
+    cut = synth.agent_inputs(0, sc, n_points=9000)
+    cut["LIDAR"] = (0, cut["LIDAR"][1][:8192])
+    b.run_step(cut, 0.0)
+    for i in (1, 2):
+        ca = a.run_step(synth.agent_inputs(i, sc), i * 0.05)
+        cb = b.run_step(synth.agent_inputs(i, sc), i * 0.05)
+        assert (ca.steer, ca.throttle, ca.brake) == (cb.steer, cb.throttle, cb.brake)
+    assert a.pipeline.overflow_ticks == 1 and b.pipeline.overflow_ticks == 0
 
 
 @pytest.mark.parametrize("hip_graphs", [True, False])
