@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
             // whole chip is streaming the canvas, so these zeros cost their share of the HBM time wherever they are put.  The
             // two workgroups of a CU put them at opposite ends - before the sums sweep (while the records are in flight) or
             // after the PointNet - so that one's stores run beside the other's latency-bound compute.
-            const bool zeros_first = (blockIdx.x / 8) & 1;   // (workgroups b and b + 8 x #XCDs... share a CU: b % 8 picks the XCD)
+            // (workgroup b goes to XCD b % 8 and, with two workgroups per CU, shares its CU with workgroup b + gridDim/2)
+            const bool zeros_first = blockIdx.x >= gridDim.x / 2;
             if (zeros_first) store_units(false_type{});
             // packed cell -> (layer, tile column, xi, yi, member of this group).  Layers order the pillars that the
             // reference's clamp (:89) sends to one canvas cell like its sorted unique rows: later layers replace earlier.
