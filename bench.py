@@ -306,7 +306,7 @@ def main():
                                         f"({n_pts} pts x 11) + 3x288x256 RGB + 288x480 tele; ERFNet seg, paint, pillar 320x320x64, "
                                         "BEV backbone+heads, uniplanner (cast+plan GRUs), brake net",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1]),
-                               launch="eager" if args.eager else "hip graphs: lidar / heads / others[N] on the main stream, brake and ego[cmd] on side streams"),
+                               launch="eager" if args.eager else "hip graphs: lidar / heads / others (capacity 15, device-resident count) on the main stream, brake and ego[cmd] on side streams"),
                    roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, hip_kernel_us_per_frame=per_frame_us)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, host)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 11
+#define LAV_ABI_VERSION 12
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -289,6 +289,26 @@ int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max
  * ------------------------------------------------------------------------------------------ */
 int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const float *u, const float *dots_bias,
                   const float *w_v, const float *b_v, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 6c. Fixed-capacity, device-resident "other vehicles" batch.  The reference reads every detection back
+ *     to the host (team_code_v2/model_inference.py:101-108: up to ~120 scalar device->host syncs) and runs the others
+ *     branch on a data-dependent batch (:123-187).  Here the count stays in HBM:
+ *
+ * lav_det_decode: from the peak rows of lav_extract_peaks ([ncls][max_det][7] = score, x, y, size0, size1, ori0, ori1) of
+ *     class `cls`, keep a row when score > min_score, near_px < |(x,y) - (ego_x,ego_y)| < far_px and not
+ *     max(size0,size1) < min_box (det_inference, model_inference.py:95-121), and |(x,y) - (cx,cy)| > skip_px (the ego's own
+ *     box, :131-133); survivors, in score order, give actors[2 i], actors[2 i + 1] = ((x - cx)/ppm, (y - cy)/ppm) (ego-frame
+ *     metres) and actors[2 max_det + i] = atan2(ori1, ori0); *n_out = their number.  Entries beyond it are zero.
+ * lav_batch_limit: from now on the batch-aware launches enqueued BY THIS THREAD - lav_conv2d, lav_crop_rotate, lav_gru_cast -
+ *     skip the rows (images, crops, samples) >= *d_rows, read on the device when the kernel runs: a capacity-sized batch
+ *     costs what its live rows cost, with no host round trip in between.  Skipped rows of the outputs are left untouched.
+ *     NULL switches it off.  (A pointer, not a value: the launches can be captured in a HIP graph.)
+ * ------------------------------------------------------------------------------------------ */
+int lav_det_decode(const float *rows, int ncls, int max_det, int cls, float min_score, float ego_x, float ego_y,
+                   float near_px, float far_px, float min_box, float cx, float cy, float skip_px, float ppm,
+                   float *actors, int *n_out, void *stream);
+int lav_batch_limit(const int *d_rows);
 
 /* ------------------------------------------------------------------------------------------
  * 7. Training-side pillar ops: what PointPillarNet needs in train mode, where BatchNorm1d uses batch

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_CAM = 4
 
 
@@ -75,6 +75,8 @@ SIGNATURES = {
     "lav_conv1d_pair_lds_bytes": (_Z, [_I, _I, _I]),
     "lav_conv1d_pair": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "lav_attn_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "lav_det_decode": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "lav_batch_limit": (_I, [_P]),
     "lav_pool_affine": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "lav_merge_ticks": (_I, [_P, _P, _I, _I, _P, _P]),
     "lav_stack_sweeps": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),

@@ -56,6 +56,12 @@ struct Arena {
 
 constexpr int WAVE = 64;
 
+// lav_batch_limit: device-resident row count honoured by the batch-aware launches of this thread (see lav_amd.h)
+inline const int *&batch_limit() {
+    static thread_local const int *p = nullptr;
+    return p;
+}
+
 // Optional per-kernel HIP-event timers (lav_profile_enable / lav_profile_read in include/lav_amd.h).
 // timer_begin returns a slot token (< 0 when profiling is off); both calls only record events on `st`.
 int timer_begin(const char *name, hipStream_t st);

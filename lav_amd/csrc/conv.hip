@@ -37,6 +37,7 @@ constexpr int NPOS_MAX = 40;  // bound on staged input positions per thread (LDS
 
 struct ConvArgs {
     const float *x, *w, *bias, *scale, *shift, *res;
+    const int *n_valid;   // lav_batch_limit: images >= *n_valid are skipped (null: all)
     unsigned long long *trace;  // debug (LAV_CONV_TRACE): [workgroup][8] wall-clock stamps
     float *y;
     int in_c_total, in_c_offset, cin, H, W;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: loops over this wave's slices run on the SALU
     const int ks = blockIdx.z % a.ksplit;
     const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
+    if (a.n_valid && n >= *a.n_valid) return;   // workgroup-uniform
     const int cb = blockIdx.y * CO_T;
     const int Q = a.QH * a.QW;
     const int Wst = a.Wst, ROWS = a.ROWS, plane = a.plane_pad;  // channel stride in LDS (ROWS*Wst rounded up to 64)
@@ -572,6 +574,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
 // pixel-contiguous), and the waves' partial tiles are summed through LDS in a fixed order.  No staging, one barrier.
 struct DirectArgs {
     const float *x, *w, *bias, *scale, *shift, *res;
+    const int *n_valid;   // lav_batch_limit: workgroups whose first pixel belongs to an image >= *n_valid exit (null: all)
     float *y, *partial;
     int in_c_total, in_c_offset, H, W;
     int cout, out_c_total, out_c_offset, OH, OW;
@@ -601,6 +604,7 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
     const int ks = blockIdx.z % a.ksplit, cls = blockIdx.z / a.ksplit;
     const int plane_o = a.OH * a.OW, plane_q = a.QH * a.QW;
     const int nty = a.cls_nty[cls], ntx = a.cls_ntx[cls];
+    if (a.n_valid && (int)(blockIdx.x * 32) / plane_q >= *a.n_valid) return;   // workgroup-uniform
     const int m = blockIdx.x * 32 + l31;
     const bool mvalid = m < a.M;
     const int mcl = min(m, a.M - 1);
@@ -918,6 +922,7 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     if (rc) return rc;
     ConvArgs a;
     a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.n_valid = lav::batch_limit();
     a.in_c_total = c->in_c_total; a.in_c_offset = c->in_c_offset; a.cin = c->cin; a.H = c->h; a.W = c->w;
     a.cout = c->cout; a.out_c_total = c->out_c_total; a.out_c_offset = c->out_c_offset; a.OH = p.OH; a.OW = p.OW;
     a.QH = p.QH; a.QW = p.QW; a.in_s = p.in_s; a.out_s = p.out_s;
@@ -958,6 +963,7 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     if (direct) {
         DirectArgs d;
         d.x = x; d.w = w_packed; d.bias = bias; d.scale = scale; d.shift = shift; d.res = residual; d.y = y; d.partial = a.partial;
+        d.n_valid = lav::batch_limit();
         d.in_c_total = c->in_c_total; d.in_c_offset = c->in_c_offset; d.H = c->h; d.W = c->w;
         d.cout = c->cout; d.out_c_total = c->out_c_total; d.out_c_offset = c->out_c_offset; d.OH = p.OH; d.OW = p.OW;
         d.cin_pad = p.cin_pad; d.cout_pad = p.cout_pad; d.dil_h = c->dil_h; d.dil_w = c->dil_w;

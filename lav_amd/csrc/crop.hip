@@ -26,9 +26,10 @@ template <bool BACKWARD>
 __global__ __launch_bounds__(256) void k_crop_rotate(float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index, int C,
                                                      int H, int W, const float *__restrict__ locs, const float *__restrict__ oris,
                                                      float ppm, int crop, float ox, float oy, int c_per_block,
-                                                     float *__restrict__ out) {
+                                                     float *__restrict__ out, const int *__restrict__ n_valid) {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.z;
+    if (n_valid && n >= *n_valid) return;   // lav_batch_limit
     if (pix >= crop * crop) return;
     const int y = pix / crop, x = pix - y * crop;
     const float o = oris[n];
@@ -86,9 +87,9 @@ int crop_launch(bool backward, float *feat, int nmaps, const int *map_index, int
     dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
     const int tok = timer_begin(what, st);
     if (backward)
-        hipLaunchKernelGGL(k_crop_rotate<true>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out);
+        hipLaunchKernelGGL(k_crop_rotate<true>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out, backward ? nullptr : lav::batch_limit());
     else
-        hipLaunchKernelGGL(k_crop_rotate<false>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out);
+        hipLaunchKernelGGL(k_crop_rotate<false>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out, backward ? nullptr : lav::batch_limit());
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

@@ -358,3 +358,52 @@ extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int 
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }
+
+// =========================================================================================================
+// Detection decode on the device: which of the vehicle peaks become "other vehicles" of the motion forecast, their
+// ego-frame position and heading, and how many there are - InferModel.det_inference's filters
+// (team_code_v2/model_inference.py:95-121) followed by the others loop of InferModel.forward (:125-144).
+// One wave; lane j owns peak row j of the vehicle class.  Comparisons in double on widened float32 values, like the
+// Python floats of the reference.  Survivors keep their score order (prefix count over the ballot).
+namespace {
+__global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ rows, int cls, int max_det, float min_score, float ego_x,
+                                                   float ego_y, float near_px, float far_px, float min_box, float cx, float cy,
+                                                   float skip_px, float ppm, float *__restrict__ actors, int *__restrict__ n_out) {
+    const int j = threadIdx.x;
+    bool ok = false;
+    double X = 0, Y = 0, co = 1, si = 0;
+    if (j < max_det) {
+        const float *r = rows + ((long)cls * max_det + j) * 7;
+        const double s = r[0], w = r[3], h = r[4];
+        const long xi = (long)r[1], yi = (long)r[2];
+        X = (double)xi; Y = (double)yi; co = r[5]; si = r[6];
+        const double dist = sqrt((double)((xi - (long)ego_x) * (xi - (long)ego_x) + (yi - (long)ego_y) * (yi - (long)ego_y)));
+        ok = s > (double)min_score && dist > (double)near_px && dist < (double)far_px && !(fmax(w, h) < (double)min_box);
+        ok = ok && sqrt((X - (double)cx) * (X - (double)cx) + (Y - (double)cy) * (Y - (double)cy)) > (double)skip_px;
+    }
+    const unsigned long long m = __ballot(ok);
+    const int pos = __popcll(m & ((1ull << j) - 1ull));
+    if (j < max_det) {   // rows beyond the count read as an actor at the origin: finite inputs for the skipped crops
+        actors[j * 2 + 0] = 0.f; actors[j * 2 + 1] = 0.f; actors[2 * max_det + j] = 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (ok) {
+        actors[pos * 2 + 0] = (float)((X - (double)cx) / (double)ppm);
+        actors[pos * 2 + 1] = (float)((Y - (double)cy) / (double)ppm);
+        actors[2 * max_det + pos] = (float)atan2(si, co);
+    }
+    if (j == 0) *n_out = __popcll(m);
+}
+}  // namespace
+
+extern "C" int lav_det_decode(const float *rows, int ncls, int max_det, int cls, float min_score, float ego_x, float ego_y,
+                              float near_px, float far_px, float min_box, float cx, float cy, float skip_px, float ppm,
+                              float *actors, int *n_out, void *stream) {
+    LAV_REQUIRE(rows && actors && n_out, "lav_det_decode: null argument");
+    LAV_REQUIRE(ncls >= 1 && cls >= 0 && cls < ncls && max_det >= 1 && max_det <= 64, "lav_det_decode: bad sizes (max_det <= 64)");
+    hipLaunchKernelGGL(k_det_decode, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), rows, cls, max_det, min_score, ego_x, ego_y,
+                       near_px, far_px, min_box, cx, cy, skip_px, ppm, actors, n_out);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}

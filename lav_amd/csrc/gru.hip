@@ -39,12 +39,13 @@ __global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restri
                                                   const float *__restrict__ w_ih, const float *__restrict__ w_hh,
                                                   const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                                   const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
-                                                  float *__restrict__ out) {
+                                                  float *__restrict__ out, const int *__restrict__ n_valid) {
     constexpr int H = CAST_H, G = 3 * H;
     __shared__ float gi[G];
     __shared__ float gh[G];
     __shared__ float h[H];
     const int cmd = blockIdx.x, b = blockIdx.y;
+    if (n_valid && b >= *n_valid) return;   // lav_batch_limit
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *e = embd + (long)b * embd_dim;
     const float *wih = w_ih + (long)cmd * G * embd_dim;
@@ -466,7 +467,7 @@ extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int n
     LAV_REQUIRE(embd && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_gru_cast: null argument");
     const int tok = timer_begin("gru_cast", static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(CAST_THREADS), 0, static_cast<hipStream_t>(stream), embd, embd_dim,
-                       num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out);
+                       num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out, lav::batch_limit());
     timer_end(tok, static_cast<hipStream_t>(stream));
     LAV_LAUNCH_CHECK();
     return LAV_OK;

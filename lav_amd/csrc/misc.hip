@@ -5,6 +5,11 @@ extern "C" int lav_abi_version(void) { return LAV_ABI_VERSION; }
 
 extern "C" const char *lav_last_error(void) { return lav::error_buffer(); }
 
+extern "C" int lav_batch_limit(const int *d_rows) {
+    lav::batch_limit() = d_rows;
+    return LAV_OK;
+}
+
 extern "C" int lav_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

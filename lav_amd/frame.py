@@ -115,18 +115,24 @@ class GraphedFramePipeline(FramePipeline):
       main   heads      fused heads, peak extraction into a fixed (2,15,7) tensor
       s_bra  brake      the brake net (needs only the camera images)
       s_ego  ego[cmd]   ego crop -> ResNet-18 -> cast -> plan; starts when the feature map exists (one per command)
-      main   others[N]  after the host decoded the peaks: N rotated crops -> ResNet-18 -> cast -> command scores
+      main   others     a FIXED-CAPACITY batch of 15 rotated crops -> ResNet-18 -> cast -> command scores whose live row count
+                        N stays in HBM (lav_det_decode at the end of the heads graph, lav_batch_limit around the branch): the
+                        GPU never waits for the host between the heads and the others branch
 
-    host:  one device->host copy of the peak tensor, the reference's score/size/range filters
-           (model_inference.py:95-144), N = number of other vehicles.
+    host:  the peak tensor and N come up behind the heads graph; the host waits for THEM only (the GPU is already in the
+           others branch) and rebuilds the detection lists the API returns with the reference's score/size/range filters
+           (model_inference.py:95-144).
+           (`device_others=False` restores round 1's flow: copy the peaks up after the heads, decode on the host, replay
+           one of 15 per-count graphs.)
 
     Static shapes: every LiDAR tick is padded to `points_per_tick` rows with NaN (NaN fails the pillar range test
     exactly like an absent point; all downstream results are independent of point count and order), the ego-box
     points are NaN-marked instead of compacted, and missing history sweeps are NaN slots of the ring.
     """
 
-    def __init__(self, *a, points_per_tick: int = 32768, **k):
+    def __init__(self, *a, points_per_tick: int = 32768, device_others: bool = True, **k):
         super().__init__(*a, **k)
+        self.device_others = device_others and os.environ.get("LAV_DEVICE_OTHERS", "1") != "0"
         dev, P = self.device, points_per_tick
         self.P = P
         f = dict(dtype=torch.float32, device=dev)
@@ -153,7 +159,9 @@ class GraphedFramePipeline(FramePipeline):
         self.h_actors = torch.zeros((45,), dtype=torch.float32).pin_memory()      # [15 x (x, y) | 15 x ori]
         self.d_actors = torch.zeros((45,), **f)
         self.hn_det, self.hn_actors = self.h_det.numpy(), self.h_actors.numpy()
-        self.ev_det = torch.cuda.Event()
+        self.d_n = torch.zeros((1,), dtype=torch.int32, device=dev)               # number of other vehicles, device resident
+        self.h_n = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.ev_det, self.ev_end = torch.cuda.Event(), torch.cuda.Event()
         self.b_features = None   # (1,384,160,160): written by the lidar graph, read by heads / ego / others
         self.b_locs, self.b_oris = self.d_actors[:30].view(15, 2), self.d_actors[30:]
         self.b_zero = torch.zeros((1, 4), **f)   # the ego vehicle's own (loc, ori)
@@ -196,7 +204,15 @@ class GraphedFramePipeline(FramePipeline):
 
     def _g_heads(self):
         heat, size, ori, pred_bev = self.infer_model.lidar_model.heads(self.b_features)
-        return dict(det_raw=ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True), pred_bev=pred_bev)  # (2,15,7)
+        det_raw = ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True)                                 # (2,15,7)
+        if self.device_others:   # who the other vehicles are and how many: decided on the device (model_inference.py:95-144)
+            im, up = self.infer_model, self.infer_model.uniplanner
+            ox, oy = up.offsets()
+            H, W = im._bev_hw
+            ops.det_decode(det_raw, self.d_actors, self.d_n, cls=1, min_score=0.2, ego_xy=(160, 280), near_px=2.0,
+                           far_px=30 * im.pixels_per_meter, min_box=0.1 * im.pixels_per_meter,
+                           centre_xy=(float(W / 2 + ox * W / 2), float(H / 2 + oy * H / 2)), skip_px=4.0, ppm=up.pixels_per_meter)
+        return dict(det_raw=det_raw, pred_bev=pred_bev)
 
     def _g_brake(self):
         bra = self.bra_model
@@ -222,6 +238,11 @@ class GraphedFramePipeline(FramePipeline):
         from .planner_common import transform_points
         cast = transform_points(cast, oris[:, None].repeat(1, up.num_cmds)) + locs.view(n, 1, 1, 2)
         return dict(other_cast_locs=cast, other_cast_cmds=cmds)
+
+    def _g_others_cap(self):
+        """The others branch at its full capacity of 15 vehicles; kernels skip the rows >= d_n (read on the device)."""
+        with ops.batch_limit(self.d_n):
+            return self._g_others(15)
 
     def _replay(self, key, fn, stream, *args, _skip=False):
         """Replay graph `key` on the current stream; first use: one eager run on the capture stream (builds the
@@ -311,13 +332,35 @@ class GraphedFramePipeline(FramePipeline):
                                  _skip="ego" in _DIAG_SKIP and ("ego", cmd_value) in self.graphs)
         o_heads = self._replay("heads", self._g_heads, self.s_cap)
         self.frame_no += 1
+        up = self.infer_model.uniplanner
+        if self.device_others:
+            # peaks and count travel up while the GPU goes straight on with the others branch; the host reads them (and rebuilds
+            # the detection lists of the API) while that branch runs - nothing on the GPU waits for it
+            self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
+            self.h_n.copy_(self.d_n, non_blocking=True)
+            self.ev_det.record(main)
+            ob = self._replay("others_cap", self._g_others_cap, self.s_cap)
+            main.wait_stream(self.s_ego)      # also keeps the next frame's input copies behind this frame's readers
+            main.wait_stream(self.s_bra)
+            self.ev_det.synchronize()
+            det, locs, _ = self.infer_model.det_decode_fast(self.hn_det)
+            N = int(self.h_n[0])
+            if N != min(len(locs), 15):
+                raise RuntimeError(f"device detection decode found {N} vehicles, the host rules {len(locs)}")
+            if N > 0:
+                other_cast, other_cmds = ob["other_cast_locs"][:N], ob["other_cast_cmds"][:N]
+            else:   # the reference returns CPU zeros (model_inference.py:167-168)
+                other_cast = torch.zeros((0, up.num_cmds, up.num_plan, 2))
+                other_cmds = torch.zeros((0, up.num_cmds))
+            return dict(ego_embd=o_ego["ego_embd"], ego_plan_locs=o_ego["ego_plan_locs"], ego_cast_locs=o_ego["ego_cast_locs"],
+                        other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=o_heads["pred_bev"],
+                        det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])
         # the frame's only blocking device->host copy before the others branch: 840 bytes into pinned memory
         self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
         self.ev_det.record(main)
         self.ev_det.synchronize()
         det, locs, oris = self.infer_model.det_decode_fast(self.hn_det)     # numpy masks: ~3x faster than the row loops
         N = min(len(locs), 15)
-        up = self.infer_model.uniplanner
         if N > 0:
             self.hn_actors[:2 * N] = locs[:N].reshape(-1)
             self.hn_actors[30:30 + N] = oris[:N]
@@ -365,8 +408,11 @@ class GraphedFramePipeline(FramePipeline):
         for cmd in cmds:
             with torch.cuda.stream(self.s_ego):
                 self._replay(("ego", int(cmd)), self._g_ego, self.s_ego, int(cmd))
-        for n in range(1, max_others + 1):
-            self._replay(("others", n), self._g_others, self.s_cap, n)
+        if self.device_others:
+            self._replay("others_cap", self._g_others_cap, self.s_cap)
+        else:
+            for n in range(1, max_others + 1):
+                self._replay(("others", n), self._g_others, self.s_cap, n)
         torch.cuda.synchronize()
         self.reset()
 

@@ -458,6 +458,37 @@ def crop_rotate_indexed(features, map_index, locs, oris, pixels_per_meter, crop,
     return _CropRotateIndexed.apply(features, map_index, locs, oris, pixels_per_meter, crop, offset_x, offset_y)
 
 
+def det_decode(rows: torch.Tensor, actors: torch.Tensor, n_out: torch.Tensor, *, cls: int, min_score: float, ego_xy, near_px: float,
+               far_px: float, min_box: float, centre_xy, skip_px: float, ppm: float):
+    """Peak rows (ncls, max_det, 7) of lav_extract_peaks -> the other vehicles' ego-frame (x, y) and headings in `actors`
+    ([2*max_det] + [max_det] floats) and their number in `n_out` (int32[1]), all in HBM (lav_det_decode)."""
+    rows = _f32c(rows, "rows")
+    ncls, max_det, _ = rows.shape
+    if actors.numel() < 3 * max_det or actors.dtype != torch.float32 or n_out.dtype != torch.int32:
+        raise RuntimeError("det_decode: actors must hold 3*max_det float32, n_out one int32")
+    check(_lib.load().lav_det_decode(_ptr(rows), ncls, max_det, int(cls), float(min_score), float(ego_xy[0]), float(ego_xy[1]),
+                                     float(near_px), float(far_px), float(min_box), float(centre_xy[0]), float(centre_xy[1]),
+                                     float(skip_px), float(ppm), _ptr(actors), _ptr(n_out), _stream()), "lav_det_decode")
+
+
+class batch_limit:
+    """`with ops.batch_limit(d_n):` - the conv / crop / cast launches enqueued inside skip the rows >= d_n[0], a count that
+    lives in HBM and is read when the kernels run (lav_batch_limit)."""
+
+    def __init__(self, d_rows: torch.Tensor):
+        if d_rows.dtype != torch.int32 or not d_rows.is_cuda:
+            raise RuntimeError("batch_limit: an int32 tensor in HBM")
+        self.d_rows = d_rows
+
+    def __enter__(self):
+        check(_lib.load().lav_batch_limit(_ptr(self.d_rows)), "lav_batch_limit")
+        return self
+
+    def __exit__(self, *exc):
+        check(_lib.load().lav_batch_limit(None), "lav_batch_limit")
+        return False
+
+
 def attn_pool(x: torch.Tensor, u: torch.Tensor, dots_bias: torch.Tensor, w_v: torch.Tensor, b_v: torch.Tensor, heads: int) -> torch.Tensor:
     """x (B,C,h,w) in HBM -> (B,C): single-query multi-head attention pooling with folded projections (lav_attn_pool)."""
     x = _f32c(x, "x")

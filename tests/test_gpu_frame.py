@@ -107,3 +107,67 @@ def test_extract_peaks_few_candidates():
     np.testing.assert_array_equal(rows[0, :n, 0].numpy(), score[:n].numpy())
     assert (rows[0, :n, 2] * W + rows[0, :n, 1]).long().tolist() == loc[:n].tolist()
     assert (rows[0, n:, 0] < -1e4).all()
+
+
+def test_det_decode_on_device_matches_host_rules():
+    """lav_det_decode (who the other vehicles are, where, how many - decided in HBM) against the host decode that the
+    reference goldens pin (InferModel.det_decode_fast: model_inference.py:95-144), on random peak rows that exercise every
+    filter: score threshold, the two range limits around the hard-coded ego pixel, the box-size rule, the ego's own box."""
+    import lav_amd
+    from tests.util import build_models
+    lm, up = build_models(DEV)
+    im = lav_amd.InferModel(lm, up, 1.5, 2.4, device=DEV)
+    rng = np.random.default_rng(3)
+    ox, oy = up.offsets()
+    H, W = im._bev_hw
+    centre = (float(W / 2 + ox * W / 2), float(H / 2 + oy * H / 2))
+    actors = torch.zeros(45, device=DEV)
+    n_out = torch.zeros(1, dtype=torch.int32, device=DEV)
+    seen = set()
+    for trial in range(40):
+        rows = np.zeros((2, 15, 7), np.float32)
+        rows[..., 0] = np.sort(rng.uniform(0.0, 1.0, (2, 15)).astype(np.float32) ** (1 + trial % 3), axis=1)[:, ::-1]
+        rows[..., 1] = rng.integers(0, 320, (2, 15)); rows[..., 2] = rng.integers(0, 320, (2, 15))
+        rows[1, :4, 1] = 160 + rng.integers(-5, 6, 4); rows[1, :4, 2] = 280 + rng.integers(-5, 6, 4)   # around the ego pixel
+        rows[..., 3:5] = rng.uniform(0.0, 3.0, (2, 15, 2)); rows[1, 5, 3:5] = 0.39                        # below the 0.4 px box limit
+        rows[..., 5:7] = rng.normal(0, 1, (2, 15, 2))
+        ops.det_decode(torch.from_numpy(rows).to(DEV), actors, n_out, cls=1, min_score=0.2, ego_xy=(160, 280), near_px=2.0,
+                       far_px=30 * im.pixels_per_meter, min_box=0.1 * im.pixels_per_meter, centre_xy=centre, skip_px=4.0,
+                       ppm=up.pixels_per_meter)
+        _, locs, oris = im.det_decode_fast(rows)
+        n = int(n_out.cpu()[0])
+        assert n == len(locs)
+        a = actors.cpu().numpy()
+        np.testing.assert_array_equal(a[:2 * n].reshape(-1, 2), locs.astype(np.float32))
+        np.testing.assert_allclose(a[30:30 + n], oris.astype(np.float32), rtol=0, atol=2.4e-7)   # double atan2, one float32 ulp
+        assert not a[2 * n:30].any() and not a[30 + n:].any()
+        seen.add(n)
+    assert len(seen) >= 5
+
+
+def test_batch_limit_skips_rows_on_the_device():
+    """ops.batch_limit: conv / crop / cast launches of a capacity-sized batch leave the rows beyond the device-resident count
+    untouched and compute the live rows exactly as an unlimited launch does."""
+    import lav_amd
+    from tests.util import build_models
+    lm, up = build_models(DEV)
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn((1, 384, 160, 160), generator=g).to(DEV)
+    locs = (torch.rand((15, 2), generator=g) * 20 - 10).to(DEV)
+    oris = (torch.rand((15,), generator=g) * 6 - 3).to(DEV)
+
+    def branch():
+        crops = up.crop_feature(feats.expand(15, -1, -1, -1), locs, oris, up.pixels_per_meter / 2, up.crop_size)
+        embd = up.lidar_conv_emb(crops)
+        return crops, embd, up.cast(embd, mode="other")
+    full = [t.clone() for t in branch()]
+    for n in (0, 1, 7, 15):
+        d_n = torch.tensor([n], dtype=torch.int32, device=DEV)
+        marks = []
+        with ops.batch_limit(d_n):
+            crops, embd, cast = branch()
+        for got, want in zip((crops, embd, cast), full):
+            assert torch.equal(got[:n], want[:n]), f"live rows differ at n={n}"
+    # a second unlimited run is unaffected by the limit having been used
+    again = branch()
+    assert all(torch.equal(a, b) for a, b in zip(again, full))
