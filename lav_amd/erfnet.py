@@ -176,10 +176,13 @@ class ERFNet(nn.Module):
     def forward(self, x, input_affine=None):
         """input_affine=(s, t): x is the raw input and the network behaves as on s*x + t (folded into the first block in
         the HIP path, applied explicitly in the torch path)."""
-        if self.training or not x.is_cuda:
+        if self.training:      # autograd path (torch ops)
             if input_affine is not None:
                 x = x * input_affine[0] + input_affine[1]
             return self.decoder(self.encoder(x))
+        if not x.is_cuda:
+            raise RuntimeError("ERFNet: eval-mode forward needs a tensor in HBM - lav_amd has no CPU path "
+                               "(CPU evaluation for tests and baselines: oracle/camera.py)")
         for stage in self._engine(x.device, input_affine):
             x = stage(x)
         return x

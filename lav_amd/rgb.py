@@ -32,7 +32,7 @@ class RGBSegmentationModel(nn.Module):
         self.erfnet = ERFNet(len(seg_channels) + 1)
 
     def forward(self, rgb):
-        if not self.training and rgb.is_cuda:     # (rgb/255 - .5)*2 folded into the first block: three launches less
+        if not self.training:     # (rgb/255 - .5)*2 folded into the first block: three launches less
             return self.erfnet(rgb, input_affine=(2.0 / 255.0, -1.0))
         return self.erfnet((rgb / 255. - .5) * 2)
 
@@ -107,7 +107,9 @@ class Attention(nn.Module):
 
     def forward(self, x):
         b, d, h, w = x.shape
-        if not self.training and x.is_cuda:
+        if not self.training:
+            if not x.is_cuda:
+                raise RuntimeError("Attention: eval-mode forward needs a tensor in HBM - lav_amd has no CPU path (oracle/camera.py)")
             u, dots_bias, w_v, b_v = self._fold(x.device, h * w)
             return ops.attn_pool(x, u, dots_bias, w_v, b_v, self.num_heads)
         tok = x.flatten(2).transpose(1, 2)                                        # b (h w) d
@@ -120,14 +122,16 @@ class Attention(nn.Module):
 
 
 class _ResNet18(_hip_resnet.ResNet):
-    """ResNet-18 trunk of the brake net: lav_amd.resnet.ResNet (MFMA convolutions) in eval mode on the GPU,
-    plain torch ops otherwise (CPU baseline / training)."""
+    """ResNet-18 trunk of the brake net: lav_amd.resnet.ResNet (MFMA convolutions) in eval mode, torch ops (autograd) in
+    train mode.  Eval mode has no CPU path."""
 
     def __init__(self, num_channels=3):
         super().__init__((2, 2, 2, 2), num_channels=num_channels)
 
     def forward(self, x):
-        if not self.training and x.is_cuda:
+        if not self.training:
+            if not x.is_cuda:
+                raise RuntimeError("brake ResNet-18: eval-mode forward needs a tensor in HBM - lav_amd has no CPU path (oracle/camera.py)")
             return super().forward(x)
         x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
         for i in range(1, 5):

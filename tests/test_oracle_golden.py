@@ -155,6 +155,7 @@ def test_frame_glue_oracle_matches_reference_agent(golden):
     """oracle/paint.preprocess, oracle/bev.move_lidar_points and oracle/frame.stack against what the REFERENCE AGENT
     (team_code_v2/lav_agent_fast.py driven by tests/golden/make_golden.py:gold_agent_fast) computed on the same
     ticks: the ego-box filter (:450-457) row for row, and the stacked cloud handed to InferModel (:363-383,547-565)."""
+    from oracle import camera as ocam
     from oracle import frame as oframe
     from lav_amd.rgb import RGBSegmentationModel
     g = golden["agent_fast"]
@@ -185,7 +186,7 @@ def test_frame_glue_oracle_matches_reference_agent(golden):
                 np.testing.assert_array_equal(cur, merged[keep])
             rgbs = [np.asarray(data[f"RGB_{k}"][1])[..., :3][..., ::-1] for k in range(3)]
             all_rgbs = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float()
-            sem = torch.softmax(seg(all_rgbs), dim=1).numpy()
+            sem = torch.softmax(ocam.seg_forward(seg, all_rgbs), dim=1).numpy()
             hist["lidars"].append(opaint.forward_paint(cur, sem))
             hist["locs"].append(g["poses"][i][:2].copy()); hist["oris"].append(float(g["poses"][i][2]))
             for k in hist:
@@ -200,3 +201,30 @@ def test_frame_glue_oracle_matches_reference_agent(golden):
     # painted classes: identical except at pixel-boundary flips of the projection (sgemm association, see oracle/paint.py)
     diff = np.abs(stacked[:, 4:8] - ref[:, 4:8]).max(1) > 1e-6
     assert diff.mean() < 2e-3, f"{diff.sum()} of {len(diff)} painted rows differ"
+
+
+def test_camera_net_oracle_matches_reference(golden):
+    """oracle/camera.py (ERFNet and the brake net restated with torch ops on the CPU) against the outputs of the
+    reference's own RGBSegmentationModel / RGBBrakePredictionModel on the same seeded weights and images."""
+    from oracle import camera as ocam
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    g = golden["rgb"]
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval()
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]); bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra.")); bra.eval()
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]
+    all_rgb = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float()
+    wide = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float()
+    tel_rgb = torch.tensor(tel[..., :3][..., ::-1][:-96][None].copy()).permute(0, 3, 1, 2).float()
+    logits = ocam.seg_forward(seg, all_rgb)
+    np.testing.assert_array_equal(logits[:, :, ::4, ::4].numpy(), g["logits_s"])      # same torch ops, same weights: bit-identical
+    st = ocam.brake_stages(bra, wide, tel_rgb)
+    np.testing.assert_array_equal(st["x1"][:, ::8].numpy(), g["bra_x1_s"])
+    np.testing.assert_allclose(st["h1"].numpy(), g["bra_h1"], rtol=1e-5, atol=1e-5 * float(np.abs(g["bra_h1"]).max()))
+    np.testing.assert_allclose(st["logit"].numpy(), g["bra_logit"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st["pred_bra"].numpy(), g["pred_bra"], rtol=0, atol=1e-6)
+    # the product modules themselves have no CPU path
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        seg(all_rgb)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        bra(wide, tel_rgb)
