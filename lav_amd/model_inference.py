@@ -5,8 +5,9 @@
     .forward(lidar_points (M,11), nxps (2,), cmd_value) ->
         (ego_embd, ego_plan_locs, ego_cast_locs, other_cast_locs, other_cast_cmds, pred_bev, det)
 
-Point painting, pillar scatter, the BEV convolutions, the ResNet embedder and the GRU decoders run on
-liblav_amd; peak extraction and the rotated crop still use torch ops on the GPU ("next").
+Point painting, pillar scatter, the BEV convolutions, peak extraction, the rotated crops, the ResNet embedder and the
+GRU decoders all run on liblav_amd; what is left to torch are trivial elementwise / tiny ops (sigmoid of cast_cmd_pred,
+transform_points, max / average pooling of the embedder).
 """
 from __future__ import annotations
 
@@ -68,11 +69,16 @@ class CoordConverter(nn.Module):
         return uvz[0].long()
 
 
-def extract_peak(heatmap, max_pool_ks: int = 7, max_det: int = 15):
-    """7x7 max-pool NMS + top-15 (model_inference.py:189-202)."""
-    mx = F.max_pool2d(heatmap[None, None], kernel_size=max_pool_ks, padding=max_pool_ks // 2, stride=1)[0, 0]
-    possible = heatmap - (mx > heatmap).float() * 1e5
-    return torch.topk(possible.view(-1), min(max_det, possible.numel()))
+def extract_peak(heatmap, max_pool_ks: int = 7, min_score: float = 0.1, max_det: int = 15, break_tie: bool = False):
+    """The reference's module-level helper (model_inference.py:189-202): 7x7 max-pool NMS + top-`max_det` of one (H,W) heat
+    map -> [(score, x, y), ...] with score > min_score, on lav_extract_peaks (one launch, one small device->host copy;
+    ties between equal scores are ordered by pixel index, deterministically, instead of topk's unspecified order)."""
+    if break_tie:
+        heatmap = heatmap + 1e-7 * torch.randn(*heatmap.size(), device=heatmap.device)
+    h, w = heatmap.shape
+    z = heatmap.new_zeros((1, h, w))
+    rows = ops.extract_peaks(heatmap[None].contiguous(), z, z, ks=max_pool_ks, max_det=min(max_det, h * w)).cpu()
+    return [(float(s), int(x), int(y)) for s, x, y in rows[0, :, :3].tolist() if s > min_score]
 
 
 class InferModel(nn.Module):

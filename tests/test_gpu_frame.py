@@ -171,3 +171,17 @@ def test_batch_limit_skips_rows_on_the_device():
     # a second unlimited run is unaffected by the limit having been used
     again = branch()
     assert all(torch.equal(a, b) for a, b in zip(again, full))
+
+
+def test_module_level_extract_peak_keeps_the_reference_signature():
+    """model_inference.extract_peak(heatmap, max_pool_ks, min_score, max_det, break_tie) -> [(score, x, y)], as
+    team_code_v2/model_inference.py:189-202, on the HIP peak kernel."""
+    from lav_amd.model_inference import extract_peak
+    g = torch.Generator().manual_seed(2)
+    hm = torch.sigmoid(torch.nn.functional.avg_pool2d(torch.randn((1, 1, 64, 48), generator=g) * 3, 5, 1, 2)[0, 0] * 4)
+    got = extract_peak(hm.to(DEV), min_score=0.3)
+    score, loc = obev.extract_peak(hm)
+    want = [(float(s), int(l) % 48, int(l) // 48) for s, l in zip(score, loc) if s > 0.3]
+    assert len(got) == len(want) > 0
+    for (s, x, y), (ws, wx, wy) in zip(got, want):
+        assert abs(s - ws) < 2e-7 and (x, y) == (wx, wy)
