@@ -90,6 +90,7 @@ struct PillarArgs {   // scalars first: they share the first cache line of the k
     int UPR;     // units per canvas row
     int NUP;     // stride of one sub-counter array = number of units rounded up to 4 (16-byte loads)
     int cap;     // records per (unit, sub) bucket
+    int nwg;     // workgroups of k_rows (classes of the unit ownership)
     unsigned long long *trace;  // debug (LAV_PILLAR_TRACE): [workgroups][16] wall-clock stamps of thread 0, else null
     int n[MAX_BATCH];
 };
@@ -98,6 +99,8 @@ struct PillarArgs {   // scalars first: they share the first cache line of the k
 struct RowsArgs {
     int batch, nx, ny, UPR, NUP, cap;
     float min_x, min_y, ppm;
+    const int *perm;   // perm[workgroup] = ownership class it works on (written by k_bin from the previous call's loads)
+    int *load;         // load[class] = points the class held in this call (the next call's hint)
     unsigned long long *trace;
 };
 
@@ -136,8 +139,35 @@ template <int D>
 __global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ st, int *__restrict__ counters,
                                              float *__restrict__ buckets, float *__restrict__ ovf, int *__restrict__ key_out,
                                              const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
-                                             const float *__restrict__ b2, float *__restrict__ wpack) {
+                                             const float *__restrict__ b2, float *__restrict__ wpack, const int *__restrict__ load,
+                                             int *__restrict__ perm) {
     constexpr int RS = rec_size(D);
+    const int nbin = max(1, (int)(((long)a.batch * a.max_points + 255) / 256));   // workgroups that bin points
+    if ((int)blockIdx.x >= nbin) {
+        // Extra workgroups (past the ones that bin points): which ownership class each workgroup of k_rows takes.  The point
+        // count of a class barely changes from one LiDAR frame to the next, so the loads k_rows recorded in the PREVIOUS call
+        // are this call's hint: classes ranked by load, the heaviest handed to workgroups 0, 1, ... and the lightest to their
+        // CU partners (workgroup w + W/2 lands on the CU of workgroup w), so that the two workgroups of a CU add up to about
+        // the same.  Any permutation is valid - the hint moves time around, never results.  Each of these workgroups ranks
+        // 64 classes, four lanes per class.
+        __shared__ int s_key[2048];
+        const int W = a.nwg;
+        const int first = ((int)blockIdx.x - nbin) * 64;
+        for (int i = threadIdx.x; i < W; i += 256) s_key[i] = (min(load[i], 0xfffff) << 11) | (2047 - i);   // distinct keys
+        __syncthreads();
+        const int i = first + (int)(threadIdx.x >> 2), q = threadIdx.x & 3;
+        if (i < W) {
+            const int ki = s_key[i];
+            int r = 0;
+            for (int j = q; j < W; j += 4) r += s_key[j] > ki;
+            r += __shfl_xor(r, 1, 64);
+            r += __shfl_xor(r, 2, 64);
+            const int half = W / 2;
+            const int slot = (W & 1) ? r : (r < half ? r : half + (W - 1 - r));
+            if (q == 0) perm[slot] = i;
+        }
+        return;
+    }
     // fetch both cache lines of the kernel-argument segment at once (taken in turn, each is a microsecond-scale miss)
     asm volatile("" ::"s"(a.max_points), "s"(key_out));
     const long total = (long)a.batch * a.max_points;
@@ -150,11 +180,11 @@ __global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ s
     {   // The counter set of the previous call was consumed by its k_rows: clean it here, so that k_rows can read "both sets
         // added up" without first waiting for the epoch word to learn which one is live.
         int *cz = counters + (size_t)((e & 1u) ^ 1u) * NSUB * a.NUP;
-        for (long i = gid; i < (long)NSUB * a.NUP; i += (long)gridDim.x * 256) cz[i] = 0;
+        for (long i = gid; i < (long)NSUB * a.NUP; i += (long)nbin * 256) cz[i] = 0;
     }
     {   // PointNet weights in fragment order (see packed_weight_floats)
         constexpr int K1 = D + 5, KS1 = layer1_ksteps(D);
-        for (long i = gid; i < packed_weight_floats(D); i += (long)gridDim.x * 256) {
+        for (long i = gid; i < packed_weight_floats(D); i += (long)nbin * 256) {
             const int c4 = (int)i & 3, l = ((int)i >> 2) & 63, row = (int)i >> 8, lp = l & 15, lg = l >> 4;
             float v;
             if (row < KS1) {
@@ -259,9 +289,14 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     long long cyc0 = 0;
     if constexpr (TRACE) cyc0 = clock64();
     const int nunits = a.batch * a.ny * a.UPR;
-    const int W = (int)gridDim.x, w = (int)blockIdx.x;
-    const int nslots = (nunits - w + W - 1) / W;   // units of this workgroup
-    if (nslots <= 0) return;
+    const int W = (int)gridDim.x;
+    const int w = a.perm[blockIdx.x];              // the ownership class this workgroup works on (k_bin's pairing, see there)
+    const int nslots = (nunits - w + W - 1) / W;   // units of the class
+    if (nslots <= 0) {
+        if (tid == 0) a.load[w] = 0;
+        return;
+    }
+    int load_sum = 0;
     // Two counter sets are used by alternate calls and k_bin has cleaned the one it did not fill: every counter is read
     // as the sum over both sets, which needs no knowledge of the epoch.
     const int *__restrict__ cn = counters;
@@ -275,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     };
     const int c_first = fetch_counts(0);
 
-    if (w == 0 && tid == 0) st->epoch_rows = st->epoch_bin + 1u;   // the next call fills the other counter set
+    if (blockIdx.x == 0 && tid == 0) st->epoch_rows = st->epoch_bin + 1u;   // the next call fills the other counter set
 
     // weight fragments, once per workgroup (fragment order written by k_bin: 22 coalesced loads)
     float a1[4][KS1], w2f[4][4][4], b2v[4];
@@ -368,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         if (gi == 0) LAV_STAMP(3);
         if (gi == 1) LAV_STAMP(11);
         if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + 15] += (unsigned long long)g.n; }
+        load_sum += g.n;
         bool prefetched = false;
         Group gnext;
         auto prefetch_next = [&]() {
@@ -453,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                 const int r_ = min(max(a.ny - 1 - xi, 0), a.ny - 1);
                 const int colc = min(yi, a.nx - 1), cu_ = colc / UW;
                 // units of this workgroup are w, w + W, w + 2 W, ...: slot of the record's unit inside the group
-                const int un = ((packed >> 24) * a.ny + r_) * a.UPR + cu_ - (int)blockIdx.x;
+                const int un = ((packed >> 24) * a.ny + r_) * a.UPR + cu_ - w;
                 const int ks = un / (int)gridDim.x;
                 const int k = ks - g.first;
                 col = k * UW + (colc - cu_ * UW);
@@ -604,15 +640,14 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                     }
                     for (; v < VJ; v += 4) {
                         const int j = v >> sh, part = v & ((1 << sh) - 1);
-                        // the next record of this wave (next job of the group, or first job of the next group) is requested
-                        // once this job's matrix instructions are queued: the request's own LDS latency then overlaps them
-                        auto request_next = [&]() {
-                            if (v + 4 < VJ) load_rec(job_ptr((v + 4) >> sh), nxt);
-                            else if (last_layer) prefetch_next();
-                        };
                         float v_[RS];
 #pragma unroll
                         for (int q = 0; q < RQ; ++q) { v_[4 * q] = cur[q].x; v_[4 * q + 1] = cur[q].y; v_[4 * q + 2] = cur[q].z; v_[4 * q + 3] = cur[q].w; }
+                        // The next record of this wave (next job of the group, or first job of the next group) is requested
+                        // NOW: a wave is stuck issuing its 84 matrix instructions for their whole duration, so a request placed
+                        // behind them leaves the L2 round trip exposed at the top of the next job (measured: 3.9 us per job).
+                        if (v + 4 < VJ) load_rec(job_ptr((v + 4) >> sh), nxt);
+                        else if (last_layer) prefetch_next();
                         const int i = j < JA ? 16 * j + lp : 16 * (j - JA) + lp;
                         bool live = i < (j < JA ? g.n : n_ovf);
                         int layer, col, xi, yi;
@@ -666,7 +701,6 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
 #pragma unroll
                                         for (int c = 0; c < CNT; ++c)
                                             d2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[ct][rr], w2f[ct][rr][LO + c], d2[c], 0, 0, 0);
-                                request_next();
 #pragma unroll
                                 for (int c = 0; c < CNT; ++c) {
                                     unsigned *trow = reinterpret_cast<unsigned *>(tile + (16 * (LO + c) + lp) * TS);
@@ -690,8 +724,6 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                                 else layer2(integral_constant<int, 3>{}, integral_constant<int, 1>{});
                             }
                             if (gi == 0 && v == v0) LAV_STAMP(8);
-                        } else {
-                            request_next();
                         }
 #pragma unroll
                         for (int q = 0; q < RQ; ++q) cur[q] = nxt[q];
@@ -716,8 +748,15 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         g = gnext;
         c_next = g.first + g.gn < nslots ? fetch_counts(g.first + g.gn) : 0;
     }
+    if (tid == 0) a.load[w] = load_sum;   // next call's pairing hint
     LAV_STAMP(12);
-    if constexpr (TRACE) { if (tid == 0) a.trace[(long)blockIdx.x * 16 + 13] = (unsigned long long)(clock64() - cyc0); }
+    if constexpr (TRACE) {
+        if (tid == 0) {
+            a.trace[(long)blockIdx.x * 16 + 13] = (unsigned long long)(clock64() - cyc0);
+            // HW_REG_XCC_ID (20) and HW_REG_HW_ID (4): where this workgroup ran
+            a.trace[(long)blockIdx.x * 16 + 14] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
 #undef LAV_STAMP
 }
 
@@ -857,6 +896,7 @@ struct Workspace {
     float *buckets;    // [nunits][NSUB][cap] records
     float *ovf;        // [batch * max_points] records (overflow list)
     float *wpack;      // PointNet weights in fragment order, rewritten by every call
+    int *load, *perm;  // pairing hint of k_rows' workgroups: loads of the previous call, permutation of this one
     int *cell_count, *cell_rank, *kept_rank, *block_sums, *totals;
     unsigned long long *cell_sums;  // [min(ncells, points)][3] fixed-point coordinate sums (training entry lav_pillar_decorate)
     int cap, upr;
@@ -882,6 +922,8 @@ size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid 
     w.state = ar.take<State>(1);
     w.counters = ar.take<int>(2 * NSUB * align_up(nunits, 4));
     w.wpack = ar.take<float>(packed_weight_floats(15));
+    w.load = ar.take<int>(2048);
+    w.perm = ar.take<int>(2048);
     w.key = ar.take<int>(total);
     w.cell_count = ar.take<int>(ncells);
     w.cell_rank = ar.take<int>(ncells + 1);
@@ -936,13 +978,23 @@ void dump_trace(const unsigned long long *d_trace, int nwg, hipStream_t st) {
         for (int i = 0; i < nwg; ++i) if (h[i * 16 + 12] > h[i * 16]) { f += (double)h[i * 16 + 13] / ((double)(h[i * 16 + 12] - h[i * 16]) / 100.0); ++nf; }
         fprintf(stderr, "  mean shader clock %.0f MHz\n", nf ? f / nf : 0.0);
     }
+    {   // which workgroups shared a CU (XCC, SE, SH, CU of HW_ID)
+        auto cu_of = [&](int i) { const unsigned long long v = h[(size_t)i * 16 + 14]; return (unsigned)(((v >> 32) & 0xf) << 16) | (unsigned)(v & 0xff00); };
+        int paired = 0;
+        for (int i = 0; i + nwg / 2 < nwg; ++i) paired += cu_of(i) == cu_of(i + nwg / 2);
+        fprintf(stderr, "  workgroups i and i + %d on the same CU: %d of %d; cu of wg 0..7:", nwg / 2, paired, nwg / 2);
+        for (int i = 0; i < std::min(nwg, 8); ++i) fprintf(stderr, " %06x", cu_of(i));
+        fprintf(stderr, " | wg %d..:", nwg / 2);
+        for (int i = nwg / 2; i < std::min(nwg, nwg / 2 + 8); ++i) fprintf(stderr, " %06x", cu_of(i));
+        fprintf(stderr, "\n");
+    }
     struct Row { double end; int i; };
     std::vector<Row> rows;
     for (int i = 0; i < nwg; ++i) rows.push_back({us(h[i * 16 + 12]), i});
     std::sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.end > y.end; });
     for (size_t k = 0; k < std::min<size_t>(rows.size(), 6); ++k) {
         const unsigned long long *r = &h[(size_t)rows[k].i * 16];
-        fprintf(stderr, "  late wg %4d: units %llu points %llu |", rows[k].i, r[14], r[15]);
+        fprintf(stderr, "  late wg %4d: hw %llx points %llu |", rows[k].i, r[14], r[15]);
         for (int q = 0; q < 13; ++q) fprintf(stderr, " %.1f", us(r[q]));
         fprintf(stderr, "\n");
     }
@@ -951,13 +1003,12 @@ void dump_trace(const unsigned long long *d_trace, int nwg, hipStream_t st) {
 template <int D>
 int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, bool want_keys, hipStream_t st) {
     const long total = (long)a.batch * a.max_points;
-    const int nunits = a.batch * a.ny * a.UPR;
     const int tok_prep = timer_begin("pillar_prep", st);
-    hipLaunchKernelGGL((k_bin<D>), dim3((unsigned)std::max(1l, (total + 255) / 256)), dim3(256), 0, st, a, w.state, w.counters, w.buckets,
-                       w.ovf, want_keys ? w.key : nullptr, net->w1, net->b1, net->w2, net->b2, w.wpack);
+    hipLaunchKernelGGL((k_bin<D>), dim3((unsigned)(std::max(1l, (total + 255) / 256) + (a.nwg + 63) / 64)), dim3(256), 0, st, a, w.state, w.counters, w.buckets,
+                       w.ovf, want_keys ? w.key : nullptr, net->w1, net->b1, net->w2, net->b2, w.wpack, w.load, w.perm);
     timer_end(tok_prep, st);
     LAV_LAUNCH_CHECK();
-    const int W = std::min(persistent_workgroups(), nunits);
+    const int W = a.nwg;
     const bool vec4 = a.nx % 4 == 0 && reinterpret_cast<uintptr_t>(canvas) % 16 == 0;
     static const bool want_trace = getenv("LAV_PILLAR_TRACE") != nullptr;
     static unsigned long long *d_trace = nullptr;
@@ -965,6 +1016,7 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     RowsArgs at;
     at.batch = a.batch; at.nx = a.nx; at.ny = a.ny; at.UPR = a.UPR; at.NUP = a.NUP; at.cap = a.cap;
     at.min_x = a.min_x; at.min_y = a.min_y; at.ppm = a.ppm; at.trace = nullptr;
+    at.perm = w.perm; at.load = w.load;
 
     if (want_trace && vec4) {
         if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)persistent_workgroups() * 16 * sizeof(unsigned long long)));
@@ -1015,6 +1067,7 @@ int fill_args(PillarArgs &a, const float *points, const int *h_num_points, int b
     a.UPR = w.upr;
     a.NUP = (int)align_up((size_t)batch * grid->ny * w.upr, 4);
     a.cap = w.cap;
+    a.nwg = std::min(persistent_workgroups(), batch * grid->ny * w.upr);
     a.trace = nullptr;
     return LAV_OK;
 }
@@ -1227,7 +1280,7 @@ extern "C" int lav_pillar_decorate(const float *points, const int *h_num_points,
     for (int b = 0; b < batch; ++b) LAV_REQUIRE(h_num_points[b] >= 0, "lav_pillar_decorate: negative num_points");
     a.min_x = grid->min_x; a.max_x = grid->max_x; a.min_y = grid->min_y; a.max_y = grid->max_y; a.ppm = grid->ppm;
     a.nx = grid->nx; a.ny = grid->ny; a.KX = grid->nx + 1; a.KY = grid->ny + 1;
-    a.UPR = w.upr; a.NUP = 0; a.cap = w.cap; a.trace = nullptr;
+    a.UPR = w.upr; a.NUP = 0; a.cap = w.cap; a.nwg = 0; a.trace = nullptr;
     const long ncells = (long)batch * a.KX * a.KY;
     const long total = (long)batch * max_points;
     const unsigned gp = (unsigned)((total + 255) / 256);
