@@ -20,10 +20,8 @@ __device__ __forceinline__ float lin(int i, int n) {
     return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
 }
 
-// BACKWARD=false: out[n][c][y][x] = bilinear(feat[map(n)][c]);  BACKWARD=true: feat_or_grad[map(n)][c] += weights * out[n][c][y][x]
-// (`out` is then the incoming gradient, read only).  map(n) = map_index[n] when given, n when there is one map per crop, else 0.
-template <bool BACKWARD>
-__global__ __launch_bounds__(256) void k_crop_rotate(float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index, int C,
+// out[n][c][y][x] = bilinear(feat[map(n)][c]);  map(n) = map_index[n] when given, n when there is one map per crop, else 0.
+__global__ __launch_bounds__(256) void k_crop_rotate(const float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index, int C,
                                                      int H, int W, const float *__restrict__ locs, const float *__restrict__ oris,
                                                      float ppm, int crop, float ox, float oy, int c_per_block,
                                                      float *__restrict__ out, const int *__restrict__ n_valid) {
@@ -55,41 +53,144 @@ __global__ __launch_bounds__(256) void k_crop_rotate(float *__restrict__ feat, i
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
     const long plane = (long)H * W;
     const int m = map_index ? map_index[n] : (feat_batch > 1 ? n : 0);
-    float *f = feat + (long)m * C * plane;
+    const float *f = feat + (long)m * C * plane;
     const int c_lo = blockIdx.y * c_per_block, c_hi = min(C, c_lo + c_per_block);
     float *o_ = out + ((long)n * C) * crop * crop + pix;
-    if constexpr (!BACKWARD) {
+    {
 #pragma unroll 8   // 32 independent gathers in flight per thread: the loop is latency bound, not bandwidth bound
         for (int c = c_lo; c < c_hi; ++c) {
             const float *p = f + c * plane;
             const float v = p[cy0 * W + cx0] * w00 + p[cy0 * W + cx1] * w01 + p[cy1 * W + cx0] * w10 + p[cy1 * W + cx1] * w11;
             o_[(long)c * crop * crop] = v;
         }
-    } else {
-        // transpose of the gather: every output-pixel gradient is spread over its four source pixels (crops overlap and
-        // share maps, hence atomics - the same choice torch's grid_sampler backward makes)
-        for (int c = c_lo; c < c_hi; ++c) {
-            float *p = f + c * plane;
-            const float g = o_[(long)c * crop * crop];
-            if (w00 != 0.f) atomicAdd(p + cy0 * W + cx0, g * w00);
-            if (w01 != 0.f) atomicAdd(p + cy0 * W + cx1, g * w01);
-            if (w10 != 0.f) atomicAdd(p + cy1 * W + cx0, g * w10);
-            if (w11 != 0.f) atomicAdd(p + cy1 * W + cx1, g * w11);
+    }
+}
+
+// Backward in GATHER form: one thread per pixel of the map gradient, no atomics, no memset, bit-reproducible.
+//
+// The scatter form (every output-pixel gradient added to its four source pixels with fp32 atomics - what torch's grid_sampler
+// backward does) cost 20 ms per call at train_full's sizes: 64+ crops x 384 channels x 96 x 96 x 4 = 0.9 G atomics.  The
+// sampling grid is a rotation at (almost exactly) the map's own pixel pitch, so a map pixel (sy, sx) is a bilinear corner of
+// only the few output pixels whose sample position falls inside the 2 x 2 square around it: the thread inverts the affine
+// map, visits the integer output positions within sqrt(2)/pitch of the pre-image, re-derives each one's corners and
+// weights with EXACTLY the forward's arithmetic (so this is the transpose of the forward, not an approximation of it) and
+// accumulates weight x gradient over its channels in registers.  Crops that share a map are summed in index order.
+constexpr int BWD_TW = 32, BWD_TH = 8;   // map pixels per workgroup (a wave stores two 128-byte row segments)
+constexpr int BWD_CPB = 32;              // channels per thread (accumulators in registers)
+
+struct CropGeom {
+    int n;
+    float cs, sn, t02, t12;
+};
+
+__global__ __launch_bounds__(256) void k_crop_rotate_bwd(const float *__restrict__ g, int n, const int *__restrict__ map_index, int C, int H,
+                                                         int W, const float *__restrict__ locs, const float *__restrict__ oris, float ppm,
+                                                         int crop, float ox, float oy, float *__restrict__ grad_feat) {
+    __shared__ CropGeom s_crop[256];
+    __shared__ int s_wave_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_x = (W + BWD_TW - 1) / BWD_TW;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int sx = tile_x * BWD_TW + (tid & (BWD_TW - 1)), sy = tile_y * BWD_TH + tid / BWD_TW;
+    const int m = blockIdx.z;
+    const int c_lo = blockIdx.y * BWD_CPB;
+    const bool inside_map = sx < W && sy < H;
+    const float k = (float)crop / (float)H;
+    const float step = 2.f / (float)(crop - 1);
+    // output pixels per map pixel along each axis of the (rotated) grid; the pre-image of the 2 x 2 square around a map pixel
+    // lies within `reach` output pixels of the pre-image of its centre
+    const float pitch_min = fminf(k * step * 0.5f * (float)(W - 1), k * step * 0.5f * (float)(H - 1));
+    const float reach = 1.41421357f / pitch_min + 0.01f;
+    const int span = (int)floorf(2.f * reach) + 1;
+    const long cc = (long)crop * crop;
+    float acc[BWD_CPB];
+#pragma unroll
+    for (int c = 0; c < BWD_CPB; ++c) acc[c] = 0.f;
+
+    for (int base = 0; base < n; base += 256) {
+        // the crops of this pass that sample map m, in index order (ordered compaction: the sum below must not depend on timing)
+        const int i = base + tid;
+        const bool mine = i < n && map_index[i] == m;
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) s_wave_cnt[wid] = __popcll(bal);
+        __syncthreads();
+        int pos = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wid) pos += s_wave_cnt[w];
+            total += s_wave_cnt[w];
         }
+        if (mine) {
+            const float o = oris[i];
+            const float cs = cosf(o), sn = sinf(o);
+            const float rx = locs[i * 2 + 0] * ppm / ((float)H / 2.f);
+            const float ry = locs[i * 2 + 1] * ppm / ((float)W / 2.f);
+            s_crop[pos] = CropGeom{i, cs, sn, -k * ox * cs + k * oy * sn + ox + rx, -k * ox * sn - k * oy * cs + oy + ry};
+        }
+        __syncthreads();
+        for (int q = 0; q < total; ++q) {
+            const CropGeom cg = s_crop[q];
+            // pre-image of the centre of (sy, sx): grid position, then output-pixel coordinates
+            const float u = (2.f * (float)sx / (float)(W - 1) - 1.f - cg.t02) / k;
+            const float v = (2.f * (float)sy / (float)(H - 1) - 1.f - cg.t12) / k;
+            const float px = ((cg.cs * u + cg.sn * v) + 1.f) / step, py = ((-cg.sn * u + cg.cs * v) + 1.f) / step;
+            const int xlo = max((int)ceilf(px - reach), 0), xhi = min((int)floorf(px + reach), crop - 1);
+            const int ylo = max((int)ceilf(py - reach), 0), yhi = min((int)floorf(py + reach), crop - 1);
+            const bool any_here = inside_map && xlo <= xhi && ylo <= yhi;
+            if (!__any(any_here)) continue;
+            const float *gq = g + ((long)cg.n * C + c_lo) * cc;
+            const int nch = min(BWD_CPB, C - c_lo);
+            for (int dy = 0; dy < span; ++dy)
+                for (int dx = 0; dx < span; ++dx) {
+                    const int x = xlo + dx, y = ylo + dy;
+                    float wgt = 0.f;
+                    if (any_here && x <= xhi && y <= yhi) {
+                        // the forward's arithmetic for output pixel (y, x), verbatim
+                        const float xs = lin(x, crop), ys = lin(y, crop);
+                        const float gx = k * cg.cs * xs + (k * -cg.sn) * ys + cg.t02;
+                        const float gy = k * cg.sn * xs + k * cg.cs * ys + cg.t12;
+                        const float ix = (gx + 1.f) * 0.5f * (float)(W - 1);
+                        const float iy = (gy + 1.f) * 0.5f * (float)(H - 1);
+                        const float fx = floorf(ix), fy = floorf(iy);
+                        const int x0 = (int)fx, y0 = (int)fy;
+                        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                        // (sy, sx) is inside the map, so a corner that equals it is a valid corner
+                        const float wx = sx == x0 ? wx0 : (sx == x0 + 1 ? wx1 : 0.f);
+                        const float wy = sy == y0 ? wy0 : (sy == y0 + 1 ? wy1 : 0.f);
+                        wgt = wx * wy;
+                    }
+                    if (wgt != 0.f) {
+                        const float *gp = gq + (long)y * crop + x;
+                        if (nch == BWD_CPB) {
+#pragma unroll
+                            for (int c = 0; c < BWD_CPB; ++c) acc[c] = fmaf(wgt, gp[c * cc], acc[c]);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < BWD_CPB; ++c)
+                                if (c < nch) acc[c] = fmaf(wgt, gp[c * cc], acc[c]);
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (inside_map) {
+        float *o = grad_feat + ((long)m * C + c_lo) * H * W + (long)sy * W + sx;
+#pragma unroll
+        for (int c = 0; c < BWD_CPB; ++c)
+            if (c_lo + c < C) o[(long)c * H * W] = acc[c];
     }
 }
 }  // namespace
 
 namespace {
-int crop_launch(bool backward, float *feat, int nmaps, const int *map_index, int C, int H, int W, const float *locs, const float *oris,
-                int n, float ppm, int crop, float ox, float oy, float *out, hipStream_t st, const char *what) {
+int crop_launch(const float *feat, int nmaps, const int *map_index, int C, int H, int W, const float *locs, const float *oris, int n,
+                float ppm, int crop, float ox, float oy, float *out, hipStream_t st) {
     const int c_per_block = 32;
     dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
-    const int tok = timer_begin(what, st);
-    if (backward)
-        hipLaunchKernelGGL(k_crop_rotate<true>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out, backward ? nullptr : lav::batch_limit());
-    else
-        hipLaunchKernelGGL(k_crop_rotate<false>, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block, out, backward ? nullptr : lav::batch_limit());
+    const int tok = timer_begin("crop_rotate", st);
+    hipLaunchKernelGGL(k_crop_rotate, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block,
+                       out, lav::batch_limit());
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
@@ -103,8 +204,8 @@ extern "C" int lav_crop_rotate(const float *feat, int feat_batch, int C, int H, 
     if (n == 0) return LAV_OK;
     LAV_REQUIRE(feat && locs && oris && out, "lav_crop_rotate: null argument");
     LAV_REQUIRE(feat_batch == 1 || feat_batch == n, "lav_crop_rotate: feat_batch must be 1 or n");
-    return crop_launch(false, const_cast<float *>(feat), feat_batch, nullptr, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x,
-                       offset_y, out, static_cast<hipStream_t>(stream), "crop_rotate");
+    return crop_launch(feat, feat_batch, nullptr, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x, offset_y, out,
+                       static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lav_crop_rotate_indexed(const float *feat, int num_maps, const int *map_index, int C, int H, int W, const float *locs,
@@ -113,8 +214,8 @@ extern "C" int lav_crop_rotate_indexed(const float *feat, int num_maps, const in
     LAV_REQUIRE(n >= 0 && num_maps >= 1 && C > 0 && H > 1 && W > 1 && crop > 1, "lav_crop_rotate_indexed: bad sizes");
     if (n == 0) return LAV_OK;
     LAV_REQUIRE(feat && map_index && locs && oris && out, "lav_crop_rotate_indexed: null argument");
-    return crop_launch(false, const_cast<float *>(feat), num_maps, map_index, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x,
-                       offset_y, out, static_cast<hipStream_t>(stream), "crop_rotate");
+    return crop_launch(feat, num_maps, map_index, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x, offset_y, out,
+                       static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lav_crop_rotate_backward(const float *grad_out, int num_maps, const int *map_index, int C, int H, int W, const float *locs,
@@ -122,10 +223,15 @@ extern "C" int lav_crop_rotate_backward(const float *grad_out, int num_maps, con
                                         float *grad_feat, void *stream) {
     LAV_REQUIRE(n >= 0 && num_maps >= 1 && C > 0 && H > 1 && W > 1 && crop > 1, "lav_crop_rotate_backward: bad sizes");
     LAV_REQUIRE(grad_feat, "lav_crop_rotate_backward: null argument");
+    LAV_REQUIRE(num_maps <= 65535, "lav_crop_rotate_backward: too many maps");
+    LAV_REQUIRE(n == 0 || (grad_out && map_index && locs && oris), "lav_crop_rotate_backward: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LAV_HIP(hipMemsetAsync(grad_feat, 0, (size_t)num_maps * C * H * W * sizeof(float), st));
-    if (n == 0) return LAV_OK;
-    LAV_REQUIRE(grad_out && map_index && locs && oris, "lav_crop_rotate_backward: null argument");
-    return crop_launch(true, grad_feat, num_maps, map_index, C, H, W, locs, oris, n, pixels_per_meter, crop, offset_x, offset_y,
-                       const_cast<float *>(grad_out), st, "crop_rotate_backward");
+    // every pixel of grad_feat is written (zeros where no crop samples it): no memset, no atomics
+    dim3 grid(((W + BWD_TW - 1) / BWD_TW) * ((H + BWD_TH - 1) / BWD_TH), (C + BWD_CPB - 1) / BWD_CPB, num_maps);
+    const int tok = timer_begin("crop_rotate_backward", st);
+    hipLaunchKernelGGL(k_crop_rotate_bwd, grid, dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris, pixels_per_meter, crop,
+                       offset_x, offset_y, grad_feat);
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
 }

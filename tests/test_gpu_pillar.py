@@ -85,6 +85,15 @@ def test_pillar_properties(ppn):
     d, _, _ = run(ppn, [pts], [50000])
     e, _, _ = run(ppn, [pts[:50000]], [50000])
     assert np.array_equal(d, e)
+    # the pairing hint of k_rows (per-class loads of the PREVIOUS call) moves time, never results: a stale hint from a very
+    # different cloud and the cloud's own hint give the same bits
+    other = pts.copy()
+    other[:, 0], other[:, 1] = 60.0 - pts[:, 0], -pts[:, 1]
+    run(ppn, [pts], [len(pts)])
+    f, ucf, _ = run(ppn, [other], [len(other)])
+    g, ucg, _ = run(ppn, [other], [len(other)])
+    assert np.array_equal(f, g)
+    np.testing.assert_array_equal(ucf, ucg)
 
 
 def test_pillar_336_grid():

@@ -125,25 +125,32 @@ def test_train_lidar_on_gpu_matches_reference_trainer(golden):
         assert info["ego_plan_locs"].shape == (20, 2) and np.isfinite(info["ego_plan_locs"]).all()
 
 
-def test_crop_rotate_indexed_forward_backward_vs_grid_sample():
-    """lav_crop_rotate_indexed / lav_crop_rotate_backward (crops of per-sample maps by index, fp32-atomic backward) vs
-    torch's affine_grid + grid_sample on the materialised maps (uniplanner.py:310-352)."""
+@pytest.mark.parametrize("H,W,crop", [(40, 40, 24), (40, 40, 33), (56, 56, 24)])   # the reference only crops square maps
+def test_crop_rotate_indexed_forward_backward_vs_grid_sample(H, W, crop):
+    """lav_crop_rotate_indexed / lav_crop_rotate_backward (crops of per-sample maps by index; the backward is a gather over the
+    map's pixels: no atomics, bit-reproducible) vs torch's affine_grid + grid_sample on the materialised maps
+    (uniplanner.py:310-352)."""
     from lav_amd.planner_common import crop_feature_torch
     g = torch.Generator().manual_seed(4)
-    feat = torch.randn((3, 24, 40, 40), generator=g)
+    feat = torch.randn((3, 40, H, W), generator=g)            # 40 channels: one full and one ragged channel block
     idx = torch.tensor([2, 0, 0, 1, 2], dtype=torch.int32)
     locs = torch.tensor([[0.0, 0.0], [3.0, -6.0], [-4.0, 2.0], [8.0, 8.0], [30.0, -30.0]])          # the last one mostly off the map
     oris = torch.tensor([0.0, 0.4, -1.1, 3.0, 0.2])
     f_gpu = feat.to(DEV).requires_grad_(True)
-    out = ops.crop_rotate_indexed(f_gpu, idx.to(DEV), locs.to(DEV), oris.to(DEV), 2.0, 24, 0.0, 0.75)
+    out = ops.crop_rotate_indexed(f_gpu, idx.to(DEV), locs.to(DEV), oris.to(DEV), 2.0, crop, 0.0, 0.75)
     f_ref = feat.clone().requires_grad_(True)
-    ref = crop_feature_torch(f_ref[idx.long()], locs, oris, 2.0, 24, 0.0, 0.75)
+    ref = crop_feature_torch(f_ref[idx.long()], locs, oris, 2.0, crop, 0.0, 0.75)
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-5)
     w = torch.randn(ref.shape, generator=g)
     (out * w.to(DEV)).sum().backward()
     (ref * w).sum().backward()
     np.testing.assert_allclose(f_gpu.grad.cpu().numpy(), f_ref.grad.numpy(), rtol=0, atol=5e-5 * float(f_ref.grad.abs().max()))
     assert float(f_ref.grad[0].abs().sum()) > 0 and float(f_ref.grad[2].abs().sum()) > 0      # two crops share map 0: gradients accumulate
+    first = f_gpu.grad.clone()
+    f_gpu.grad = None
+    out2 = ops.crop_rotate_indexed(f_gpu, idx.to(DEV), locs.to(DEV), oris.to(DEV), 2.0, crop, 0.0, 0.75)
+    (out2 * w.to(DEV)).sum().backward()
+    assert torch.equal(first, f_gpu.grad)                                                       # run-to-run identical bits
 
 
 def test_train_lidar_loss_curve_vs_reference_trainer(golden):
