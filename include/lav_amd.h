@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 12
+#define LAV_ABI_VERSION 13
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -163,6 +163,28 @@ int lav_gru_plan_steps(const float *embd, const float *nxp, const float *cast_lo
                        const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                        const float *mlp_w, const float *mlp_b, float *out,
                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3b. GRU over a sequence with a saved tape - the TRAINING side of the same decoders: what nn.GRU (cuDNN there, MIOpen
+ *     here) does under UniPlanner.cast / _plan / BEVPlanner in train mode (team_code_v2/models/uniplanner.py:255-308,
+ *     lav/models/bev_planner_v2.py, called from lav/lav_final_v2.py:140-259 and lav/lav_privileged_v2.py:110-159).
+ *     One launch per time step (recurrent GEMM on MFMA fused with the gates); the input projection and the weight
+ *     gradients are plain GEMMs over all (row, step) pairs and are the caller's (see lav_amd/ops.py:gru_seq).
+ *
+ *     x      : input-side pre-activations W_ih u + b_ih, gate order (r, z, n): [R][T][3H] when x_per_step, else [R][3H]
+ *              (the same input at every step - the cast decoders)
+ *     h0     : [R][H];  w_hh [3H][H], b_hh [3H];  out [R][T][H];  tape [R][T][4][H] = (r, z, n, W_hn h + b_hn) per step
+ *              (may be NULL for an inference-only forward)
+ *   backward : dout [R][T][H] -> dx [R][T][3H] (gradient of x per step; sum over T for a shared x), dgh [R][T][3H]
+ *              (gradient of the recurrent-side pre-activations: dW_hh = dgh^T [h0, out[:, :-1]], db_hh = sum dgh), dh0 [R][H].
+ *              w_hh_t = W_hh transposed, [H][3H].  H must be a multiple of 16.  No atomics: results are bit-reproducible.
+ */
+int lav_gru_seq_forward(const float *x, int x_per_step, const float *h0, const float *w_hh, const float *b_hh,
+                        int R, int T, int H, float *out, float *tape, void *stream);
+size_t lav_gru_seq_backward_workspace_bytes(int R, int H);
+int lav_gru_seq_backward(const float *dout, const float *tape, const float *out, const float *h0, const float *w_hh_t,
+                         int R, int T, int H, float *dx, float *dgh, float *dh0,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. 2-D convolutions on the matrix cores (fp32-in / fp32-accumulate MFMA: exact fp32 products,

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_CAM = 4
 
 
@@ -74,6 +74,9 @@ SIGNATURES = {
     "lav_conv1d_pair_pack_weights": (_I, [_I, _P, _P]),
     "lav_conv1d_pair_lds_bytes": (_Z, [_I, _I, _I]),
     "lav_conv1d_pair": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "lav_gru_seq_forward": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "lav_gru_seq_backward_workspace_bytes": (_Z, [_I, _I]),
+    "lav_gru_seq_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "lav_attn_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "lav_det_decode": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "lav_batch_limit": (_I, [_P]),

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "gru_seq.hpp"
 
 namespace {
 using namespace lav;
@@ -213,6 +214,30 @@ __global__ __launch_bounds__(256) void k_plan_step(PlanArgs a, int it, int t) {
             }
         }
         __syncthreads();
+    }
+}
+
+// Many state rows (the trainer's frozen teacher: batch x commands = 100+ rows): a step is lav::launch_gru_fwd_step (16 rows x 16
+// units per workgroup, recurrent GEMM on MFMA) instead of k_plan_step, whose every workgroup walks ALL rows six at a time.
+// This kernel lays out what that step reads: u[r][t] = (target point in crop units, previous iteration's waypoint) and, on the
+// first iteration, the initial state h0[r] = embd[sample of r].
+constexpr int PLAN_MFMA_MIN_ROWS = 16;
+__global__ __launch_bounds__(256) void k_plan_inputs(PlanArgs a, int it, float *__restrict__ u, float *__restrict__ h0) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)a.R * a.T) {
+        const int r = (int)(i / a.T), t = (int)(i - (long)r * a.T);
+        int b, ci, c;
+        row_decode(a, r, b, ci, c);
+        const float *prev = it == 0 ? a.cast_locs + (((long)b * a.num_cmds + c) * a.T + t) * 2
+                                    : a.out + ((((long)b * a.iters + (it - 1)) * a.NC + ci) * a.T + t) * 2;
+        *reinterpret_cast<float4 *>(u + i * 4) =
+            make_float4(a.nxp[b * 2 + 0] * a.ppm / a.crop * 2.f - 1.f, a.nxp[b * 2 + 1] * a.ppm / a.crop * 2.f - 1.f, prev[0], prev[1]);
+    }
+    if (it == 0) {
+        for (long k = i; k < (long)a.R * a.H; k += (long)gridDim.x * 256) {
+            const int r = (int)(k / a.H);
+            h0[k] = a.embd[(long)(r / a.NC) * a.H + (k - (long)r * a.H)];
+        }
     }
 }
 
@@ -475,7 +500,8 @@ extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int n
 
 extern "C" size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T) {
     // step-per-launch path: h sequence [T][R][H] floats; persistent path: 2 granule buffers [R][H] u64 + status word
-    const size_t seq = (size_t)T * B * num_cmds * H * sizeof(float);
+    // (+ many-row path: initial state [R][H] and inputs [R][T][4])
+    const size_t seq = ((size_t)T * B * num_cmds * H + (size_t)B * num_cmds * H + (size_t)B * num_cmds * T * 4) * sizeof(float) + 512;
     const size_t gran = 2 * (size_t)PLAN_RC * H * sizeof(unsigned long long) + 256;
     return lav::align_up(seq > gran ? seq : gran, 256);
 }
@@ -517,9 +543,24 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
         LAV_LAUNCH_CHECK();
         return LAV_OK;
     }
+    const size_t seq_floats = lav::align_up((size_t)T * a.R * H, 64);
+    const bool many_rows = a.R >= PLAN_MFMA_MIN_ROWS && workspace_bytes >= (seq_floats + (size_t)a.R * H + 64 + (size_t)a.R * T * 4) * sizeof(float) &&
+                           !(impl && impl[0] == 'v');   // LAV_PLAN_IMPL=v: the VALU step kernel at any size (A/B knob)
+    float *h0 = a.hseq + seq_floats, *u = h0 + lav::align_up((size_t)a.R * H, 64);
     for (int it = 0; it < iters; ++it) {
-        for (int t = 0; t < T; ++t) {
-            hipLaunchKernelGGL(k_plan_step, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, it, t);
+        if (many_rows) {
+            hipLaunchKernelGGL(k_plan_inputs, dim3((unsigned)(((long)a.R * T + 255) / 256)), dim3(256), 0, st, a, it, u, h0);
+            for (int t = 0; t < T; ++t) {
+                lav::GruFwdArgs f{};
+                f.h_prev = t == 0 ? h0 : a.hseq + (long)(t - 1) * a.R * H; f.h_prev_stride = H;
+                f.u = u + (long)t * 4; f.u_stride = (long)T * 4; f.I = 4; f.w_ih = w_ih; f.b_ih = b_ih;
+                f.w_hh = w_hh; f.b_hh = b_hh;
+                f.h_out = a.hseq + (long)t * a.R * H; f.h_out_stride = H;
+                f.R = a.R; f.H = H;
+                lav::launch_gru_fwd_step(f, st);
+            }
+        } else {
+            for (int t = 0; t < T; ++t) hipLaunchKernelGGL(k_plan_step, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, it, t);
         }
         hipLaunchKernelGGL(k_plan_out, dim3(a.R), dim3(64 * OUT_WAVES), 0, st, a, it);
     }

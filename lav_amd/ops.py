@@ -216,6 +216,59 @@ def gru_plan(embd, nxp, cast_locs, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, iters: 
     return out
 
 
+class _GruSeq(torch.autograd.Function):
+    """GRU recurrence over a sequence on lav_gru_seq_forward / lav_gru_seq_backward (one launch per step, MFMA recurrent
+    GEMM fused with the gates).  Differentiable in x (the input-side pre-activations), h0, w_hh and b_hh; the weight
+    gradients are two GEMMs over the tape (rocBLAS through torch)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_hh, b_hh, T):
+        lib = _lib.load()
+        x, h0 = _f32c(x, "x"), _f32c(h0, "h0")
+        w_hh, b_hh = _f32c(w_hh, "w_hh"), _f32c(b_hh, "b_hh")
+        R, H = h0.shape
+        per_step = x.dim() == 3
+        if (per_step and tuple(x.shape) != (R, T, 3 * H)) or (not per_step and tuple(x.shape) != (R, 3 * H)):
+            raise RuntimeError(f"gru_seq: x has shape {tuple(x.shape)}, expected ({R}, {T}, {3 * H}) or ({R}, {3 * H})")
+        if tuple(w_hh.shape) != (3 * H, H) or b_hh.numel() != 3 * H:
+            raise RuntimeError("gru_seq: w_hh must be (3H, H) and b_hh (3H,)")
+        out = torch.empty((R, T, H), dtype=torch.float32, device=x.device)
+        need_tape = any(ctx.needs_input_grad[:4])
+        tape = torch.empty((R, T, 4, H), dtype=torch.float32, device=x.device) if need_tape else None
+        check(lib.lav_gru_seq_forward(_ptr(x), int(per_step), _ptr(h0), _ptr(w_hh), _ptr(b_hh), R, T, H, _ptr(out),
+                                      _ptr(tape) if need_tape else None, _stream()), "lav_gru_seq_forward")
+        if need_tape:
+            ctx.save_for_backward(tape, out, h0, w_hh)
+            ctx.per_step = per_step
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        tape, out, h0, w_hh = ctx.saved_tensors
+        R, T, H = out.shape
+        dout = _f32c(dout, "dout")
+        dx = torch.empty((R, T, 3 * H), dtype=torch.float32, device=out.device)
+        dgh = torch.empty((R, T, 3 * H), dtype=torch.float32, device=out.device)
+        dh0 = torch.empty((R, H), dtype=torch.float32, device=out.device)
+        if R == 0:
+            return (dx if ctx.per_step else dx.sum(1)), dh0, torch.zeros_like(w_hh), w_hh.new_zeros(3 * H), None
+        ws = _workspace("gru_seq_bwd", lib.lav_gru_seq_backward_workspace_bytes(R, H), out.device)
+        w_hh_t = w_hh.t().contiguous()
+        check(lib.lav_gru_seq_backward(_ptr(dout), _ptr(tape), _ptr(out), _ptr(h0), _ptr(w_hh_t), R, T, H, _ptr(dx), _ptr(dgh),
+                                       _ptr(dh0), _ptr(ws), ws.numel(), _stream()), "lav_gru_seq_backward")
+        h_prev = torch.cat([h0[:, None], out[:, :-1]], dim=1)                       # (R, T, H): the state each step started from
+        dw_hh = dgh.view(R * T, 3 * H).t() @ h_prev.reshape(R * T, H)
+        db_hh = dgh.sum(dim=(0, 1))
+        return (dx if ctx.per_step else dx.sum(1)), dh0, dw_hh, db_hh, None
+
+
+def gru_seq(x, h0, w_hh, b_hh, T: int):
+    """h_t = GRUCell(x_t, h_{t-1}) for t < T with the input side already projected: x (R,T,3H) or (R,3H) (the same input at
+    every step) = W_ih u + b_ih in torch's gate order (r, z, n); h0 (R,H) -> (R,T,H).  Same arithmetic as nn.GRU."""
+    return _GruSeq.apply(x, h0, w_hh, b_hh, int(T))
+
+
 def gru_plan_status(B: int, H: int, num_cmds: int, cmd: int, device, stream=None) -> int:
     """Status word of the last gru_plan launch on `stream` (default: the current one) with these sizes: 0 = completed,
     1 = the persistent kernel gave up waiting for its peers and returned NaN.  Synchronises that stream."""

@@ -143,7 +143,10 @@ class DecoderMixin:
         B = embd.size(0)
         u = embd[:, None].expand(-1, self.num_plan, -1).contiguous()
         h0 = embd.new_zeros((1, B, nc * H))
-        out, _ = torch._VF.gru(u, h0, [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, self.training, False, True)      # (B, T, nc*H)
+        if embd.is_cuda:   # liblav_amd's sequence GRU: the input is the same at every step, so it is projected once
+            out = ops.gru_seq(F.linear(embd, w_ih, b_ih), h0[0], w_hh, b_hh, self.num_plan)                       # (B, T, nc*H)
+        else:
+            out, _ = torch._VF.gru(u, h0, [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, self.training, False, True)
         out = out.view(B, self.num_plan, nc, H)
         w = torch.stack([m.weight for m in mlps])                                                               # (nc, 2, H)
         b = torch.stack([m.bias for m in mlps])                                                                 # (nc, 2)
@@ -163,7 +166,12 @@ class DecoderMixin:
         outs = []
         for _ in range(self.num_plan_iter):
             u = torch.cat([u0, plan_loc.transpose(0, 1).reshape(nb * B, T, 2)], dim=2)
-            step = torch.cumsum(self.plan_mlp(self.plan_gru(u, h0)[0]), dim=1)                                # (nb*B, T, 2)
+            if u.is_cuda:
+                g = self.plan_gru
+                hseq = ops.gru_seq(F.linear(u, g.weight_ih_l0, g.bias_ih_l0), h0[0], g.weight_hh_l0, g.bias_hh_l0, T)
+            else:
+                hseq = self.plan_gru(u, h0)[0]
+            step = torch.cumsum(self.plan_mlp(hseq), dim=1)                                                   # (nb*B, T, 2)
             plan_loc = step.view(nb, B, T, 2).transpose(0, 1) + plan_loc
             outs.append(plan_loc)
         return torch.stack(outs, dim=1)

@@ -86,6 +86,16 @@ def test_gru_vs_oracle_other_batch(models):
         ref = obev.cast(embd, usd)
     assert_close(up.cast(embd.to(DEV)).cpu().numpy(), ref.numpy(), atol=2e-5, what="cast B=15")
     assert up.cast(torch.zeros((0, 512), device=DEV)).shape == (0, 6, 20, 2)
+    # plan with many state rows (15 samples x 6 commands = 90: the trainer's frozen teacher): the MFMA step path, against the
+    # oracle and against the VALU step kernel
+    nxp = torch.from_numpy(r.normal(0.0, 10.0, (15, 2)).astype(np.float32))
+    with torch.no_grad():
+        ref_plan = obev.plan(embd, nxp, ref, usd)
+    cast = up.cast(embd.to(DEV))
+    got = up.plan(embd.to(DEV), nxp.to(DEV), cast_locs=cast, pixels_per_meter=4, crop_size=192)
+    assert_close(got.cpu().numpy(), ref_plan.numpy(), atol=1e-4, what="plan B=15, all commands (MFMA steps)")
+    one = up.plan(embd.to(DEV), nxp.to(DEV), cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=2)     # 15 rows: VALU steps
+    assert_close(one[:, :, 0].cpu().numpy(), got[:, :, 2].cpu().numpy(), atol=2e-5, what="plan B=15, one command")
 
 
 def test_plan_timeout_is_loud_and_recoverable(golden, monkeypatch):

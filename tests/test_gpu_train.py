@@ -153,6 +153,43 @@ def test_crop_rotate_indexed_forward_backward_vs_grid_sample(H, W, crop):
     assert torch.equal(first, f_gpu.grad)                                                       # run-to-run identical bits
 
 
+@pytest.mark.parametrize("R,T,I,H,shared", [(37, 7, 4, 512, False), (5, 20, 4, 48, False), (70, 20, 512, 384, True), (16, 1, 8, 64, False)])
+def test_gru_seq_forward_backward_vs_torch_gru(R, T, I, H, shared):
+    """lav_gru_seq_forward / _backward (one launch per step: MFMA recurrent GEMM + gates; gather-style backward, no atomics)
+    against torch's nn.GRU on the CPU in fp32: outputs and the gradients of the input, the initial state and all four
+    parameter tensors within 1e-4 of the largest reference value (uniplanner.py:255-308 in train mode).  `shared`: the
+    same input at every step (the cast decoders) - projected once, its gradient summed over the steps."""
+    g = torch.Generator().manual_seed(R * 1000 + H)
+    gru = torch.nn.GRU(I, H, batch_first=True)
+    with torch.no_grad():
+        for p_ in gru.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.5 / H ** 0.5))
+    u = torch.randn((R, I) if shared else (R, T, I), generator=g)
+    h0 = torch.randn((R, H), generator=g) * 0.5
+    w = torch.randn((R, T, H), generator=g)
+    # reference
+    u_ref, h0_ref = u.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+    seq = u_ref[:, None].expand(-1, T, -1).contiguous() if shared else u_ref
+    out_ref, _ = gru(seq, h0_ref[None])
+    (out_ref * w).sum().backward()
+    ref_grads = [u_ref.grad, h0_ref.grad] + [p_.grad.clone() for p_ in gru.parameters()]
+    # HIP
+    par = [p_.detach().clone().to(DEV).requires_grad_(True) for p_ in gru.parameters()]        # w_ih, w_hh, b_ih, b_hh
+    u_gpu, h0_gpu = u.to(DEV).requires_grad_(True), h0.to(DEV).requires_grad_(True)
+    out = ops.gru_seq(torch.nn.functional.linear(u_gpu, par[0], par[2]), h0_gpu, par[1], par[3], T)
+    (out * w.to(DEV)).sum().backward()
+    scale = float(out_ref.detach().abs().max())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=0, atol=1e-4 * scale)
+    for name, got, want in zip(("du", "dh0", "dw_ih", "dw_hh", "db_ih", "db_hh"), [u_gpu.grad, h0_gpu.grad] + [p_.grad for p_ in par], ref_grads):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-4 * float(want.abs().max()), err_msg=name)
+    # bit-reproducible (no atomics anywhere in the layer's own kernels)
+    first = h0_gpu.grad.clone()
+    h0_gpu.grad = None
+    out2 = ops.gru_seq(torch.nn.functional.linear(u_gpu, par[0], par[2]), h0_gpu, par[1], par[3], T)
+    (out2 * w.to(DEV)).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(first, h0_gpu.grad)
+
+
 def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     """BASELINE.json config #5 ("loss-curve match to reference for 500 steps"): the reference's LAV.train_lidar
     (lav/lav_final_v2.py:140-259, the loop of lav/train_full_v2.py:24-46) ran 500 optimisation steps on CPU over four
