@@ -287,15 +287,28 @@ def main():
         m = micro["agent_196608pts"]
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed PMC pass of this very kernel (counters cannot be read from inside a run)
-            with open(os.path.join(REPO, "profiles", "r02_a_pmc_pillar.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r02_b_pmc_pillar.json")) as f:
                 pm = json.load(f)
             traffic = pm["k_rows"][str(m["points"])]["traffic_bytes"]
-            traffic_src = "profiles/r02_a_pmc_pillar.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, on this round's kernels)"
+            traffic_src = "profiles/r02_b_pmc_pillar.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, on the final kernels of round 2)"
         except Exception:
             pass
-        roofline = dict(bound="hbm", kernel="k_rows (pillar PointNet + scatter-max + canvas)", achieved=m["achieved"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=m["frac"], traffic=traffic, traffic_source=traffic_src, points=m["points"], algorithmic_bytes=m["algorithmic_bytes"],
-                        avg_kernel_us=m["kernel_us"], launches=100)
+        # the PointNet is fused into the scatter kernel, so its roof is max(bytes / HBM peak, flops / matrix peak).
+        # At the frame's 196 608 points the matrix term is the larger one (2.0 GFLOP of fp32 MFMA = 12.8 us at 157.3 TFLOP/s
+        # against 4.4 us for the 34.9 MB): the kernel is matrix-bound there, HBM-bound at config #2's 32 768 points
+        # (roofline_pillar_isolated carries both sizes with both figures).  `frac` is the fraction of the BINDING roof;
+        # the bytes figure stays beside it as frac_hbm / achieved_hbm.
+        hbm = dict(achieved=m["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=m["frac"], algorithmic_bytes=m["algorithmic_bytes"],
+                   bound_us=m["hbm_bound_us"])
+        common = dict(kernel="k_rows (pillar PointNet + scatter-max + canvas)", traffic=traffic, traffic_source=traffic_src, points=m["points"],
+                      avg_kernel_us=m["kernel_us"], launches=100, hbm_bound_us=m["hbm_bound_us"], mfma_bound_us=m["mfma_bound_us"],
+                      bound_rule="max(algorithmic bytes / 8 TB/s, algorithmic PointNet flops / 157.3 TFLOP/s), SURVEY 8(d)")
+        if m["mfma_bound_us"] > m["hbm_bound_us"]:
+            roofline = dict(bound="mfma", achieved=m["pointnet_tflops"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(m["pointnet_tflops"] / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=m["pointnet_flops"],
+                            frac_hbm=hbm["frac"], achieved_hbm_GBs=hbm["achieved"], algorithmic_bytes=m["algorithmic_bytes"], **common)
+        else:
+            roofline = dict(bound="hbm", **hbm, frac_mfma=round(m["pointnet_tflops"] / MFMA_F32_PEAK_TFLOPS, 4), **common)
 
     if rank == 0:
         res = dict(metric="frames/s full agent fwd (32k-pt LiDAR + 3 cams)", value=round(world * args.steps / dt, 2),

@@ -166,8 +166,9 @@ def test_every_layer_shape_of_the_frame_has_a_launch_plan():
     without a GPU: ERFNet on 3x(288x256), brake ResNet on 288x768 and 192x480, BEV stack, ResNet-18 on crops."""
     from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
     lib = _lib.load()
-    seg = RGBSegmentationModel([4, 6, 7, 10]).eval()
-    bra = RGBBrakePredictionModel([4, 6, 7, 10]).eval()
+    # train mode: the modules' torch path (eval mode is HIP only and raises on CPU tensors); the layer shapes are the same
+    seg = RGBSegmentationModel([4, 6, 7, 10]).train()
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]).train()
     todo = _conv_shapes_of(seg, [(3, 3, 288, 256)]) + _conv_shapes_of(bra, [(1, 3, 288, 768), (1, 3, 192, 480)])
     res = lav_amd.resnet18(num_channels=384)
     res.train(False)
