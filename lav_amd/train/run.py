@@ -89,9 +89,10 @@ def other_weight_schedule(it, beta=0.8):
 
 
 def main(what):
-    """Command line of lav/train_full_v2.py:48-70 / lav/train_bev_v2.py:42-63 (same flags and defaults) plus what this
-    build adds: --synthetic / --steps-per-epoch (seeded synthetic batches stand in for the LMDB loaders, which need the
-    `lmdb` package), --save-dir, --lidar / --bev / --uniplanner (checkpoints to start from), --max-points, --log-every."""
+    """Command line of lav/train_full_v2.py:48-70 / lav/train_bev_v2.py:42-63 (same flags and defaults): the recorded routes
+    under the config's `data_dir` are read by lav_amd.data ('temporal_lidar_painted' / 'temporal_bev' loaders, every rank its
+    own shard of each epoch).  What this build adds: --synthetic / --steps-per-epoch (seeded synthetic batches instead of a
+    data set), --save-dir, --lidar / --bev / --uniplanner (checkpoints to start from), --max-points, --log-every."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--config-path", default=None, help="the reference's config_v2.yaml (training keys are read from it)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
@@ -103,9 +104,9 @@ def main(what):
     ap.add_argument("--batch-size", type=int, default=32 if what == "lidar" else 256, help="GLOBAL batch, split over the ranks")
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--weight-decay", type=float, default=2e-4, help="accepted for command-line compatibility; the reference never passes it to Adam")
-    ap.add_argument("--num-workers", type=int, default=16, help="accepted for command-line compatibility (synthetic batches need no workers)")
+    ap.add_argument("--num-workers", type=int, default=16, help="DataLoader workers (recorded routes only)")
     ap.add_argument("--seed", type=int, default=2021)
-    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic batches (the only data source wired up)")
+    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic batches instead of the config's data_dir")
     ap.add_argument("--steps-per-epoch", type=int, default=20, help="iterations that make one epoch of synthetic data")
     ap.add_argument("--save-dir", default="checkpoints")
     ap.add_argument("--lidar", default=None, help="lidar_*.th to start from")
@@ -114,9 +115,8 @@ def main(what):
     ap.add_argument("--max-points", type=int, default=None)
     ap.add_argument("--log-every", type=int, default=None, help="steps between the eval-mode log inference (default: --num-per-log)")
     args = ap.parse_args()
-    if not args.synthetic:
-        raise SystemExit("only --synthetic batches are wired up: the LMDB readers of lav/utils/datasets need the `lmdb` "
-                         "package, which this image does not have")
+    if not args.synthetic and not args.config_path:
+        raise SystemExit("recorded routes are read from the data_dir of --config-path (or pass --synthetic)")
     rank, world, device = setup_distributed()
     if args.device == "cpu":
         device = torch.device("cpu")
@@ -129,15 +129,32 @@ def main(what):
     torch.manual_seed(cfg.seed + rank)
     lav = LAV(cfg, device, what=what, checkpoints=ck)
     log = lambda it, inf: print(it, {k: round(v, 4) for k, v in inf.items() if isinstance(v, float)}, flush=True)
-    global_it, t0 = 0, time.perf_counter()
-    for epoch in range(args.num_epoch):
+    loader = None
+    if not args.synthetic:
+        from ..data import get_data_loader
+        loader = get_data_loader("temporal_bev" if what == "bev" else "temporal_lidar_painted", args, rank=rank, world=world)
+        if len(loader) == 0:
+            raise SystemExit(f"{args.config_path}: data_dir holds fewer frames than one batch of {args.batch_size}")
+
+    def batches(epoch):
+        if loader is not None:
+            if world > 1:
+                loader.sampler.set_epoch(epoch)
+            yield from loader
+            return
         for it in range(args.steps_per_epoch):
             seed = cfg.seed + 1000003 * epoch + 1009 * it + 100 * rank
             if what == "bev":
-                batch = synthetic_bev_batch(per_rank, seed=seed, device=device)
+                yield synthetic_bev_batch(per_rank, seed=seed, device=device)
+            else:
+                yield synthetic_lidar_batch(per_rank, seed=seed, max_points=args.max_points or cfg.max_lidar_points, device=device)
+
+    global_it, t0 = 0, time.perf_counter()
+    for epoch in range(args.num_epoch):
+        for batch in batches(epoch):
+            if what == "bev":
                 info = lav.train_bev(*batch, other_weight=other_weight_schedule(global_it))
             else:
-                batch = synthetic_lidar_batch(per_rank, seed=seed, max_points=args.max_points or cfg.max_lidar_points, device=device)
                 info = lav.train_lidar(*batch)
             if global_it % args.num_per_log == 0 and rank == 0:
                 log(global_it, info)
@@ -155,6 +172,7 @@ def main(what):
     if rank == 0:
         print(json.dumps(dict(what=what, samples_per_s=round(args.batch_size * global_it / dt, 2), n_gpus=world,
                               global_batch=args.batch_size, steps=global_it, epochs=args.num_epoch,
+                              data="synthetic batches" if loader is None else f"{len(loader.dataset)} recorded frames",
                               lr=(lav.bev_optim if what == "bev" else lav.lidar_optim).param_groups[0]["lr"],
                               scheduler_epochs=(lav.bev_scheduler if what == "bev" else lav.lidar_scheduler).last_epoch)))
     if world > 1:

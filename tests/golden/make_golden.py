@@ -509,6 +509,50 @@ def gold_train_curve(steps=None):
         torch.set_grad_enabled(False)
 
 
+from tests.util import DATASET_CASES, dataset_fixture_config  # noqa: E402  (shared with tests/test_data_host.py)
+
+
+def gold_datasets():
+    """Samples of the REFERENCE's data loaders (lav/utils/datasets/*.py, the classes train_bev_v2.py / train_full_v2.py read
+    through get_data_loader) on the synthetic routes, with torch / numpy seeded per sample.  The classes run unmodified over
+    tests/golden/_shims/{lmdb,cv2,numba}.py; `lmdb` and `cv2` delegate to this repository's restatements
+    (lav_amd.data.lmdb_ro / image), so the fixture pins the loaders' logic - keys, actor filtering, frames, augmentation,
+    target maps, order of random draws - and not liblmdb's file format or OpenCV's interpolation (parity unpinned there)."""
+    import tempfile
+    import types
+    sys.path.insert(0, REF)
+    import lav.utils  # noqa: F401
+    pkg = types.ModuleType("lav.utils.datasets")          # skip the package __init__: it imports the RGB loaders' `imgaug`
+    pkg.__path__ = [os.path.join(REF, "lav", "utils", "datasets")]
+    sys.modules["lav.utils.datasets"] = pkg
+    from lav.utils.datasets.bev_dataset import BEVDataset
+    from lav.utils.datasets.lidar_dataset import LiDARDataset
+    from lav.utils.datasets.lidar_painted_dataset import LiDARPaintedDataset
+    from lav.utils.datasets.temporal_bev_dataset import TemporalBEVDataset
+    from lav.utils.datasets.temporal_lidar_painted_dataset import TemporalLiDARPaintedDataset
+    classes = dict(bev=BEVDataset, temporal_bev=TemporalBEVDataset, lidar=LiDARDataset, lidar_painted=LiDARPaintedDataset,
+                   temporal_lidar_painted=TemporalLiDARPaintedDataset)
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        cfg_path = dataset_fixture_config(root)
+        for name, picks in DATASET_CASES:
+            ds = classes[name](cfg_path)
+            out[f"{name}/len"] = len(ds)
+            where = {(os.path.basename(ds.dir_map[i]), ds.idx_map[i]): i for i in range(len(ds))}    # the reference walks routes in glob order
+            for route, frame in [("route_000", p) if p < 10 else ("route_001", p - 10) for p in picks]:
+                i = where[(route, frame)]
+                torch.manual_seed(1000 + frame)
+                np.random.seed(1000 + frame)
+                with torch.enable_grad():
+                    sample = ds[i]
+                for k, v in enumerate(sample):
+                    v = np.asarray(v)
+                    if name in ("lidar", "lidar_painted") and k == 0:
+                        v = v[:sample[1]]                       # the tail of these two loaders' point buffer is np.empty
+                    out[f"{name}/{route}/{frame}/{k}"] = v
+    save("datasets", **out)
+
+
 def gold_keys(lm, up):
     import json
     seg = RGBSegmentationModel([4, 6, 7, 10]); bra = RGBBrakePredictionModel([4, 6, 7, 10])
@@ -535,6 +579,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["train_curve"]:     # only the loss-curve fixture (hours of CPU time)
         gold_train_curve()
+        sys.exit(0)
+    if sys.argv[1:] == ["datasets"]:     # only the data-loader fixture
+        gold_datasets()
         sys.exit(0)
     if sys.argv[1:] == ["train"]:     # only the training fixture
         gold_train()

@@ -1,6 +1,8 @@
 """Training path on the GPU: the liblav_amd training ops (lav_pillar_decorate, lav_scatter_max + backward; through the
 C ABI) against the reference goldens / a torch restatement, train-mode PointPillarNet gradients, and two optimisation
 steps of train_lidar / train_bev against the REFERENCE trainers' loss terms (tests/golden/train.npz)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -233,3 +235,19 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     for j, k in enumerate(keys):
         if ref[-100:, j].mean() < 0.5 * ref[:20, j].mean():
             assert ours[-100:, j].mean() < 0.75 * ours[:20, j].mean(), f"{k} did not decrease like the reference's"
+
+
+def test_train_full_driver_reads_recorded_routes(tmp_path):
+    """train_full_v2.py without --synthetic on the MI355X: one epoch over a 3-frame synthetic route through the
+    'temporal_lidar_painted' loader of lav_amd.data (one batch of 2, drop_last) - loader dtypes / shapes meet the HIP training
+    step, checkpoints are written under the reference's names."""
+    import subprocess
+    import sys
+    from tests.util import dataset_fixture_config
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dataset_fixture_config(str(tmp_path), routes=1, frames=23)
+    out = subprocess.run([sys.executable, os.path.join(repo, "train_full_v2.py"), "--config-path", cfg, "--batch-size", "2", "--num-epoch", "1",
+                          "--num-workers", "0", "--save-dir", str(tmp_path / "ck")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert '"steps": 1' in out.stdout and "3 recorded frames" in out.stdout
+    assert os.path.exists(tmp_path / "ck" / "lidar_1.th") and os.path.exists(tmp_path / "ck" / "uniplanner_1.th")

@@ -73,3 +73,23 @@ def assert_close(a, b, atol, rtol=0.0, what=""):
     tol = atol + rtol * np.abs(b)
     bad = err > tol
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} beyond tol; max err {err.max():.3e} (|ref| max {np.abs(b).max():.3e})"
+
+
+# ---------------------------------------------------------------------------------------------- data-loader fixture
+DATASET_CASES = (("temporal_bev", (0, 9, 13)), ("bev", (3,)), ("lidar", (10,)), ("lidar_painted", (17,)), ("temporal_lidar_painted", (0, 3, 12)))
+
+
+def dataset_fixture_config(root, routes=2, frames=30):
+    """Route data + YAML of the loader fixture (tests/golden/make_golden.py:gold_datasets and tests/test_data_host.py build the
+    same thing): synthetic routes written by lav_amd.data.synthetic_route (seeded), the data-loader keys of the reference's
+    config_v2.yaml (tests/golden/dataset_config.yaml) with data_dir pointed at them."""
+    import yaml
+    from lav_amd.data import synthetic_route
+    synthetic_route.make_dataset(os.path.join(root, "data"), routes=routes, frames=frames, seed=0, points=2500)
+    with open(os.path.join(GOLD, "dataset_config.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["data_dir"] = os.path.join(root, "data")
+    path = os.path.join(root, "config.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return path
