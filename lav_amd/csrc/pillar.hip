@@ -10,10 +10,14 @@
 //           counter (2 sub-counters on different cache lines); the point is written ONCE as a 48-byte record
 //           {11 floats, packed cell} into the unit's fixed-capacity bucket, or appended to an overflow list when the
 //           bucket is full (adversarial clouds only).  No scan, no second pass over the cloud.
-//   k_rows  persistent workgroups, two per CU (W = 512).  Workgroup w OWNS units w, w + W, w + 2 W, ...: six or seven
-//           units spread evenly over the canvas, so that the dense cells around the ego vehicle are dealt out over the
-//           whole chip without any scan, queue or inter-workgroup traffic - a workgroup reads 16 counters and knows its
-//           work.  Its units are processed as one GROUP (up to 8 units = 256 tile columns):
+//           Extra workgroups of k_bin rank the point counts that the ownership classes of k_rows held in the PREVIOUS
+//           call and write the permutation class <- workgroup that pairs heavy with light classes on a CU (a hint: any
+//           permutation gives the same canvas).
+//   k_rows  persistent workgroups, two per CU (W = 512).  Ownership class w OWNS units w, w + W, w + 2 W, ...: six or
+//           seven units spread evenly over the canvas, so that the dense cells around the ego vehicle are dealt out over
+//           the whole chip without any scan, queue or inter-workgroup traffic - a workgroup reads which class it works on
+//           (perm[blockIdx]), then 16 counters, and knows its work.  Its units are processed as one GROUP (up to 8 units
+//           = 256 tile columns):
 //        (0) units without points stream zeros straight from registers;
 //        (a) per-cell xyz sums and counts in LDS (64-bit fixed point: order independent, so the canvas is
 //            bit-identical for ANY arrival order / input permutation; exact to 2^-32 m); only the tile columns that
