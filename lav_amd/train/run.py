@@ -14,15 +14,20 @@ from .synthetic import synthetic_bev_batch, synthetic_lidar_batch
 
 
 def setup_distributed():
-    """(rank, world, device).  One process per GPU; RCCL ("nccl") on GPUs, gloo otherwise."""
+    """(rank, world, device).  One process per GPU; RCCL ("nccl") on GPUs, gloo otherwise.  LAV_DIST_BACKEND=gloo forces
+    gloo with HIP tensors (gradients hop through the host) and lets ranks share a GPU (local rank modulo the device count):
+    how the data-parallel step over the HIP autograd functions is exercised on a one-GPU box (tests/test_gpu_train.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     cuda = torch.cuda.is_available()
+    backend = os.environ.get("LAV_DIST_BACKEND") or ("nccl" if cuda else "gloo")
     if cuda:
+        if backend == "gloo":
+            local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl" if cuda else "gloo")
+        dist.init_process_group(backend)
     return rank, world, torch.device("cuda", local) if cuda else torch.device("cpu")
 
 
@@ -169,8 +174,16 @@ def main(what):
     if device.type == "cuda":
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    in_sync = None
+    if world > 1:   # data parallel keeps the replicas identical: compare a checksum of every trained parameter across the ranks
+        # (BatchNorm's running statistics are per-rank by design - DDP re-broadcasts rank 0's before each forward - and are left out)
+        mods = (lav.bev_planner,) if what == "bev" else (lav.lidar_model, lav.uniplanner)
+        mine = torch.stack([p_.detach().double().sum() for m in mods for p_ in m.parameters() if p_.requires_grad]).to(device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        in_sync = all(torch.equal(every[0], e) for e in every[1:])
     if rank == 0:
-        print(json.dumps(dict(what=what, samples_per_s=round(args.batch_size * global_it / dt, 2), n_gpus=world,
+        print(json.dumps(dict(what=what, samples_per_s=round(args.batch_size * global_it / dt, 2), n_gpus=world, replicas_in_sync=in_sync,
                               global_batch=args.batch_size, steps=global_it, epochs=args.num_epoch,
                               data="synthetic batches" if loader is None else f"{len(loader.dataset)} recorded frames",
                               lr=(lav.bev_optim if what == "bev" else lav.lidar_optim).param_groups[0]["lr"],

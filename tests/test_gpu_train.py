@@ -254,3 +254,19 @@ def test_train_full_driver_reads_recorded_routes(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert '"steps": 1' in out.stdout and "3 recorded frames" in out.stdout
     assert os.path.exists(tmp_path / "ck" / "lidar_1.th") and os.path.exists(tmp_path / "ck" / "uniplanner_1.th")
+
+
+def test_two_rank_data_parallel_step_over_the_hip_autograd_functions(tmp_path):
+    """Two ranks of train_full_v2.py on this one GPU (gloo moves the gradients through the host - RCCL refuses two ranks on
+    a device; on a multi-GPU node the same code runs over RCCL): DistributedDataParallel's gradient hooks must fire for the
+    parameters that reach the loss through liblav_amd's autograd functions (sequence GRU, indexed crops, pillar ops) and
+    through find_unused_parameters for those that do not; after two optimisation steps both replicas hold identical weights."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29641", os.path.join(repo, "train_full_v2.py"), "--synthetic", "--batch-size", "2", "--num-epoch", "1",
+                          "--steps-per-epoch", "2", "--max-points", "20000", "--save-dir", str(tmp_path / "ck")],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, LAV_DIST_BACKEND="gloo"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert '"n_gpus": 2' in out.stdout and '"replicas_in_sync": true' in out.stdout and '"steps": 2' in out.stdout, out.stdout[-1500:]
