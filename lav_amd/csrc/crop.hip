@@ -9,6 +9,9 @@
 //   tx = -k ox cos + k oy sin + ox + loc_x * ppm/(H/2),   ty = -k ox sin - k oy cos + oy + loc_y * ppm/(W/2)
 //   grid (align_corners=True): xs = linspace(-1, 1, crop)[x], ys likewise;  gx = t00 xs + t01 ys + t02 ...
 //   sample (align_corners=True): ix = (gx + 1)/2 * (W-1), bilinear, zeros outside.
+#include <cmath>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -75,25 +78,58 @@ __global__ __launch_bounds__(256) void k_crop_rotate(const float *__restrict__ f
 // map, visits the integer output positions within sqrt(2)/pitch of the pre-image, re-derives each one's corners and
 // weights with EXACTLY the forward's arithmetic (so this is the transpose of the forward, not an approximation of it) and
 // accumulates weight x gradient over its channels in registers.  Crops that share a map are summed in index order.
-constexpr int BWD_TW = 32, BWD_TH = 8;   // map pixels per workgroup (a wave stores two 128-byte row segments)
+// A workgroup owns a 16 x 16 tile of the map: the output gradients it can touch lie in a (rotated) box of at most 27 x 27
+// pixels, which is staged in LDS eight channels at a time with coalesced row reads, so the per-pixel gathers hit LDS and
+// not 8+ L1 lines per wave instruction.
+constexpr int BWD_TW = 16, BWD_TH = 16;  // map pixels per workgroup: a square tile keeps its rotated pre-image compact
 constexpr int BWD_CPB = 32;              // channels per thread (accumulators in registers)
+constexpr int BWD_SUB = 8;               // channels staged in LDS at a time
+constexpr int BWD_CAP = 1024;            // floats per staged channel: bounding box of the tile's pre-image (<= 27 x 27 at pitch 1)
+constexpr int BWD_MAXSPAN = 3;           // candidates per axis the staged path holds in registers
 
 struct CropGeom {
     int n;
     float cs, sn, t02, t12;
 };
 
-__global__ __launch_bounds__(256) void k_crop_rotate_bwd(const float *__restrict__ g, int n, const int *__restrict__ map_index, int C, int H,
+// Weight with which output pixel (y, x) of a crop samples map pixel (sy, sx): the forward's arithmetic, verbatim (0 when
+// (sy, sx) is not one of its four corners).  (sy, sx) is inside the map, so a corner that equals it is a valid corner.
+__device__ __forceinline__ float corner_weight(const CropGeom &cg, float k, int x, int y, int sx, int sy, int W, int H, int crop) {
+    const float xs = lin(x, crop), ys = lin(y, crop);
+    const float gx = k * cg.cs * xs + (k * -cg.sn) * ys + cg.t02;
+    const float gy = k * cg.sn * xs + k * cg.cs * ys + cg.t12;
+    const float ix = (gx + 1.f) * 0.5f * (float)(W - 1);
+    const float iy = (gy + 1.f) * 0.5f * (float)(H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const float wx = sx == x0 ? wx0 : (sx == x0 + 1 ? wx1 : 0.f);
+    const float wy = sy == y0 ? wy0 : (sy == y0 + 1 ? wy1 : 0.f);
+    return wx * wy;
+}
+
+// Output-pixel coordinates (continuous) whose sample position is the centre of map pixel (sx, sy).
+__device__ __forceinline__ void preimage(const CropGeom &cg, float k, float step, float sx, float sy, int W, int H, float &px, float &py) {
+    const float u = (2.f * sx / (float)(W - 1) - 1.f - cg.t02) / k;
+    const float v = (2.f * sy / (float)(H - 1) - 1.f - cg.t12) / k;
+    px = ((cg.cs * u + cg.sn * v) + 1.f) / step;
+    py = ((-cg.sn * u + cg.cs * v) + 1.f) / step;
+}
+
+__global__ __launch_bounds__(256, 3) void k_crop_rotate_bwd(const float *__restrict__ g, int n, const int *__restrict__ map_index, int C, int H,
                                                          int W, const float *__restrict__ locs, const float *__restrict__ oris, float ppm,
                                                          int crop, float ox, float oy, float *__restrict__ grad_feat) {
     __shared__ CropGeom s_crop[256];
     __shared__ int s_wave_cnt[4];
+    __shared__ float s_g[BWD_SUB][BWD_CAP];   // the output gradients the tile can touch, BWD_SUB channels at a time
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tiles_x = (W + BWD_TW - 1) / BWD_TW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-    const int sx = tile_x * BWD_TW + (tid & (BWD_TW - 1)), sy = tile_y * BWD_TH + tid / BWD_TW;
+    const int tx0 = tile_x * BWD_TW, ty0 = tile_y * BWD_TH;
+    const int sx = tx0 + (tid & (BWD_TW - 1)), sy = ty0 + tid / BWD_TW;
     const int m = blockIdx.z;
     const int c_lo = blockIdx.y * BWD_CPB;
+    const int nch = min(BWD_CPB, C - c_lo);
     const bool inside_map = sx < W && sy < H;
     const float k = (float)crop / (float)H;
     const float step = 2.f / (float)(crop - 1);
@@ -130,44 +166,151 @@ __global__ __launch_bounds__(256) void k_crop_rotate_bwd(const float *__restrict
         __syncthreads();
         for (int q = 0; q < total; ++q) {
             const CropGeom cg = s_crop[q];
-            // pre-image of the centre of (sy, sx): grid position, then output-pixel coordinates
-            const float u = (2.f * (float)sx / (float)(W - 1) - 1.f - cg.t02) / k;
-            const float v = (2.f * (float)sy / (float)(H - 1) - 1.f - cg.t12) / k;
-            const float px = ((cg.cs * u + cg.sn * v) + 1.f) / step, py = ((-cg.sn * u + cg.cs * v) + 1.f) / step;
+            // bounding box (in output pixels) of everything the tile can be a corner of: the map is affine, so the extremes
+            // of the pre-image are at the tile's corners.  Workgroup-uniform.
+            float cx[4], cy[4];
+            preimage(cg, k, step, (float)tx0, (float)ty0, W, H, cx[0], cy[0]);
+            preimage(cg, k, step, (float)(tx0 + BWD_TW - 1), (float)ty0, W, H, cx[1], cy[1]);
+            preimage(cg, k, step, (float)tx0, (float)(ty0 + BWD_TH - 1), W, H, cx[2], cy[2]);
+            preimage(cg, k, step, (float)(tx0 + BWD_TW - 1), (float)(ty0 + BWD_TH - 1), W, H, cx[3], cy[3]);
+            const int bx0 = max((int)ceilf(fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3])) - reach) - 1, 0);
+            const int bx1 = min((int)floorf(fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3])) + reach) + 1, crop - 1);
+            const int by0 = max((int)ceilf(fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3])) - reach) - 1, 0);
+            const int by1 = min((int)floorf(fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3])) + reach) + 1, crop - 1);
+            if (bx0 > bx1 || by0 > by1) continue;   // the crop does not reach this tile
+            const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+            // this thread's candidates
+            float px, py;
+            preimage(cg, k, step, (float)sx, (float)sy, W, H, px, py);
+            const int xlo = max((int)ceilf(px - reach), 0), xhi = min((int)floorf(px + reach), crop - 1);
+            const int ylo = max((int)ceilf(py - reach), 0), yhi = min((int)floorf(py + reach), crop - 1);
+            const bool any_here = inside_map && xlo <= xhi && ylo <= yhi;
+            const float *gq = g + ((long)cg.n * C + c_lo) * cc;
+            if (bw * bh > BWD_CAP || bw > 32) __builtin_trap();   // the host only picks this kernel when the box always fits (crop_bwd_staged_ok)
+            {
+                // staged path: weights and LDS offsets of the (up to) 3 x 3 candidates in registers
+                float wgt[BWD_MAXSPAN * BWD_MAXSPAN];
+                int off[BWD_MAXSPAN * BWD_MAXSPAN];
+#pragma unroll
+                for (int dy = 0; dy < BWD_MAXSPAN; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < BWD_MAXSPAN; ++dx) {
+                        const int x = xlo + dx, y = ylo + dy;
+                        const bool live = any_here && dx < span && dy < span && x <= xhi && y <= yhi;
+                        const float w_ = live ? corner_weight(cg, k, x, y, sx, sy, W, H, crop) : 0.f;
+                        wgt[dy * BWD_MAXSPAN + dx] = w_;
+                        // a candidate with a weight lies inside the box by construction; the others read element 0
+                        off[dy * BWD_MAXSPAN + dx] = w_ != 0.f ? (y - by0) * bw + (x - bx0) : 0;
+                        __builtin_amdgcn_sched_barrier(0);   // one candidate at a time: nine interleaved copies of the weight arithmetic cost 100+ registers
+                    }
+#pragma unroll
+                for (int cs0 = 0; cs0 < BWD_CPB; cs0 += BWD_SUB) {
+                    if (cs0 < nch) {   // workgroup-uniform
+                        // rows of the box (channel-major), one per half-wave, coalesced; four rows in flight per thread
+                        const int rows = min(BWD_SUB, nch - cs0) * bh, l32 = tid & 31;
+                        const float *gs = gq + (long)cs0 * cc + (long)by0 * crop + bx0 + l32;
+                        for (int r0 = tid >> 5; r0 < rows; r0 += 32) {
+                            float v[4];
+                            int dst[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int r = r0 + 8 * u, c = r / bh, yy = r - c * bh;
+                                const bool ok = r < rows && l32 < bw;
+                                dst[u] = ok ? c * BWD_CAP + yy * bw + l32 : -1;
+                                v[u] = ok ? gs[(long)c * cc + (long)yy * crop] : 0.f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (dst[u] >= 0) (&s_g[0][0])[dst[u]] = v[u];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int c = 0; c < BWD_SUB; ++c) {
+#pragma unroll
+                            for (int j = 0; j < BWD_MAXSPAN * BWD_MAXSPAN; ++j) acc[cs0 + c] = fmaf(wgt[j], s_g[c][off[j]], acc[cs0 + c]);
+                            if (c & 1) __builtin_amdgcn_sched_barrier(0);   // 18 LDS reads in flight, not all 72 (registers)
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside_map) {
+        float *o = grad_feat + ((long)m * C + c_lo) * H * W + (long)sy * W + sx;
+#pragma unroll
+        for (int c = 0; c < BWD_CPB; ++c)
+            if (c_lo + c < C) o[(long)c * H * W] = acc[c];
+    }
+}
+
+// The same gradient without the LDS stage, for geometries whose boxes do not fit it (a map much larger or smaller than the
+// crop: pitch far from 1): 32 x 8 pixel tiles, candidates gathered from L2.
+__global__ __launch_bounds__(256) void k_crop_rotate_bwd_general(const float *__restrict__ g, int n, const int *__restrict__ map_index, int C,
+                                                                 int H, int W, const float *__restrict__ locs, const float *__restrict__ oris,
+                                                                 float ppm, int crop, float ox, float oy, float *__restrict__ grad_feat) {
+    __shared__ CropGeom s_crop[256];
+    __shared__ int s_wave_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_x = (W + 31) / 32;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int sx = tile_x * 32 + (tid & 31), sy = tile_y * 8 + (tid >> 5);
+    const int m = blockIdx.z;
+    const int c_lo = blockIdx.y * BWD_CPB;
+    const int nch = min(BWD_CPB, C - c_lo);
+    const bool inside_map = sx < W && sy < H;
+    const float k = (float)crop / (float)H;
+    const float step = 2.f / (float)(crop - 1);
+    const float pitch_min = fminf(k * step * 0.5f * (float)(W - 1), k * step * 0.5f * (float)(H - 1));
+    const float reach = 1.41421357f / pitch_min + 0.01f;
+    const int span = (int)floorf(2.f * reach) + 1;
+    const long cc = (long)crop * crop;
+    float acc[BWD_CPB];
+#pragma unroll
+    for (int c = 0; c < BWD_CPB; ++c) acc[c] = 0.f;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        const bool mine = i < n && map_index[i] == m;
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) s_wave_cnt[wid] = __popcll(bal);
+        __syncthreads();
+        int pos = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wid) pos += s_wave_cnt[w];
+            total += s_wave_cnt[w];
+        }
+        if (mine) {
+            const float o = oris[i];
+            const float cs = cosf(o), sn = sinf(o);
+            const float rx = locs[i * 2 + 0] * ppm / ((float)H / 2.f);
+            const float ry = locs[i * 2 + 1] * ppm / ((float)W / 2.f);
+            s_crop[pos] = CropGeom{i, cs, sn, -k * ox * cs + k * oy * sn + ox + rx, -k * ox * sn - k * oy * cs + oy + ry};
+        }
+        __syncthreads();
+        for (int q = 0; q < total; ++q) {
+            const CropGeom cg = s_crop[q];
+            float px, py;
+            preimage(cg, k, step, (float)sx, (float)sy, W, H, px, py);
             const int xlo = max((int)ceilf(px - reach), 0), xhi = min((int)floorf(px + reach), crop - 1);
             const int ylo = max((int)ceilf(py - reach), 0), yhi = min((int)floorf(py + reach), crop - 1);
             const bool any_here = inside_map && xlo <= xhi && ylo <= yhi;
             if (!__any(any_here)) continue;
             const float *gq = g + ((long)cg.n * C + c_lo) * cc;
-            const int nch = min(BWD_CPB, C - c_lo);
             for (int dy = 0; dy < span; ++dy)
                 for (int dx = 0; dx < span; ++dx) {
                     const int x = xlo + dx, y = ylo + dy;
-                    float wgt = 0.f;
-                    if (any_here && x <= xhi && y <= yhi) {
-                        // the forward's arithmetic for output pixel (y, x), verbatim
-                        const float xs = lin(x, crop), ys = lin(y, crop);
-                        const float gx = k * cg.cs * xs + (k * -cg.sn) * ys + cg.t02;
-                        const float gy = k * cg.sn * xs + k * cg.cs * ys + cg.t12;
-                        const float ix = (gx + 1.f) * 0.5f * (float)(W - 1);
-                        const float iy = (gy + 1.f) * 0.5f * (float)(H - 1);
-                        const float fx = floorf(ix), fy = floorf(iy);
-                        const int x0 = (int)fx, y0 = (int)fy;
-                        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                        // (sy, sx) is inside the map, so a corner that equals it is a valid corner
-                        const float wx = sx == x0 ? wx0 : (sx == x0 + 1 ? wx1 : 0.f);
-                        const float wy = sy == y0 ? wy0 : (sy == y0 + 1 ? wy1 : 0.f);
-                        wgt = wx * wy;
-                    }
-                    if (wgt != 0.f) {
+                    const float w_ = (any_here && x <= xhi && y <= yhi) ? corner_weight(cg, k, x, y, sx, sy, W, H, crop) : 0.f;
+                    if (w_ != 0.f) {
                         const float *gp = gq + (long)y * crop + x;
                         if (nch == BWD_CPB) {
 #pragma unroll
-                            for (int c = 0; c < BWD_CPB; ++c) acc[c] = fmaf(wgt, gp[c * cc], acc[c]);
+                            for (int c = 0; c < BWD_CPB; ++c) acc[c] = fmaf(w_, gp[c * cc], acc[c]);
                         } else {
 #pragma unroll
                             for (int c = 0; c < BWD_CPB; ++c)
-                                if (c < nch) acc[c] = fmaf(wgt, gp[c * cc], acc[c]);
+                                if (c < nch) acc[c] = fmaf(w_, gp[c * cc], acc[c]);
                         }
                     }
                 }
@@ -180,6 +323,16 @@ __global__ __launch_bounds__(256) void k_crop_rotate_bwd(const float *__restrict
         for (int c = 0; c < BWD_CPB; ++c)
             if (c_lo + c < C) o[(long)c * H * W] = acc[c];
     }
+}
+
+// Host side of the choice: the staged kernel holds 3 x 3 candidates per pixel and a box of at most 32 x 32 output pixels per tile.
+bool crop_bwd_staged_ok(int H, int W, int crop) {
+    const float k = (float)crop / (float)H, step = 2.f / (float)(crop - 1);
+    const float pitch_min = std::fmin(k * step * 0.5f * (float)(W - 1), k * step * 0.5f * (float)(H - 1));
+    const float reach = 1.41421357f / pitch_min + 0.01f;
+    const int span = (int)std::floor(2.f * reach) + 1;
+    const float box = (float)(BWD_TW - 1) * 1.41421357f / pitch_min + 2.f * reach + 3.f;   // upper bound of a tile's box side
+    return span <= BWD_MAXSPAN && box <= 32.f;
 }
 }  // namespace
 
@@ -227,10 +380,16 @@ extern "C" int lav_crop_rotate_backward(const float *grad_out, int num_maps, con
     LAV_REQUIRE(n == 0 || (grad_out && map_index && locs && oris), "lav_crop_rotate_backward: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // every pixel of grad_feat is written (zeros where no crop samples it): no memset, no atomics
-    dim3 grid(((W + BWD_TW - 1) / BWD_TW) * ((H + BWD_TH - 1) / BWD_TH), (C + BWD_CPB - 1) / BWD_CPB, num_maps);
+    const bool staged = crop_bwd_staged_ok(H, W, crop) && !getenv("LAV_CROP_BWD_GENERAL");   // (A/B knob)
+    const int tw = staged ? BWD_TW : 32, th = staged ? BWD_TH : 8;
+    dim3 grid(((W + tw - 1) / tw) * ((H + th - 1) / th), (C + BWD_CPB - 1) / BWD_CPB, num_maps);
     const int tok = timer_begin("crop_rotate_backward", st);
-    hipLaunchKernelGGL(k_crop_rotate_bwd, grid, dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris, pixels_per_meter, crop,
-                       offset_x, offset_y, grad_feat);
+    if (staged)
+        hipLaunchKernelGGL(k_crop_rotate_bwd, grid, dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris, pixels_per_meter, crop,
+                           offset_x, offset_y, grad_feat);
+    else
+        hipLaunchKernelGGL(k_crop_rotate_bwd_general, grid, dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris, pixels_per_meter,
+                           crop, offset_x, offset_y, grad_feat);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

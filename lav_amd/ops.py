@@ -235,6 +235,7 @@ class _GruSeq(torch.autograd.Function):
         out = torch.empty((R, T, H), dtype=torch.float32, device=x.device)
         need_tape = any(ctx.needs_input_grad[:4])
         tape = torch.empty((R, T, 4, H), dtype=torch.float32, device=x.device) if need_tape else None
+        train_work["gru_seq_forward_flops"] += 2 * R * H * 3 * H * T
         check(lib.lav_gru_seq_forward(_ptr(x), int(per_step), _ptr(h0), _ptr(w_hh), _ptr(b_hh), R, T, H, _ptr(out),
                                       _ptr(tape) if need_tape else None, _stream()), "lav_gru_seq_forward")
         if need_tape:
@@ -255,6 +256,7 @@ class _GruSeq(torch.autograd.Function):
             return (dx if ctx.per_step else dx.sum(1)), dh0, torch.zeros_like(w_hh), w_hh.new_zeros(3 * H), None
         ws = _workspace("gru_seq_bwd", lib.lav_gru_seq_backward_workspace_bytes(R, H), out.device)
         w_hh_t = w_hh.t().contiguous()
+        train_work["gru_seq_backward_flops"] += 2 * R * 3 * H * H * T
         check(lib.lav_gru_seq_backward(_ptr(dout), _ptr(tape), _ptr(out), _ptr(h0), _ptr(w_hh_t), R, T, H, _ptr(dx), _ptr(dgh),
                                        _ptr(dh0), _ptr(ws), ws.numel(), _stream()), "lav_gru_seq_backward")
         h_prev = torch.cat([h0[:, None], out[:, :-1]], dim=1)                       # (R, T, H): the state each step started from
@@ -476,6 +478,11 @@ class Conv1dPair:
         return y
 
 
+# algorithmic work of the training-side kernels since the last reset (bench.py's training roofline reads it next to the
+# library's HIP-event timers): bytes the crop gradient must move, flops of the recurrent GEMMs
+train_work = {"crop_rotate_backward_bytes": 0, "crop_rotate_backward_calls": 0, "gru_seq_forward_flops": 0, "gru_seq_backward_flops": 0}
+
+
 class _CropRotateIndexed(torch.autograd.Function):
     """Rotated crops taken from per-sample feature maps by index, differentiable in the maps (training path)."""
 
@@ -501,6 +508,8 @@ class _CropRotateIndexed(torch.autograd.Function):
         M, Cc, H, W, ppm, crop, ox, oy = ctx.geom
         grad_out = _f32c(grad_out, "grad_out")
         grad_feat = torch.empty((M, Cc, H, W), dtype=torch.float32, device=grad_out.device)
+        train_work["crop_rotate_backward_bytes"] += 4 * (grad_out.numel() + grad_feat.numel())     # read every output gradient once, write the map gradient once
+        train_work["crop_rotate_backward_calls"] += 1
         check(_lib.load().lav_crop_rotate_backward(_ptr(grad_out), M, _ptr(map_index), Cc, H, W, _ptr(locs), _ptr(oris), locs.shape[0], ppm,
                                                    crop, ox, oy, _ptr(grad_feat), _stream()), "lav_crop_rotate_backward")
         return grad_feat, None, None, None, None, None, None, None

@@ -31,8 +31,10 @@ def setup_distributed():
     return rank, world, torch.device("cuda", local) if cuda else torch.device("cpu")
 
 
-def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log=None):
-    """Runs warmup + steps optimisation steps on a fixed synthetic shard per rank; returns (seconds for `steps`, last info)."""
+def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log=None, profile_steps=0):
+    """Runs warmup + steps optimisation steps on a fixed synthetic shard per rank; returns (seconds for `steps`, last info).
+    profile_steps > 0: that many EXTRA steps after the timed region with the library's HIP-event timers armed; their per-kernel
+    times and the algorithmic work lav_amd.ops counted over the same steps come back in info["hand_kernels"]."""
     rank, world, device = setup_distributed()
     cfg = cfg or TrainConfig()
     if global_batch % world:
@@ -68,6 +70,27 @@ def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if profile_steps > 0 and device.type == "cuda":   # every rank steps (the gradient exchange needs them all)
+        import ctypes
+        from .. import _lib, ops
+        lib = _lib.load()
+        lib.lav_profile_enable(4096)
+        lib.lav_profile_reset()
+        for k in ops.train_work:
+            ops.train_work[k] = 0
+        for _ in range(profile_steps):
+            step()
+        torch.cuda.synchronize()
+        kernels = {}
+        for name in ("crop_rotate_backward", "crop_rotate", "gru_seq_forward", "gru_seq_backward", "gru_plan", "scatter_max", "pillar_decorate"):
+            ms, n = ctypes.c_double(), ctypes.c_int()
+            lib.lav_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n))
+            if n.value:
+                kernels[name] = dict(calls_per_step=n.value / profile_steps, ms_per_call=ms.value / n.value, ms_per_step=ms.value / profile_steps)
+        lib.lav_profile_enable(0)
+        info = dict(info, hand_kernels=dict(kernels=kernels, work_per_step={k: v / profile_steps for k, v in ops.train_work.items()}))
+    if world > 1:
+        dist.barrier()
     return dt, info, (rank, world)
 
 

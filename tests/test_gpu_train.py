@@ -127,12 +127,15 @@ def test_train_lidar_on_gpu_matches_reference_trainer(golden):
         assert info["ego_plan_locs"].shape == (20, 2) and np.isfinite(info["ego_plan_locs"]).all()
 
 
+@pytest.mark.parametrize("general", [False, True])
 @pytest.mark.parametrize("H,W,crop", [(40, 40, 24), (40, 40, 33), (56, 56, 24)])   # the reference only crops square maps
-def test_crop_rotate_indexed_forward_backward_vs_grid_sample(H, W, crop):
+def test_crop_rotate_indexed_forward_backward_vs_grid_sample(H, W, crop, general, monkeypatch):
     """lav_crop_rotate_indexed / lav_crop_rotate_backward (crops of per-sample maps by index; the backward is a gather over the
     map's pixels: no atomics, bit-reproducible) vs torch's affine_grid + grid_sample on the materialised maps
     (uniplanner.py:310-352)."""
     from lav_amd.planner_common import crop_feature_torch
+    if general:   # the kernel for geometries whose pre-image boxes do not fit the LDS stage (same arithmetic, gathers from L2)
+        monkeypatch.setenv("LAV_CROP_BWD_GENERAL", "1")
     g = torch.Generator().manual_seed(4)
     feat = torch.randn((3, 40, H, W), generator=g)            # 40 channels: one full and one ragged channel block
     idx = torch.tensor([2, 0, 0, 1, 2], dtype=torch.int32)
