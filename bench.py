@@ -151,6 +151,18 @@ def train_bench(args):
                         gru_seq_tflops={d: round(hk["work_per_step"][f"gru_seq_{d}_flops"] / (hk["kernels"][f"gru_seq_{d}"]["ms_per_step"] * 1e-3) / 1e12, 2)
                                         for d in ("forward", "backward") if f"gru_seq_{d}" in hk["kernels"]},
                         note="convolutions and BatchNorm of the step run on MIOpen (56 % + 8 % of its GPU time): this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
+    elif rank == 0 and hk and any(n.startswith("gru_seq") for n in hk["kernels"]):
+        # no crop gradient in this step: the sequence GRU (recurrent GEMM on MFMA fused with the gates, one launch per time step)
+        name = max((n for n in hk["kernels"] if n.startswith("gru_seq")), key=lambda n: hk["kernels"][n]["ms_per_step"])
+        k = hk["kernels"][name]
+        tf = hk["work_per_step"][f"{name}_flops"] / (k["ms_per_step"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=f"lav_{name} (k_gru_fwd_step / k_gru_bwd_step, one launch per time step)", achieved=round(tf, 2),
+                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                        algorithmic_flops=hk["work_per_step"][f"{name}_flops"] / max(k["calls_per_step"], 1e-9), avg_kernel_us=round(k["ms_per_call"] * 1e3, 1),
+                        launches=int(round(k["calls_per_step"] * 2)),
+                        hand_kernels_ms_per_step={n: round(v["ms_per_step"], 3) for n, v in hk["kernels"].items()},
+                        note="a step of these GRUs is a 192..400 x 512 x 1536 GEMM: latency-bound, not matrix-bound; convolutions and BatchNorm of the "
+                             "step run on MIOpen: this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
     if rank == 0:
         print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
