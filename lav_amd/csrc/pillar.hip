@@ -1071,7 +1071,7 @@ int fill_args(PillarArgs &a, const float *points, const int *h_num_points, int b
     a.UPR = w.upr;
     a.NUP = (int)align_up((size_t)batch * grid->ny * w.upr, 4);
     a.cap = w.cap;
-    a.nwg = std::min(persistent_workgroups(), batch * grid->ny * w.upr);
+    a.nwg = std::min(std::min(persistent_workgroups(), batch * grid->ny * w.upr), 2048);   // 2048: the pairing tables (load / perm, k_bin's s_key)
     a.trace = nullptr;
     return LAV_OK;
 }
