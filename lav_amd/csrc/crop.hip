@@ -69,6 +69,128 @@ __global__ __launch_bounds__(256) void k_crop_rotate(const float *__restrict__ f
     }
 }
 
+// The same crop with the source pixels staged through LDS.  A workgroup owns a 16 x 16 tile of one crop's output; the map
+// pixels its samples touch lie in a (rotated) box of at most ~27 x 27 pixels, read with coalesced row loads eight channels at
+// a time, so the four corner reads of every output pixel hit LDS instead of 8+ L1 lines per wave instruction.  Corners,
+// weights and the order of the four products are the unstaged kernel's: the outputs are bit-identical.
+constexpr int FWD_TILE = 16;
+constexpr int FWD_SUB = 8;       // channels staged at a time
+constexpr int FWD_CAP = 1024;    // floats per staged channel
+constexpr int FWD_CPB = 32;      // channels per workgroup
+
+struct SamplePos {
+    float w00, w01, w10, w11;
+    int cx0, cx1, cy0, cy1;
+};
+
+__device__ __forceinline__ SamplePos sample_pos(int x, int y, int crop, int H, int W, float k, float cs, float sn, float t02, float t12,
+                                                float &ix, float &iy) {
+    const float xs = lin(x, crop), ys = lin(y, crop);
+    const float gx = k * cs * xs + (k * -sn) * ys + t02;
+    const float gy = k * sn * xs + k * cs * ys + t12;
+    ix = (gx + 1.f) * 0.5f * (float)(W - 1);
+    iy = (gy + 1.f) * 0.5f * (float)(H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    SamplePos p;
+    p.w00 = (vx0 && vy0) ? wx0 * wy0 : 0.f; p.w01 = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+    p.w10 = (vx0 && vy1) ? wx0 * wy1 : 0.f; p.w11 = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+    p.cx0 = min(max(x0, 0), W - 1); p.cx1 = min(max(x1, 0), W - 1);
+    p.cy0 = min(max(y0, 0), H - 1); p.cy1 = min(max(y1, 0), H - 1);
+    return p;
+}
+
+__global__ __launch_bounds__(256, 3) void k_crop_rotate_staged(const float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index,
+                                                               int C, int H, int W, const float *__restrict__ locs,
+                                                               const float *__restrict__ oris, float ppm, int crop, float ox, float oy,
+                                                               float *__restrict__ out, const int *__restrict__ n_valid) {
+    __shared__ float s_f[FWD_SUB][FWD_CAP];
+    const int n = blockIdx.z;
+    if (n_valid && n >= *n_valid) return;   // lav_batch_limit (workgroup-uniform)
+    const int tid = threadIdx.x;
+    const int tiles_x = (crop + FWD_TILE - 1) / FWD_TILE;
+    const int ty0 = (int)(blockIdx.x / tiles_x) * FWD_TILE, tx0 = (int)(blockIdx.x % tiles_x) * FWD_TILE;
+    const int x = tx0 + (tid & (FWD_TILE - 1)), y = ty0 + tid / FWD_TILE;
+    const bool live = x < crop && y < crop;
+    const float o = oris[n];
+    const float cs = cosf(o), sn = sinf(o);
+    const float k = (float)crop / (float)H;
+    const float rx = locs[n * 2 + 0] * ppm / ((float)H / 2.f);
+    const float ry = locs[n * 2 + 1] * ppm / ((float)W / 2.f);
+    const float t02 = -k * ox * cs + k * oy * sn + ox + rx;
+    const float t12 = -k * ox * sn - k * oy * cs + oy + ry;
+    float ix, iy;
+    const SamplePos sp = sample_pos(min(x, crop - 1), min(y, crop - 1), crop, H, W, k, cs, sn, t02, t12, ix, iy);
+    // box of the tile's samples: the sample position is affine in (x, y), so its extremes are at the tile's corners (one pixel of
+    // margin for rounding); workgroup-uniform
+    float ex[4], ey[4];
+    const int xe = min(tx0 + FWD_TILE - 1, crop - 1), ye = min(ty0 + FWD_TILE - 1, crop - 1);
+    sample_pos(tx0, ty0, crop, H, W, k, cs, sn, t02, t12, ex[0], ey[0]);
+    sample_pos(xe, ty0, crop, H, W, k, cs, sn, t02, t12, ex[1], ey[1]);
+    sample_pos(tx0, ye, crop, H, W, k, cs, sn, t02, t12, ex[2], ey[2]);
+    sample_pos(xe, ye, crop, H, W, k, cs, sn, t02, t12, ex[3], ey[3]);
+    const float fx_lo = floorf(fminf(fminf(ex[0], ex[1]), fminf(ex[2], ex[3]))), fx_hi = floorf(fmaxf(fmaxf(ex[0], ex[1]), fmaxf(ex[2], ex[3])));
+    const float fy_lo = floorf(fminf(fminf(ey[0], ey[1]), fminf(ey[2], ey[3]))), fy_hi = floorf(fmaxf(fmaxf(ey[0], ey[1]), fmaxf(ey[2], ey[3])));
+    // (float clamps first: positions far outside the map must not overflow the integer conversion)
+    const int bx0 = (int)fminf(fmaxf(fx_lo - 1.f, 0.f), (float)(W - 1)), bx1 = (int)fminf(fmaxf(fx_hi + 2.f, 0.f), (float)(W - 1));
+    const int by0 = (int)fminf(fmaxf(fy_lo - 1.f, 0.f), (float)(H - 1)), by1 = (int)fminf(fmaxf(fy_hi + 2.f, 0.f), (float)(H - 1));
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    if (bw * bh > FWD_CAP || bw > 32) __builtin_trap();   // the host only picks this kernel when the box always fits (crop_fwd_staged_ok)
+    // this thread's four corners inside the box; a corner outside it (cannot happen by construction) is read from the map itself
+    const bool boxed = sp.cx0 >= bx0 && sp.cx1 <= bx1 && sp.cy0 >= by0 && sp.cy1 <= by1;
+    const int o00 = (sp.cy0 - by0) * bw + (sp.cx0 - bx0), o01 = (sp.cy0 - by0) * bw + (sp.cx1 - bx0);
+    const int o10 = (sp.cy1 - by0) * bw + (sp.cx0 - bx0), o11 = (sp.cy1 - by0) * bw + (sp.cx1 - bx0);
+    const long plane = (long)H * W, cc = (long)crop * crop;
+    const int m = map_index ? map_index[n] : (feat_batch > 1 ? n : 0);
+    const int c_lo = blockIdx.y * FWD_CPB, nch = min(FWD_CPB, C - c_lo);
+    const float *f = feat + ((long)m * C + c_lo) * plane;
+    float *o_ = out + ((long)n * C + c_lo) * cc + (long)y * crop + x;
+    const int l32 = tid & 31;
+    for (int cs0 = 0; cs0 < nch; cs0 += FWD_SUB) {
+        const int nsub = min(FWD_SUB, nch - cs0), rows = nsub * bh;
+        const float *fs = f + (long)cs0 * plane + (long)by0 * W + bx0 + l32;
+        for (int r0 = tid >> 5; r0 < rows; r0 += 32) {
+            float v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u, c = r / bh, yy = r - c * bh;
+                const bool ok = r < rows && l32 < bw;
+                dst[u] = ok ? c * FWD_CAP + yy * bw + l32 : -1;
+                v[u] = ok ? fs[(long)c * plane + (long)yy * W] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) (&s_f[0][0])[dst[u]] = v[u];
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < FWD_SUB; ++c) {
+                if (c < nsub) {
+                    float v;
+                    if (boxed) {
+                        v = s_f[c][o00] * sp.w00 + s_f[c][o01] * sp.w01 + s_f[c][o10] * sp.w10 + s_f[c][o11] * sp.w11;
+                    } else {
+                        const float *p = f + (long)(cs0 + c) * plane;
+                        v = p[sp.cy0 * W + sp.cx0] * sp.w00 + p[sp.cy0 * W + sp.cx1] * sp.w01 + p[sp.cy1 * W + sp.cx0] * sp.w10 + p[sp.cy1 * W + sp.cx1] * sp.w11;
+                    }
+                    o_[(long)(cs0 + c) * cc] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool crop_fwd_staged_ok(int H, int W, int crop) {
+    const float k = (float)crop / (float)H, step = 2.f / (float)(crop - 1);
+    const float pitch_max = std::fmax(k * step * 0.5f * (float)(W - 1), k * step * 0.5f * (float)(H - 1));   // map pixels per output pixel
+    return (float)(FWD_TILE - 1) * 1.41421357f * pitch_max + 5.f <= 32.f;
+}
+
 // Backward in GATHER form: one thread per pixel of the map gradient, no atomics, no memset, bit-reproducible.
 //
 // The scatter form (every output-pixel gradient added to its four source pixels with fp32 atomics - what torch's grid_sampler
@@ -340,10 +462,16 @@ namespace {
 int crop_launch(const float *feat, int nmaps, const int *map_index, int C, int H, int W, const float *locs, const float *oris, int n,
                 float ppm, int crop, float ox, float oy, float *out, hipStream_t st) {
     const int c_per_block = 32;
-    dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
     const int tok = timer_begin("crop_rotate", st);
-    hipLaunchKernelGGL(k_crop_rotate, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block,
-                       out, lav::batch_limit());
+    if (crop_fwd_staged_ok(H, W, crop) && !getenv("LAV_CROP_FWD_GENERAL")) {   // (A/B knob)
+        const int tiles = (crop + FWD_TILE - 1) / FWD_TILE;
+        hipLaunchKernelGGL(k_crop_rotate_staged, dim3(tiles * tiles, (C + FWD_CPB - 1) / FWD_CPB, n), dim3(256), 0, st, feat, nmaps, map_index, C,
+                           H, W, locs, oris, ppm, crop, ox, oy, out, lav::batch_limit());
+    } else {
+        dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
+        hipLaunchKernelGGL(k_crop_rotate, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block,
+                           out, lav::batch_limit());
+    }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

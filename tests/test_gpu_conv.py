@@ -122,6 +122,23 @@ def test_crop_rotate_matches_torch_grid_sample():
     assert_close(out.numpy(), ref.numpy(), atol=2e-4, what="rotated crop (per-sample maps)")
 
 
+def test_crop_rotate_staged_kernel_is_bit_identical_to_the_gathering_one(monkeypatch):
+    """The LDS-staged forward (16 x 16 output tiles, the touched box of the map read row by row) and the kernel that gathers its
+    four corners from L2: same corners, same weights, same order of the products - same bits.  Frame-sized map (the ego crop and
+    crops half off the map), a ragged channel block, a crop size that is not a multiple of the tile."""
+    from lav_amd import ops
+    locs = torch.tensor([[0.0, 0.0], [-5.0, -20.0], [7.5, -32.5], [38.0, 38.0], [-39.0, 3.0], [55.0, -60.0]]).to(DEV)
+    oris = torch.tensor([0.0, 0.3, -1.2, 2.9, -3.1, 0.78]).to(DEV)
+    for shape, crop in (((1, 40, 160, 160), 96), ((6, 8, 80, 80), 41)):
+        feat = rnd(shape, 33).to(DEV)
+        staged = ops.crop_rotate(feat, locs, oris, 2.0, crop, 0.0, 0.75)
+        monkeypatch.setenv("LAV_CROP_FWD_GENERAL", "1")
+        gathered = ops.crop_rotate(feat, locs, oris, 2.0, crop, 0.0, 0.75)
+        monkeypatch.delenv("LAV_CROP_FWD_GENERAL")
+        assert torch.equal(staged, gathered), f"{shape} crop {crop}: max |diff| {(staged - gathered).abs().max().item()}"
+        assert float(staged.abs().max()) > 0
+
+
 def test_workspace_growth_does_not_invalidate_captured_graphs():
     """A split-K layer captured in a HIP graph keeps working after a later, larger layer made the per-stream workspace
     grow: the old buffer (whose address is baked into the graph's kernel nodes) is retired, not freed."""
