@@ -70,6 +70,42 @@ def test_lmdb_picks_the_newer_meta_page(tmp_path):
     assert lmdb_ro.open(str(tmp_path / "swapped")).begin().get(b"key") == b"value"
 
 
+def test_lmdb_reader_fuzz(tmp_path):
+    """Random key / value populations (hypothesis): whatever the writer lays out, the reader returns it - including keys that are
+    prefixes of one another, the 511-byte maximum, empty values and values straddling the inline / overflow threshold."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    counter = [0]
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(st.dictionaries(st.binary(min_size=1, max_size=511), st.one_of(st.binary(max_size=64), st.binary(min_size=2000, max_size=2100),
+                                                                      st.binary(min_size=4000, max_size=9000)), max_size=120),
+           st.sampled_from([512, 4096, 16384]))
+    def run(items, psize):
+        counter[0] += 1
+        path = str(tmp_path / f"env{counter[0]}")
+        items = {k: v for k, v in items.items() if 8 + len(k) + 8 <= psize // 4}      # a key must leave room for two nodes on a page
+        lmdb_ro.write(path, items.items(), psize=psize)
+        env = lmdb_ro.open(path, readonly=True, lock=False)
+        txn = env.begin()
+        assert env.stat()["psize"] == psize and env.stat()["entries"] == len(items)
+        for k, v in items.items():
+            assert txn.get(k) == v
+            assert txn.get(k + b"\x00") == items.get(k + b"\x00") and txn.get(k[:-1]) == items.get(k[:-1])
+        assert list(txn.items()) == sorted(items.items())
+        env.close()
+    run()
+
+
+def test_synthetic_route_command_line(tmp_path):
+    out = subprocess.run([sys.executable, "-m", "lav_amd.data.synthetic_route", str(tmp_path / "d"), "--routes", "1", "--frames", "22", "--points", "300"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-1500:]
+    txn = lmdb_ro.open(str(tmp_path / "d" / "route_000")).begin()
+    assert int(txn.get(b"len")) == 22 and txn.get(b"town") == b"Town01" and len(txn.get(b"lidar_00021")) == 300 * 16
+    assert image.imdecode(np.frombuffer(txn.get(b"map_0_00000"), np.uint8), image.IMREAD_GRAYSCALE).shape == (320, 320)
+
+
 # ------------------------------------------------------------------------------------------------------------ images
 def test_warp_affine_identity_quarter_turn_and_small_angles():
     r = np.random.default_rng(0)
