@@ -3,7 +3,10 @@
 // Replaces crop_feature of the reference (team_code_v2/model_inference.py:204-238, uniplanner.py:310-352), which
 // materialises an (N, 96, 96, 2) sampling grid with a batched matmul and then runs torch's generic grid sampler
 // (measured 370-400 us per call here).  One thread computes the source position of one output pixel once and then
-// walks the 384 channels: 4 gathers + 1 coalesced store per channel.
+// walks the 384 channels: 4 corner reads + 1 coalesced store per channel.  Two kernels with identical arithmetic (and bits):
+// k_crop_rotate_staged - 16 x 16 output tiles, the touched box of the map staged through LDS (the common geometry, map pitch
+// ~ output pitch) - and k_crop_rotate, which gathers the corners from L2 (any geometry).  Training: lav_crop_rotate_indexed
+// (crop i from map map_index[i]) and lav_crop_rotate_backward (gather form, below).
 //
 //   theta = [[k cos, -k sin, tx], [k sin, k cos, ty]],  k = crop/H,
 //   tx = -k ox cos + k oy sin + ox + loc_x * ppm/(H/2),   ty = -k ox sin - k oy cos + oy + loc_y * ppm/(W/2)
