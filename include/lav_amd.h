@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 13
+#define LAV_ABI_VERSION 14
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -214,7 +214,15 @@ typedef struct lav_conv {
                           network that runs on a side stream next to another network's kernels */
     float pad_value;   /* what out-of-image taps read (0 = zero padding).  A network whose input normalisation x' = s*x + t
                           has been folded into its first convolution pads the RAW image with -t/s instead */
+    int precision;     /* how the fp32 contraction is evaluated: LAV_CONV_F32 = v_mfma_f32_32x32x2_f32 only (bit-for-bit an
+                          fmaf chain); LAV_CONV_BF16X6 = layers whose plan favours it run on the bf16 matrix cores with every
+                          fp32 operand split exactly into three bf16 pieces and the six leading partial products accumulated
+                          in fp32 (error of an fp32 dot product, 2.4x the matrix rate; fp32 subnormal inputs are flushed);
+                          0 = the library default (environment LAV_CONV_PRECISION = f32 | bf16x6, default bf16x6).  The
+                          packed weights of a layer depend on it: pack and run with the same descriptor */
 } lav_conv;
+#define LAV_CONV_F32 1
+#define LAV_CONV_BF16X6 2
 
 /* output spatial size of the convolution */
 int lav_conv_out_hw(const lav_conv *c, int *oh, int *ow);

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_CAM = 4
 
 
@@ -33,7 +33,10 @@ class Camera(C.Structure):
 class Conv(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "batch", "in_c_total", "in_c_offset", "cin", "h", "w", "cout", "kh", "kw", "stride", "pad_h", "pad_w",
-        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid", "target_cus")] + [("pad_value", C.c_float)]
+        "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid", "target_cus")] + [("pad_value", C.c_float), ("precision", C.c_int)]
+
+
+CONV_F32, CONV_BF16X6 = 1, 2     # lav_conv.precision (0 = library default: LAV_CONV_PRECISION, bf16x6)
 
 
 # name -> (restype, argtypes); every symbol declared in include/lav_amd.h

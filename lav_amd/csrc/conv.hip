@@ -21,6 +21,7 @@
 // offset store (fused torch.cat of lidar.py:143).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.hpp"
@@ -443,6 +444,8 @@ int build_plan(const lav_conv &c, Plan &p) {
     return LAV_OK;
 }
 
+#include "conv_split.hpp"
+
 // Tile shape + staging geometry.  Cost model (units: MFMA time of one k-step): a CU runs ceil(nwg/256) workgroups
 // back to back on its matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch.
 // Wide images switch to row-blocked tiles (a tile = PIXW pixels of ONE output-grid row) when the full-width rows of
@@ -779,6 +782,40 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
     if (mode == 2 && d.ok) d.cost = 0.0;
     return d;
 }
+// precision of a layer: LAV_CONV_F32 (exact fp32 MFMA kernels only) or LAV_CONV_BF16X6 (the split kernel where its plan
+// wins); 0 in the descriptor = LAV_CONV_PRECISION (f32 | bf16x6), default bf16x6
+int resolve_precision(const lav_conv &c) {
+    if (c.precision == LAV_CONV_F32 || c.precision == LAV_CONV_BF16X6) return c.precision;
+    static const int dflt = [] {
+        const char *e = getenv("LAV_CONV_PRECISION");
+        return e && (!strcmp(e, "f32") || !strcmp(e, "fp32")) ? LAV_CONV_F32 : LAV_CONV_BF16X6;
+    }();
+    return dflt;
+}
+
+// which kernel runs a layer: 0 tiled fp32, 1 direct fp32, 2 split bf16x6
+struct Choice {
+    int kind;
+    DirectPlan dp;
+    SplitPlan sp;
+};
+
+Choice decide(const lav_conv &c, const Plan &p, double tile_cost) {
+    Choice ch;
+    ch.dp = choose_direct(c, p);
+    ch.sp.ok = false;
+    ch.kind = ch.dp.ok && ch.dp.cost < tile_cost ? 1 : 0;
+    if (resolve_precision(c) == LAV_CONV_BF16X6) {
+        const char *e = getenv("LAV_CONV_SPLIT");   // 0 never / 1 by cost / 2 whenever the split kernel can take the layer
+        const int mode = e ? atoi(e) : 1;
+        if (mode) {
+            ch.sp = choose_split(c, p);
+            const double other = ch.kind == 1 ? ch.dp.cost : tile_cost;
+            if (ch.sp.ok && (mode == 2 || ch.sp.cost < other)) ch.kind = 2;
+        }
+    }
+    return ch;
+}
 }  // namespace
 
 extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
@@ -792,8 +829,14 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     double cost = 0;
     rc = choose_tile(*c, p, a, MP, MC, lds, &cost);
     if (rc) return rc;
-    const DirectPlan d = choose_direct(*c, p);
-    if (d.ok && d.cost < cost) {   // direct path: info[0] = 0, info[1] = waves per workgroup
+    const Choice ch = decide(*c, p, cost);
+    const DirectPlan &d = ch.dp;
+    if (ch.kind == 2) {   // split kernel: info[0] = -1, then MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows
+        info[0] = -1; info[1] = ch.sp.MP; info[2] = ch.sp.MC; info[3] = ch.sp.WPX; info[4] = ch.sp.tw; info[5] = (int)ch.sp.lds;
+        info[6] = ch.sp.ksplit; info[7] = ch.sp.tap_group; info[8] = ch.sp.th;
+        return LAV_OK;
+    }
+    if (ch.kind == 1) {   // direct path: info[0] = 0, info[1] = waves per workgroup
         info[0] = 0; info[1] = d.waves; info[2] = d.mc; info[3] = 0; info[4] = 0; info[5] = d.waves * d.mc * 32 * 33 * 4;
         info[6] = d.ksplit; info[7] = 1; info[8] = 1;
         return LAV_OK;
@@ -873,7 +916,8 @@ extern "C" size_t lav_conv_packed_weight_floats(const lav_conv *c) {
     if (!c) return 0;
     Plan p;
     if (build_plan(*c, p)) return 0;
-    return p.wfloats;
+    // the fp32 packing, followed (16-byte aligned) by the three-piece bf16 packing of the split kernel
+    return resolve_precision(*c) == LAV_CONV_BF16X6 ? (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 4 : p.wfloats;
 }
 
 extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed) {
@@ -895,6 +939,8 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
                     dst[(size_t)(co / 32) * t.size() * p.cin_pad * 32 + ((ti * p.cin_pad + ci) / 8) * 256 + ((ci & 1) * 32 + co % 32) * 4 + (ci % 8) / 2] = h_weight[src];
                 }
     }
+    if (resolve_precision(*c) == LAV_CONV_BF16X6)
+        split_pack_weights(*c, p, h_weight, reinterpret_cast<unsigned char *>(h_packed + (p.wfloats + 3) / 4 * 4));
     return LAV_OK;
 }
 
@@ -907,8 +953,9 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     size_t lds;
     double cost = 0;
     if (choose_tile(*c, p, a, MP, MC, lds, &cost)) return 0;
-    const DirectPlan d = choose_direct(*c, p);
-    if (d.ok && d.cost < cost) a.ksplit = d.ksplit;
+    const Choice ch = decide(*c, p, cost);
+    if (ch.kind == 1) a.ksplit = ch.dp.ksplit;
+    if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     return a.ksplit > 1 ? (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float) : 0;
 }
 
@@ -934,9 +981,11 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     double cost = 0;
     rc = choose_tile(*c, p, a, MP, MC, lds, &cost);
     if (rc) return rc;
-    const DirectPlan dp = choose_direct(*c, p);
-    const bool direct = dp.ok && dp.cost < cost;
+    const Choice ch = decide(*c, p, cost);
+    const DirectPlan &dp = ch.dp;
+    const bool direct = ch.kind == 1;
     if (direct) a.ksplit = dp.ksplit;
+    if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float);
         if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, need);
@@ -960,6 +1009,7 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         for (size_t t = 0; t < p.taps[cl].size(); ++t) a.toff[cl * p.taps_per_class + t] = p.taps[cl][t].dy * a.Wst + p.taps[cl][t].dx;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ch.kind == 2) return launch_split(*c, p, ch.sp, a, reinterpret_cast<const unsigned char *>(w_packed + (p.wfloats + 3) / 4 * 4), st);
     if (direct) {
         DirectArgs d;
         d.x = x; d.w = w_packed; d.bias = bias; d.scale = scale; d.shift = shift; d.res = residual; d.y = y; d.partial = a.partial;

@@ -1,0 +1,625 @@
+// fp32 convolution on the bf16 matrix cores by operand splitting - included by conv.hip (inside its namespace).
+//
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 matrix rate).  Every fp32 value is
+// the exact sum of three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significant bits; x1 = bf16(x - x0), ...), so
+//     a*b = a0b0 + (a0b1 + a1b0) + (a0b2 + a2b0 + a1b1) + O(2^-24 |ab|)
+// is six v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate) per 16 k-steps instead of eight fp32 MFMAs of 64
+// cycles: 192 instead of 512 matrix-pipe cycles, with the error of an fp32 dot product (tools/probes/split_mfma_probe.hip
+// on MI355X, K = 1152, 2^12 dynamic range: max |err| / sum|ab| 3.1e-7 against 6.3e-7 for the fp32 MFMA chain).  fp32
+// range is kept (bf16 has the fp32 exponent); fp32 SUBNORMAL inputs are flushed by the bf16 matrix pipe.
+//
+// Kernel structure (one workgroup = 8 waves):
+//   waves 0-3  compute: MP x MC tiles of 32 pixels x 32 couts each (wave grid WPX x 4/WPX), operands from LDS with one
+//              ds_read_b128 per (plane, tile row/column) and tap, software pipelined over taps
+//   waves 4-7  loaders.  Weights: pre-split packed weights [cout block][tap][16-channel chunk][plane][lane][8 bf16] move
+//              HBM/L2 -> LDS by asynchronous DMA (global_load_lds, 1 KB per instruction, pieces dealt round-robin to the
+//              four waves), one or two tap groups ahead (ring of 2-3 buffers).  Activations: NCHW fp32 -> registers
+//              (coalesced along the row, all loads of a chunk in flight, issued a whole chunk before they are needed) ->
+//              three bf16 pieces -> LDS as [plane][k half][position][8 channels] (16 bytes per entry = one lane's B
+//              operand), double buffered per 16-channel chunk.  Stride-s layers are staged column-parity split so
+//              that the 32 lanes of a tap read consecutive entries.
+//   barriers   one per (chunk, tap group); they order LDS only: the loaders wait with a COUNTED s_waitcnt vmcnt for the
+//              DMA the next stage needs, their register loads stay in flight across barriers.
+// The pixel tile is a 2-D block of the output grid (th rows x tw columns, tw a multiple of 32) - a 3x3 layer stages
+// (th+2)(tw+2) positions for th*tw pixels instead of three full-width rows per 128 - or PIXW consecutive linearised
+// pixels for maps narrower than 32.  Epilogue, split-K partials and transposed-convolution classes: as k_conv.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SPLIT_NT = 8;          // most staged positions per activation-loader thread (128 threads): plane <= 1024
+constexpr int SPLIT_LOADERS = 128;
+
+struct SplitArgs {
+    const float *x;
+    const unsigned char *w;          // split packed weights (bytes)
+    const float *bias, *scale, *shift, *res;
+    const int *n_valid;
+    float *y, *partial;
+    long long *trace;                // debug (LAV_SPLIT_TRACE): [workgroup][8] cycle counts
+    int in_c_total, in_c_offset, cin, H, W;
+    int cout, out_c_total, out_c_offset, OH, OW;
+    int nchunks, nblk_total;         // cin_pad / 16, cout_pad / 32
+    int QH, QW, in_s, out_s, nclasses, ksplit;
+    int tw, th, tiles_x;             // 2-D tile (tw = 0: linearised pixels)
+    int Wst, Wsub, ROWS, plane;      // staged patch: ROWS x Wst entries per (piece, k half), Wst = in_s * Wsub
+    int tap_group, taps_per_class;
+    int debug;                       // timing experiments (LAV_SPLIT_DEBUG bits: 1 no weight DMA, 2 no activation staging, 4 no MFMA): wrong results
+    int wring;                       // weight ring slots in LDS (one tap of the tile each): the DMA runs this many steps ahead
+    int relu_pre, relu_post, sigmoid;
+    float pad_value;
+    int cls_ntaps[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES], cls_out_oy[MAX_CLASSES], cls_out_ox[MAX_CLASSES];
+    long cls_woff[MAX_CLASSES];      // byte offset of the class's weights
+    int toff[MAX_TAPS];              // class c, tap t -> entry offset dy*Wst + (dx % in_s)*Wsub + dx / in_s
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate); n is rounded DOWN to a multiple
+// of 3 (the DMA wave issues three pieces per fragment), which only waits for a little more
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+    switch (min(n, 63) / 3) {
+#define LAV_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * k) : "memory"); break;
+        LAV_W(0) LAV_W(1) LAV_W(2) LAV_W(3) LAV_W(4) LAV_W(5) LAV_W(6) LAV_W(7) LAV_W(8) LAV_W(9) LAV_W(10)
+        LAV_W(11) LAV_W(12) LAV_W(13) LAV_W(14) LAV_W(15) LAV_W(16) LAV_W(17) LAV_W(18) LAV_W(19) LAV_W(20)
+#undef LAV_W
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+
+// barrier that adds the cycles spent in it to `acc` (trace builds of the loop only)
+#define SPLIT_TIMED(barrier_call, acc) do { if (a.trace) { const long long t_ = clock64(); barrier_call; acc += clock64() - t_; } else { barrier_call; } } while (0)
+
+// x -> three bf16 pieces (round half up on the dropped bits), returned in the HIGH halves of p0..p2
+__device__ __forceinline__ void split3(float x, unsigned &p0, unsigned &p1, unsigned &p2) {
+    p0 = (__float_as_uint(x) + 0x8000u) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(p0);          // exact
+    p1 = (__float_as_uint(r1) + 0x8000u) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(p1);         // exact
+    p2 = __float_as_uint(r2) + 0x8000u;                // low half is dropped by the pack
+}
+// {hi half of odd, hi half of even} -> one dword of two bf16 (even in the low half)
+__device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
+
+template <int MP, int MC>
+struct SplitOps {
+    u32x4 a[MC][3], b[MP][3];
+};
+
+// NT: staged positions per activation-loader thread (plane <= 192 * NT); every loader thread issues all 16 * NT loads
+// of a chunk unconditionally (clamped addresses, values selected afterwards): loads behind branches make the compiler
+// drain the queue at each join, one memory round trip per position
+template <int MP, int MC, int WPX, int NT>
+__global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
+    constexpr int WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = blockIdx.z % a.ksplit;
+    const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
+    if (a.n_valid && n >= *a.n_valid) return;   // workgroup-uniform
+    const int ntaps = a.cls_ntaps[cls];
+    int qy0, qx0, q0 = 0;
+    if (a.tw) {
+        const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+        qy0 = ty * a.th; qx0 = tx * a.tw;
+    } else {
+        q0 = blockIdx.x * PIXW; qy0 = q0 / a.QW; qx0 = 0;
+    }
+    const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls], in_ox = qx0 * a.in_s + a.cls_in_ox[cls];
+    const int plane = a.plane;
+    const int ibuf_bytes = 6 * plane * 16;                    // [3 pieces][2 k halves][plane] x 16 B
+    constexpr int WSLOT = NBLK * 3 * 1024;                    // one tap's weights of the tile: [cout block][piece][lane] x 16 B
+    unsigned char *s_in = smem_raw, *s_w = smem_raw + 2 * ibuf_bytes;
+    const int chunk_lo = ks * a.nchunks / a.ksplit, chunk_hi = (ks + 1) * a.nchunks / a.ksplit;
+    const int nchunk = chunk_hi - chunk_lo, nsteps = nchunk * ntaps;   // a step = one tap of one 16-channel chunk
+    const int *toff = a.toff + cls * a.taps_per_class;
+    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+
+    if (wid == 4 || wid == 5) {
+        // ------------------------------------------------------------------------------ weight waves (2 x 64 threads)
+        // One tap of the tile = NBLK * 3 pieces of 1 KB ([cout block][bf16 piece][lane] x 16 B), dealt alternately to the
+        // two waves; a piece travels HBM/L2 -> registers (global_load_dwordx4) -> LDS (ds_write_b128).  The asynchronous
+        // LDS DMA (global_load_lds) saturates at ~25 GB/s per CU on this part; a 128-cout tile needs 12 KB per ~0.35 us of
+        // matrix work.  WF steps of requests are in flight in registers (the compiler counts vmcnt for them), so the LDS
+        // ring is just two slots: step i+2 is written while the compute waves fetch step i+1 and multiply step i.
+        constexpr int WF = 4, NPW = (NBLK * 3 + 1) / 2;
+        const int lw = wid - 4;
+        const unsigned char *wcls = a.w + a.cls_woff[cls];
+        unsigned rel[NPW];   // source offset of this wave's pieces relative to (tap, chunk)
+        bool live[NPW];
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int pc = lw + 2 * k;
+            live[k] = pc < NBLK * 3;
+            const int pcc = min(pc, NBLK * 3 - 1), b = pcc / 3, pl = pcc - b * 3;
+            const int blk = min((int)blockIdx.y * NBLK + b, a.nblk_total - 1);
+            rel[k] = (unsigned)((blk * ntaps * a.nchunks * 3 + pl) * 1024) + lane * 16;
+        }
+        u32x4 wreg[WF][NPW];
+        int r_t = 0, r_chunk = chunk_lo, r_step = 0;   // next step to request
+        auto request = [&](u32x4 (&dst)[NPW]) {
+            if (r_step < nsteps && !((a.debug & 1) && r_step >= 2)) {
+                const unsigned char *base = wcls + ((long)r_t * a.nchunks + r_chunk) * 3072;
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) dst[k] = *reinterpret_cast<const u32x4 *>(base + rel[k]);
+            }
+            if (++r_t == ntaps) { r_t = 0; ++r_chunk; }
+            ++r_step;
+        };
+        int w_slot = 0;                                  // LDS slot of the next step to write
+        auto deposit = [&](const u32x4 (&src)[NPW]) {
+            unsigned char *dst = s_w + w_slot * WSLOT + lw * 1024 + lane * 16;
+#pragma unroll
+            for (int k = 0; k < NPW; ++k)
+                if (live[k]) *reinterpret_cast<u32x4 *>(dst + k * 2048) = src[k];
+            w_slot ^= 1;
+        };
+        long long waited = 0;
+        // prologue: steps 0 and 1 into the two slots, steps 2 .. WF+1 requested
+#pragma unroll
+        for (int f = 0; f < 2; ++f) request(wreg[f]);
+        deposit(wreg[0]);
+        deposit(wreg[1]);
+#pragma unroll
+        for (int f = 0; f < WF; ++f) request(wreg[f]);   // steps 2 .. WF+1: set f holds step 2 + f
+        lds_barrier();
+        lds_barrier();   // the compute waves have fetched step 0's operands: slot 0 may be overwritten
+        // step i: deposit step i+2 (set i % WF) into slot i % 2, then request step i+2+WF into the same set
+        for (int i = 0; i < nsteps; i += WF) {
+#pragma unroll
+            for (int f = 0; f < WF; ++f) {
+                if (i + f < nsteps) {
+                    if (i + f + 2 < nsteps) deposit(wreg[f]);
+                    request(wreg[f]);
+                    SPLIT_TIMED(lds_barrier(), waited);
+                }
+            }
+        }
+        if (a.trace && tid == 256) a.trace[wg * 8 + 7] = waited;
+        return;
+    }
+    if (wid >= 6) {
+        // ------------------------------------------------------------------------------ activation waves (2 x 64 threads)
+        const int lt = tid - 384;
+        int goff[NT];   // byte offset of the position inside a channel plane, < 0: outside the image / the staged patch
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int pos = lt + SPLIT_LOADERS * i;
+            const int rr = pos / a.Wst, xl = pos - rr * a.Wst;
+            const int par = xl / a.Wsub, xq = xl - par * a.Wsub;
+            const int iy = iy_base + rr, ix = in_ox + xq * a.in_s + par;
+            const bool ok = pos < plane && rr < a.ROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            goff[i] = ok ? (iy * a.W + ix) * 4 : -1;
+        }
+        const long cplane = (long)a.H * a.W;
+        const char *xin = reinterpret_cast<const char *>(a.x + ((long)n * a.in_c_total + a.in_c_offset) * cplane);
+        float v[NT][16];
+        auto issue_loads = [&](int sc) {
+            const int ci0 = (chunk_lo + sc) * 16;
+            const int nc = min(16, a.cin - ci0);   // wave-uniform
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const char *pc = xin + ((long)ci0 + min(c, nc - 1)) * cplane * 4;   // scalar base, 32-bit lane offset
+#pragma unroll
+                for (int i = 0; i < NT; ++i) v[i][c] = *reinterpret_cast<const float *>(pc + (unsigned)max(goff[i], 0));
+            }
+        };
+        auto convert_store = [&](int sc) {
+            const int ci0 = (chunk_lo + sc) * 16;
+            const int nc = min(16, a.cin - ci0);
+            unsigned char *dst = s_in + (sc & 1) * ibuf_bytes;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int pos = lt + SPLIT_LOADERS * i;
+                const bool ok = goff[i] >= 0;
+                u32x4 q[3][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c0 = 8 * h + 2 * e;
+                        const float x0 = c0 < nc ? (ok ? v[i][c0] : a.pad_value) : 0.f;
+                        const float x1 = c0 + 1 < nc ? (ok ? v[i][c0 + 1] : a.pad_value) : 0.f;
+                        unsigned e0, e1, e2, o0, o1, o2;
+                        split3(x0, e0, e1, e2);
+                        split3(x1, o0, o1, o2);
+                        q[0][h][e] = pack_hi(e0, o0); q[1][h][e] = pack_hi(e1, o1); q[2][h][e] = pack_hi(e2, o2);
+                    }
+                if (pos < plane) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4 *>(dst + ((pl * 2 + h) * plane + pos) * 16) = q[pl][h];
+                }
+            }
+        };
+        // Chunk c+2 is converted into the buffer of chunk c during the LAST tap of chunk c (the compute waves fetched that
+        // tap's operands a step earlier) from registers whose loads were issued a whole chunk before; the same registers
+        // then take the loads of chunk c+3.
+        long long waited = 0, conv = 0;
+        if (nchunk > 0) { issue_loads(0); convert_store(0); }
+        if (nchunk > 1) { issue_loads(1); convert_store(1); }
+        if (nchunk > 2) issue_loads(2);
+        lds_barrier();
+        lds_barrier();
+        int c = 0, t = 0;
+        for (int i = 0; i < nsteps; ++i) {
+            if (t == ntaps - 1 && !(a.debug & 2)) {
+                if (c + 2 < nchunk) SPLIT_TIMED(convert_store(c + 2), conv);
+                if (c + 3 < nchunk) issue_loads(c + 3);
+            }
+            SPLIT_TIMED(lds_barrier(), waited);
+            if (++t == ntaps) { t = 0; ++c; }
+        }
+        if (a.trace && tid == 384) { a.trace[wg * 8 + 5] = conv; a.trace[wg * 8 + 6] = waited; }
+        return;
+    }
+    // -------------------------------------------------------------------------------------- compute waves
+    const int wp = wid % WPX, wc = wid / WPX;
+    const int Q = a.QH * a.QW;
+    int pqy[MP], pqx[MP], base[MP];
+    bool pvalid[MP];
+#pragma unroll
+    for (int mp = 0; mp < MP; ++mp) {
+        const int local = (wp * MP + mp) * 32 + l31;
+        if (a.tw) {
+            const int ty = local / a.tw, tx = local - ty * a.tw;
+            pqy[mp] = qy0 + ty; pqx[mp] = qx0 + tx;
+            pvalid[mp] = pqy[mp] < a.QH && pqx[mp] < a.QW;
+            pqy[mp] = min(pqy[mp], a.QH - 1); pqx[mp] = min(pqx[mp], a.QW - 1);
+        } else {
+            const int q = q0 + local;
+            pvalid[mp] = q < Q;
+            const int qc = min(q, Q - 1);
+            pqy[mp] = qc / a.QW; pqx[mp] = qc - pqy[mp] * a.QW;
+        }
+        base[mp] = ((pqy[mp] - qy0) * a.in_s * a.Wst + (pqx[mp] - qx0) + half * plane) * 16;
+    }
+    f32x16 acc[MC][MP];
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mc][mp][r] = 0.f;
+
+    const int pstride = 2 * plane * 16;   // bytes between the pieces of the input buffer
+    auto load_ops = [&](SplitOps<MP, MC> &o, const unsigned char *bin, const unsigned char *bw, int to) {
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) o.a[mc][pl] = *reinterpret_cast<const u32x4 *>(bw + (mc * 3 + pl) * 1024);
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) o.b[mp][pl] = *reinterpret_cast<const u32x4 *>(bin + pl * pstride + base[mp] + to * 16);
+    };
+    auto mma = [&](const SplitOps<MP, MC> &o) {
+        // smallest terms first; consecutive instructions go to different accumulators
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+                for (int mp = 0; mp < MP; ++mp)
+                    acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.a[mc][PA[k]]), __builtin_bit_cast(bf16x8, o.b[mp][PB[k]]),
+                                                                          acc[mc][mp], 0, 0, 0);
+    };
+    // tap offsets: lane t of one VGPR holds tap t's offset, fetched with v_readlane (a scalar load per tap would share
+    // lgkmcnt with the LDS reads and drain the operand pipeline at every tap)
+    const int toff_lane = toff[min(lane, a.taps_per_class - 1)];
+    auto tap_off = [&](int t) { return __builtin_amdgcn_readlane(toff_lane, t); };
+    long long waited = 0;
+    if (a.trace && tid == 0) a.trace[wg * 8 + 0] = clock64();
+    lds_barrier();
+    if (a.trace && tid == 0) a.trace[wg * 8 + 1] = clock64();
+    {
+        // operands of the NEXT step: tap f_t of chunk parity f_par, weight slot f_slot
+        int f_t = 0, f_par = 0, f_slot = 0;
+        const unsigned char *bw_lane = s_w + (wc * MC * 3 * 64 + lane) * 16;
+        auto fetch = [&](SplitOps<MP, MC> &o) {
+            load_ops(o, s_in + f_par * ibuf_bytes, bw_lane + f_slot * WSLOT, tap_off(f_t));
+            if (++f_t == ntaps) { f_t = 0; f_par ^= 1; }
+            f_slot ^= 1;
+        };
+        SplitOps<MP, MC> o0, o1;
+        if (nsteps > 0) fetch(o0);
+        lds_barrier();   // step 0's operands are in registers before the loaders reuse its weight slot
+        const bool no_mma = a.debug & 4;
+        for (int i = 0; i < nsteps; i += 2) {
+            if (i + 1 < nsteps) fetch(o1);
+            if (!no_mma) mma(o0);
+            SPLIT_TIMED(lds_barrier(), waited);
+            if (i + 1 < nsteps) {
+                if (i + 2 < nsteps) fetch(o0);
+                if (!no_mma) mma(o1);
+                SPLIT_TIMED(lds_barrier(), waited);
+            }
+        }
+    }
+    if (a.trace && tid == 0) { a.trace[wg * 8 + 2] = clock64(); a.trace[wg * 8 + 4] = waited; }
+
+    // -------------------------------------------------------------------------------------- epilogue (as k_conv)
+    const int cb = (blockIdx.y * NBLK + wc * MC) * 32;
+    const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
+    if (a.ksplit > 1) {
+        const long plane_o = (long)a.OH * a.OW;
+        const int batch = gridDim.z / (a.ksplit * a.nclasses);
+        float *pbase = a.partial + ((long)ks * batch + n) * a.cout * plane_o;
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                const int oy = pqy[mp] * a.out_s + out_oy, ox = pqx[mp] * a.out_s + out_ox;
+                const bool pix_ok = pvalid[mp] && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb + mc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (pix_ok && co < a.cout) pbase[co * plane_o + (long)oy * a.OW + ox] = acc[mc][mp][r];
+                }
+            }
+        return;
+    }
+    // epilogue vectors: always loaded (from a valid address) and selected afterwards - no loads behind branches
+    const bool has_bias = a.bias != nullptr, has_aff = a.scale != nullptr, has_res = a.res != nullptr;
+    const float *bias_p = has_bias ? a.bias : a.x, *scale_p = has_aff ? a.scale : a.x, *shift_p = has_aff ? a.shift : a.x;
+    const float *res_p = has_res ? a.res : a.y;
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
+        float bv[16], sv[16], tv[16];
+        int cov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb + mc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            cov[r] = co;
+            const int cc = has_bias || has_aff ? min(co, a.cout - 1) : 0;
+            bv[r] = bias_p[cc]; sv[r] = scale_p[cc]; tv[r] = shift_p[cc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bv[r] = has_bias ? bv[r] : 0.f; sv[r] = has_aff ? sv[r] : 1.f; tv[r] = has_aff ? tv[r] : 0.f;
+        }
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp) {
+            const int oy = pqy[mp] * a.out_s + out_oy, ox = pqx[mp] * a.out_s + out_ox;
+            const bool pix_ok = pvalid[mp] && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+            const long pix = (long)oy * a.OW + ox;
+            const long cbase = ((long)n * a.out_c_total + a.out_c_offset) * a.OH * a.OW;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long idx = cbase + (long)min(cov[r], a.cout - 1) * a.OH * a.OW + (pix_ok ? pix : 0);
+                rv[r] = res_p[has_res ? idx : 0];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mc][mp][r] + bv[r];
+                if (a.relu_pre) v = v > 0.f ? v : 0.f;
+                v = fmaf(v, sv[r], tv[r]);
+                v += has_res ? rv[r] : 0.f;
+                if (a.relu_post) v = v > 0.f ? v : 0.f;
+                if (a.sigmoid && cov[r] >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
+                if (pix_ok && cov[r] < a.cout) a.y[cbase + (long)cov[r] * a.OH * a.OW + pix] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// bytes of the split packed weights of one plan
+inline size_t split_weight_bytes(const Plan &p) {
+    size_t taps = 0;
+    for (auto &t : p.taps) taps += t.size();
+    return taps * (size_t)(p.cout_pad / 32) * (p.cin_pad / 16) * 3 * 1024;
+}
+
+inline unsigned short bf16_round(float x, float &rest) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    u = (u + 0x8000u) & 0xffff0000u;
+    float b;
+    memcpy(&b, &u, 4);
+    rest = x - b;
+    return (unsigned short)(u >> 16);
+}
+
+// [class][cout block][tap][chunk][piece][lane = khalf*32 + cout%32][8 channels] bf16
+inline void split_pack_weights(const lav_conv &c, const Plan &p, const float *h_weight, unsigned char *out) {
+    const int nblk = p.cout_pad / 32, nchunks = p.cin_pad / 16;
+    unsigned short *o = reinterpret_cast<unsigned short *>(out);
+    size_t cls_off = 0;   // in u16
+    for (int cls = 0; cls < p.nclasses; ++cls) {
+        const auto &t = p.taps[cls];
+        for (int blk = 0; blk < nblk; ++blk)
+            for (size_t ti = 0; ti < t.size(); ++ti)
+                for (int ch = 0; ch < nchunks; ++ch)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = blk * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + e;
+                            float w = 0.f;
+                            if (co < c.cout && ci < c.cin)
+                                w = c.transposed ? h_weight[(((size_t)ci * c.cout + co) * c.kh + t[ti].ky) * c.kw + t[ti].kx]
+                                                 : h_weight[(((size_t)co * c.cin + ci) * c.kh + t[ti].ky) * c.kw + t[ti].kx];
+                            float r1, r2, r3;
+                            const unsigned short p0 = bf16_round(w, r1), p1 = bf16_round(r1, r2), p2 = bf16_round(r2, r3);
+                            const size_t frag = cls_off + ((((size_t)blk * t.size() + ti) * nchunks + ch) * 3) * 512;
+                            o[frag + 0 * 512 + lane * 8 + e] = p0;
+                            o[frag + 1 * 512 + lane * 8 + e] = p1;
+                            o[frag + 2 * 512 + lane * 8 + e] = p2;
+                        }
+        cls_off += t.size() * (size_t)nblk * nchunks * 3 * 512;
+    }
+}
+
+struct SplitPlan {
+    bool ok;
+    int MP, MC, WPX, tw, th, tiles_x, tiles, Wst, Wsub, ROWS, plane, tap_group, ksplit, wring;
+    size_t lds;
+    double cost;
+};
+
+// Tile shape, tile geometry, tap group and split-K factor of the split kernel, by estimated time (us).
+// LAV_SPLIT_FORCE="MP,MC,WPX,tw,tg,ks" pins a configuration (probes); fields that are 0 / -1 stay free.
+inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
+    SplitPlan best{};
+    best.ok = false; best.cost = 1e30;
+    int f_mp = 0, f_mc = 0, f_wpx = 0, f_tw = -1, f_tg = 0, f_ks = 0, f_wring = 0;
+    if (const char *e = getenv("LAV_SPLIT_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &f_mp, &f_mc, &f_wpx, &f_tw, &f_tg, &f_ks, &f_wring);
+    static const double c_fixed = [] { const char *e = getenv("LAV_SPLIT_C_FIXED"); return e ? atof(e) : 5.0; }();
+    static const double c_mma = [] { const char *e = getenv("LAV_SPLIT_C_MMA"); return e ? atof(e) : 0.1; }();
+    static const double c_stage = [] { const char *e = getenv("LAV_SPLIT_C_STAGE"); return e ? atof(e) : 0.05; }();
+    static const double c_chunk = [] { const char *e = getenv("LAV_SPLIT_C_CHUNK"); return e ? atof(e) : 1.2; }();
+    const long ncu = c.target_cus >= 16 && c.target_cus <= 256 ? c.target_cus : 256;
+    const int nchunks = p.cin_pad / 16;
+    const size_t LDS_MAX = 160 * 1024;
+    const int shapes[6][3] = {{2, 2, 4}, {1, 2, 4}, {1, 1, 4}, {2, 2, 2}, {1, 2, 2}, {1, 1, 2}};   // MP, MC, WPX
+    for (auto &sh : shapes) {
+        const int MP = sh[0], MC = sh[1], WPX = sh[2], WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
+        if ((f_mp && MP != f_mp) || (f_mc && MC != f_mc) || (f_wpx && WPX != f_wpx)) continue;
+        if (NBLK * 32 > p.cout_pad && NBLK > 1 && !(f_mc && f_wpx)) continue;   // more cout blocks than the layer has
+        for (int tw : {0, 32, 64, 128, 256}) {
+            if (tw > PIXW || (f_tw >= 0 && tw != f_tw)) continue;
+            if (tw && tw / 2 >= p.QW && tw > 32) continue;        // half of the tile would hang over the image
+            if (tw == 0 && p.QW >= 64 && f_tw < 0) continue;      // wide maps: full-width rows of a linearised tile are too much staging
+            const int th = tw ? PIXW / tw : 0;
+            int cols, rows;
+            long tiles;
+            int tiles_x = 1;
+            if (tw) {
+                cols = tw; rows = th;
+                tiles_x = (p.QW + tw - 1) / tw;
+                tiles = (long)tiles_x * ((p.QH + th - 1) / th);
+            } else {
+                cols = p.QW; rows = (int)std::min<long>((PIXW - 1 + p.QW - 1) / p.QW + 1, p.QH);
+                tiles = ((long)p.QH * p.QW + PIXW - 1) / PIXW;
+            }
+            const int Wreal = (cols - 1) * p.in_s + p.max_dx + 1;
+            const int Wsub = (Wreal + p.in_s - 1) / p.in_s, Wst = Wsub * p.in_s;
+            const int ROWS = (rows - 1) * p.in_s + p.max_dy + 1;
+            const int plane = (ROWS * Wst + 63) / 64 * 64;
+            if (plane > SPLIT_LOADERS * SPLIT_NT) continue;
+            {
+                // LDS: two activation chunk buffers + two weight slots (one tap of the tile each)
+                const size_t lds_in = (size_t)2 * 6 * plane * 16, wslot = (size_t)NBLK * 3 * 1024;
+                const int wring = 2;
+                const size_t lds = lds_in + wring * wslot;
+                if (lds > LDS_MAX) continue;
+                const long wgs1 = tiles * ((c.cout + NBLK * 32 - 1) / (NBLK * 32)) * c.batch * p.nclasses;
+                const int ks_max = f_ks ? f_ks : (nchunks >= 4 ? std::min(16, nchunks / 2) : 1);
+                const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
+                for (int ks = f_ks ? f_ks : 1; ks <= ks_max; ++ks) {
+                    const long wgs = wgs1 * ks;
+                    const int nch = (nchunks + ks - 1) / ks;
+                    // per chunk: matrix work + one barrier per tap, and the loaders' floor (a chunk's loads + conversion)
+                    const double chunk_us = std::max(p.taps_per_class * (MP * MC * c_mma + c_stage), c_chunk * plane / 384.0);
+                    const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
+                    if (t < best.cost * (ks > 1 ? 0.97 : 1.0) - 1e-9) {
+                        best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, 1, ks, wring, lds, t};
+                    }
+                }
+            }
+        }
+    }
+    return best;
+}
+
+template <int MP, int MC, int WPX, int NT>
+int launch_split_nt(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split<MP, MC, WPX, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT>), grid, dim3(512), lds, st, sa);
+    return LAV_OK;
+}
+template <int MP, int MC, int WPX>
+int launch_split_t(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
+    if (sa.plane <= SPLIT_LOADERS * 2) return launch_split_nt<MP, MC, WPX, 2>(sa, grid, lds, st);
+    if (sa.plane <= SPLIT_LOADERS * 4) return launch_split_nt<MP, MC, WPX, 4>(sa, grid, lds, st);
+    return launch_split_nt<MP, MC, WPX, SPLIT_NT>(sa, grid, lds, st);
+}
+
+// `a`: the epilogue / output description already filled in by lav_conv2d (pointers, sizes, flags, partial slab)
+inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, const ConvArgs &a, const unsigned char *w_split, hipStream_t st) {
+    SplitArgs s;
+    s.x = a.x; s.w = w_split; s.bias = a.bias; s.scale = a.scale; s.shift = a.shift; s.res = a.res; s.n_valid = a.n_valid;
+    s.y = a.y; s.partial = a.partial;
+    s.in_c_total = a.in_c_total; s.in_c_offset = a.in_c_offset; s.cin = a.cin; s.H = a.H; s.W = a.W;
+    s.cout = a.cout; s.out_c_total = a.out_c_total; s.out_c_offset = a.out_c_offset; s.OH = a.OH; s.OW = a.OW;
+    s.nchunks = p.cin_pad / 16; s.nblk_total = p.cout_pad / 32;
+    s.QH = p.QH; s.QW = p.QW; s.in_s = p.in_s; s.out_s = p.out_s; s.nclasses = p.nclasses; s.ksplit = sp.ksplit;
+    s.tw = sp.tw; s.th = sp.th; s.tiles_x = sp.tiles_x;
+    s.Wst = sp.Wst; s.Wsub = sp.Wsub; s.ROWS = sp.ROWS; s.plane = sp.plane;
+    s.tap_group = sp.tap_group; s.taps_per_class = p.taps_per_class; s.wring = sp.wring;
+    s.relu_pre = a.relu_pre; s.relu_post = a.relu_post; s.sigmoid = a.sigmoid; s.pad_value = a.pad_value;
+    long woff = 0;
+    for (int i = 0; i < MAX_CLASSES; ++i) {
+        const bool live = i < p.nclasses;
+        s.cls_ntaps[i] = live ? (int)p.taps[i].size() : 0;
+        s.cls_in_oy[i] = live ? p.in_oy[i] : 0; s.cls_in_ox[i] = live ? p.in_ox[i] : 0;
+        s.cls_out_oy[i] = live ? p.out_oy[i] : 0; s.cls_out_ox[i] = live ? p.out_ox[i] : 0;
+        s.cls_woff[i] = woff;
+        if (live) woff += (long)p.taps[i].size() * s.nblk_total * s.nchunks * 3 * 1024;
+    }
+    for (int i = 0; i < MAX_TAPS; ++i) s.toff[i] = 0;
+    for (int cl = 0; cl < p.nclasses; ++cl)
+        for (size_t t = 0; t < p.taps[cl].size(); ++t) {
+            const int dy = p.taps[cl][t].dy, dx = p.taps[cl][t].dx;
+            s.toff[cl * p.taps_per_class + t] = dy * sp.Wst + (dx % p.in_s) * sp.Wsub + dx / p.in_s;
+        }
+    s.trace = nullptr;
+    { const char *e = getenv("LAV_SPLIT_DEBUG"); s.debug = e ? atoi(e) : 0; }
+    const int NBLK = (4 / sp.WPX) * sp.MC;
+    static const bool want_trace = getenv("LAV_SPLIT_TRACE") != nullptr;
+    static long long *d_trace = nullptr;
+    if (want_trace) {
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)65536 * 8 * sizeof(long long)));
+        LAV_HIP(hipMemsetAsync(d_trace, 0, (size_t)65536 * 8 * sizeof(long long), st));
+        s.trace = d_trace;
+    }
+    dim3 grid(sp.tiles, (c.cout + NBLK * 32 - 1) / (NBLK * 32), c.batch * p.nclasses * sp.ksplit);
+    const int tok = timer_begin("conv2d", st);
+    int rc = LAV_EINVAL;
+    switch (sp.MP * 100 + sp.MC * 10 + sp.WPX) {
+        case 224: rc = launch_split_t<2, 2, 4>(s, grid, sp.lds, st); break;
+        case 124: rc = launch_split_t<1, 2, 4>(s, grid, sp.lds, st); break;
+        case 114: rc = launch_split_t<1, 1, 4>(s, grid, sp.lds, st); break;
+        case 222: rc = launch_split_t<2, 2, 2>(s, grid, sp.lds, st); break;
+        case 122: rc = launch_split_t<1, 2, 2>(s, grid, sp.lds, st); break;
+        case 112: rc = launch_split_t<1, 1, 2>(s, grid, sp.lds, st); break;
+        default: return fail(LAV_EINVAL, "lav_conv2d: split tile %dx%d/%d not built", sp.MP, sp.MC, sp.WPX);
+    }
+    if (rc) return rc;
+    if (sp.ksplit > 1) {
+        const long total = (long)c.batch * a.cout * p.OH * p.OW;
+        hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, c.batch);
+    }
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    static int runs = 0;
+    if (s.trace && ++runs % 8 == 0) {   // debug: where the workgroups' time goes (cycles of the shader clock)
+        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+        if (nwg <= 65536) {
+            std::vector<long long> h(nwg * 8);
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                double pro = 0, loop = 0, cw = 0, lconv = 0, lw = 0, dw = 0;
+                long long t0 = h[0], t1 = 0;
+                for (size_t i = 0; i < nwg; ++i) {
+                    pro += (double)(h[i * 8 + 1] - h[i * 8]); loop += (double)(h[i * 8 + 2] - h[i * 8 + 1]);
+                    cw += (double)h[i * 8 + 4]; lconv += (double)h[i * 8 + 5]; lw += (double)h[i * 8 + 6]; dw += (double)h[i * 8 + 7];
+                    t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 2]);
+                }
+                const int nst = (s.nchunks / sp.ksplit) * p.taps_per_class;
+                fprintf(stderr, "[split trace] %zu wgs %dx%d/w%d tw%d ring %d ks%d, %d steps: span %.0f kcyc | per wg: prologue wait %.0f, loop %.0f cyc (%.0f per step) | barrier wait: compute %.0f, loaders %.0f (convert %.0f) %.0f\n",
+                        nwg, sp.MP, sp.MC, sp.WPX, sp.tw, sp.wring, sp.ksplit, nst, (double)(t1 - t0) / 1e3, pro / nwg, loop / nwg, loop / nwg / std::max(nst, 1),
+                        cw / nwg, lw / nwg, lconv / nwg, dw / nwg);
+            }
+        }
+    }
+    return LAV_OK;
+}

@@ -298,7 +298,7 @@ class ConvLayer:
     def __init__(self, weight: torch.Tensor, *, stride=1, padding=(0, 0), dilation=(1, 1), transposed=False,
                  output_padding=0, bias: Optional[torch.Tensor] = None, bn=None, bn_eps: float = 1e-5,
                  relu_pre=False, relu_post=False, sigmoid=False, in_c_total=None, in_c_offset=0, out_c_total=None, target_cus=0, pad_value=0.0,
-                 out_c_offset=0, device=None):
+                 out_c_offset=0, precision=0, device=None):
         lib = _lib.load()
         w = weight.detach().to("cpu", torch.float32).contiguous()
         if transposed:
@@ -315,7 +315,7 @@ class ConvLayer:
         self.desc = Conv(1, self.in_c_total, in_c_offset, cin, 0, 0, cout, kh, kw, int(stride), int(padding[0]),
                          int(padding[1]), int(dilation[0]), int(dilation[1]), int(bool(transposed)),
                          int(output_padding), self.out_c_total, out_c_offset, int(relu_pre), int(relu_post),
-                         int(sigmoid), int(target_cus), float(pad_value))
+                         int(sigmoid), int(target_cus), float(pad_value), int(precision))
         probe = Conv.from_buffer_copy(self.desc)
         probe.h, probe.w = 64, 64
         nfl = lib.lav_conv_packed_weight_floats(C.byref(probe))
