@@ -450,7 +450,7 @@ int build_plan(const lav_conv &c, Plan &p) {
 // back to back on its matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch.
 // Wide images switch to row-blocked tiles (a tile = PIXW pixels of ONE output-grid row) when the full-width rows of
 // a linearised tile do not fit the staging map / LDS.
-int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds, double *cost = nullptr) {
+int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC, size_t &lds, double *cost = nullptr, double *raw_cost = nullptr) {
     // *cost: the plan's estimate in us; made infinite-cheap (0) for deep 2x2-tile plans, which the direct kernel never beats
     a.cin_pad = p.cin_pad; a.cout_pad = p.cout_pad;
     const long Q = (long)p.QH * p.QW;
@@ -537,6 +537,7 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
         }
     }
     if (cost) *cost = (found && MP == 2 && MC == 2 && bg.nwg * a.ksplit >= 512) ? 0.0 : best;   // 384->256 head conv: tiled 486 us (93 TF/s), direct 565
+    if (raw_cost) *raw_cost = best;   // the estimate itself (what the split kernel's plan is compared with)
     LAV_REQUIRE(found, "lav_conv2d: no tile shape fits (grid %dx%d, stride %d, %d taps)", p.QH, p.QW, p.in_s, p.taps_per_class);
     a.rowblock = bg.rowblock; a.xblocks = bg.xblocks; a.Wst = bg.Wst; a.ROWS = bg.ROWS;
     a.plane_pad = bg.plane_pad; a.tap_group = bg.tap_group; a.in_bufs = bg.in_bufs;
@@ -800,7 +801,7 @@ struct Choice {
     SplitPlan sp;
 };
 
-Choice decide(const lav_conv &c, const Plan &p, double tile_cost) {
+Choice decide(const lav_conv &c, const Plan &p, double tile_cost, double tile_raw) {
     Choice ch;
     ch.dp = choose_direct(c, p);
     ch.sp.ok = false;
@@ -810,10 +811,20 @@ Choice decide(const lav_conv &c, const Plan &p, double tile_cost) {
         const int mode = e ? atoi(e) : 1;
         if (mode) {
             ch.sp = choose_split(c, p);
-            const double other = ch.kind == 1 ? ch.dp.cost : tile_cost;
-            if (ch.sp.ok && (mode == 2 || ch.sp.cost < other)) ch.kind = 2;
+            // the direct kernel's estimate is calibrated on small maps and runs ~30 % optimistic once a layer has several
+            // hundred tiles (measured 64ch @ 160x160: 34.6 us against a model of 24.8; split kernel 26.1 against 25.0)
+            double other = ch.kind == 1 ? ch.dp.cost * (1.0 + 0.3 * std::min(1.0, (double)ch.dp.tiles / 800.0)) : tile_raw;
+            // deep 7x7 stems: the split kernel's tiles are LDS-bound there (64 pixels x 64 couts) and only match the tiled
+            // fp32 kernel (measured 451 vs 431 us at 7 crops)
+            const bool deep_stem = p.taps_per_class > 16 && c.cin >= 64;
+            if (ch.sp.ok && (mode == 2 || (ch.sp.cost < other && !deep_stem))) ch.kind = 2;
         }
     }
+    static const bool dbg = getenv("LAV_CONV_PLAN_DEBUG") != nullptr;
+    if (dbg)
+        fprintf(stderr, "[conv plan] B%d %d->%d k%dx%d s%d %dx%d%s: tiled %.1f us, direct %.1f us, split %.1f us -> %s\n", c.batch, c.cin, c.cout, c.kh, c.kw,
+                c.stride, c.h, c.w, c.transposed ? " T" : "", tile_raw, ch.dp.ok ? ch.dp.cost : -1.0, ch.sp.ok ? ch.sp.cost : -1.0,
+                ch.kind == 2 ? "split" : ch.kind == 1 ? "direct" : "tiled");
     return ch;
 }
 }  // namespace
@@ -826,10 +837,10 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     ConvArgs a;
     int MP, MC;
     size_t lds;
-    double cost = 0;
-    rc = choose_tile(*c, p, a, MP, MC, lds, &cost);
+    double cost = 0, raw = 0;
+    rc = choose_tile(*c, p, a, MP, MC, lds, &cost, &raw);
     if (rc) return rc;
-    const Choice ch = decide(*c, p, cost);
+    const Choice ch = decide(*c, p, cost, raw);
     const DirectPlan &d = ch.dp;
     if (ch.kind == 2) {   // split kernel: info[0] = -1, then MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows
         info[0] = -1; info[1] = ch.sp.MP; info[2] = ch.sp.MC; info[3] = ch.sp.WPX; info[4] = ch.sp.tw; info[5] = (int)ch.sp.lds;
@@ -951,9 +962,9 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     ConvArgs a;
     int MP, MC;
     size_t lds;
-    double cost = 0;
-    if (choose_tile(*c, p, a, MP, MC, lds, &cost)) return 0;
-    const Choice ch = decide(*c, p, cost);
+    double cost = 0, raw = 0;
+    if (choose_tile(*c, p, a, MP, MC, lds, &cost, &raw)) return 0;
+    const Choice ch = decide(*c, p, cost, raw);
     if (ch.kind == 1) a.ksplit = ch.dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     return a.ksplit > 1 ? (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float) : 0;
@@ -978,10 +989,10 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
 
     int MP, MC;
     size_t lds;
-    double cost = 0;
-    rc = choose_tile(*c, p, a, MP, MC, lds, &cost);
+    double cost = 0, raw = 0;
+    rc = choose_tile(*c, p, a, MP, MC, lds, &cost, &raw);
     if (rc) return rc;
-    const Choice ch = decide(*c, p, cost);
+    const Choice ch = decide(*c, p, cost, raw);
     const DirectPlan &dp = ch.dp;
     const bool direct = ch.kind == 1;
     if (direct) a.ksplit = dp.ksplit;

@@ -81,6 +81,20 @@ __device__ __forceinline__ void split3(float x, unsigned &p0, unsigned &p1, unsi
 // {hi half of odd, hi half of even} -> one dword of two bf16 (even in the low half)
 __device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
 
+// scheduling hint: K-th of NR groups "some MFMAs, then one LDS read"
+template <int K, int NM, int NR>
+struct SplitInterleave {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, (NM * (K + 1)) / NR - (NM * K) / NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        SplitInterleave<K + 1, NM, NR>::run();
+    }
+};
+template <int NM, int NR>
+struct SplitInterleave<NR, NM, NR> {
+    static __device__ __forceinline__ void run() {}
+};
+
 template <int MP, int MC>
 struct SplitOps {
     u32x4 a[MC][3], b[MP][3];
@@ -101,10 +115,10 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     const int ntaps = a.cls_ntaps[cls];
     int qy0, qx0, q0 = 0;
     if (a.tw) {
-        const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+        const int tx = blockIdx.y % a.tiles_x, ty = blockIdx.y / a.tiles_x;
         qy0 = ty * a.th; qx0 = tx * a.tw;
     } else {
-        q0 = blockIdx.x * PIXW; qy0 = q0 / a.QW; qx0 = 0;
+        q0 = blockIdx.y * PIXW; qy0 = q0 / a.QW; qx0 = 0;
     }
     const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls], in_ox = qx0 * a.in_s + a.cls_in_ox[cls];
     const int plane = a.plane;
@@ -113,6 +127,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     unsigned char *s_in = smem_raw, *s_w = smem_raw + 2 * ibuf_bytes;
     const int chunk_lo = ks * a.nchunks / a.ksplit, chunk_hi = (ks + 1) * a.nchunks / a.ksplit;
     const int nchunk = chunk_hi - chunk_lo, nsteps = nchunk * ntaps;   // a step = one tap of one 16-channel chunk
+    const int nsteps_pad = (nsteps + 3) & ~3;                 // barriers every role executes (the weight waves' loop is unrolled by 4)
     const int *toff = a.toff + cls * a.taps_per_class;
     const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -128,54 +143,55 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         constexpr int WF = 4, NPW = (NBLK * 3 + 1) / 2;
         const int lw = wid - 4;
         const unsigned char *wcls = a.w + a.cls_woff[cls];
+        // Everything below is unconditional straight-line code per step (a dead piece of an odd piece count repeats the
+        // wave's first piece, requests past the last step re-read the last one, deposits past it land in a slot nobody
+        // reads any more): with branches around the loads the compiler drains vmcnt to 0 at every deposit, i.e. pays the
+        // full memory latency every step instead of once.
         unsigned rel[NPW];   // source offset of this wave's pieces relative to (tap, chunk)
-        bool live[NPW];
+        int doff[NPW];       // LDS offset of the piece inside a slot
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
-            const int pc = lw + 2 * k;
-            live[k] = pc < NBLK * 3;
-            const int pcc = min(pc, NBLK * 3 - 1), b = pcc / 3, pl = pcc - b * 3;
-            const int blk = min((int)blockIdx.y * NBLK + b, a.nblk_total - 1);
+            int pc = lw + 2 * k;
+            if (pc >= NBLK * 3) pc = lw;
+            const int b = pc / 3, pl = pc - b * 3;
+            const int blk = min((int)blockIdx.x * NBLK + b, a.nblk_total - 1);
             rel[k] = (unsigned)((blk * ntaps * a.nchunks * 3 + pl) * 1024) + lane * 16;
+            doff[k] = pc * 1024 + lane * 16;
         }
         u32x4 wreg[WF][NPW];
-        int r_t = 0, r_chunk = chunk_lo, r_step = 0;   // next step to request
+        int r_t = 0, r_chunk = chunk_lo;   // next step to request
         auto request = [&](u32x4 (&dst)[NPW]) {
-            if (r_step < nsteps && !((a.debug & 1) && r_step >= 2)) {
-                const unsigned char *base = wcls + ((long)r_t * a.nchunks + r_chunk) * 3072;
+            const unsigned char *base = wcls + ((long)r_t * a.nchunks + min(r_chunk, chunk_hi - 1)) * 3072;
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) dst[k] = *reinterpret_cast<const u32x4 *>(base + rel[k]);
-            }
-            if (++r_t == ntaps) { r_t = 0; ++r_chunk; }
-            ++r_step;
+            for (int k = 0; k < NPW; ++k) dst[k] = *reinterpret_cast<const u32x4 *>(base + rel[k]);
+            const bool wrap = r_t + 1 == ntaps;
+            r_t = wrap ? 0 : r_t + 1;
+            r_chunk += wrap ? 1 : 0;
         };
         int w_slot = 0;                                  // LDS slot of the next step to write
         auto deposit = [&](const u32x4 (&src)[NPW]) {
-            unsigned char *dst = s_w + w_slot * WSLOT + lw * 1024 + lane * 16;
+            unsigned char *dst = s_w + w_slot * WSLOT;
 #pragma unroll
-            for (int k = 0; k < NPW; ++k)
-                if (live[k]) *reinterpret_cast<u32x4 *>(dst + k * 2048) = src[k];
+            for (int k = 0; k < NPW; ++k) *reinterpret_cast<u32x4 *>(dst + doff[k]) = src[k];
             w_slot ^= 1;
         };
         long long waited = 0;
         // prologue: steps 0 and 1 into the two slots, steps 2 .. WF+1 requested
-#pragma unroll
-        for (int f = 0; f < 2; ++f) request(wreg[f]);
+        request(wreg[0]);
+        request(wreg[1]);
         deposit(wreg[0]);
         deposit(wreg[1]);
 #pragma unroll
-        for (int f = 0; f < WF; ++f) request(wreg[f]);   // steps 2 .. WF+1: set f holds step 2 + f
+        for (int f = 0; f < WF; ++f) request(wreg[f]);   // set f holds step 2 + f
         lds_barrier();
         lds_barrier();   // the compute waves have fetched step 0's operands: slot 0 may be overwritten
         // step i: deposit step i+2 (set i % WF) into slot i % 2, then request step i+2+WF into the same set
-        for (int i = 0; i < nsteps; i += WF) {
+        for (int i = 0; i < nsteps_pad; i += WF) {
 #pragma unroll
             for (int f = 0; f < WF; ++f) {
-                if (i + f < nsteps) {
-                    if (i + f + 2 < nsteps) deposit(wreg[f]);
-                    request(wreg[f]);
-                    SPLIT_TIMED(lds_barrier(), waited);
-                }
+                deposit(wreg[f]);
+                request(wreg[f]);
+                SPLIT_TIMED(lds_barrier(), waited);
             }
         }
         if (a.trace && tid == 256) a.trace[wg * 8 + 7] = waited;
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             SPLIT_TIMED(lds_barrier(), waited);
             if (++t == ntaps) { t = 0; ++c; }
         }
+        for (int i = nsteps; i < nsteps_pad; ++i) lds_barrier();
         if (a.trace && tid == 384) { a.trace[wg * 8 + 5] = conv; a.trace[wg * 8 + 6] = waited; }
         return;
     }
@@ -329,22 +346,31 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         SplitOps<MP, MC> o0, o1;
         if (nsteps > 0) fetch(o0);
         lds_barrier();   // step 0's operands are in registers before the loaders reuse its weight slot
-        const bool no_mma = a.debug & 4;
-        for (int i = 0; i < nsteps; i += 2) {
-            if (i + 1 < nsteps) fetch(o1);
-            if (!no_mma) mma(o0);
+        // Two steps per iteration (static register sets).  The operand fetch is unconditional - past the last step it reads
+        // stale LDS that nobody uses - so that fetch and matrix instructions share one basic block, and the LDS reads of the
+        // next step are spread between this step's matrix instructions (one read per NM / NR of them): issued as one burst
+        // they leave the matrix pipe idle after every barrier.
+        int i = 0;
+        for (; i + 1 < nsteps; i += 2) {
+            fetch(o1);
+            mma(o0);
+            SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
             SPLIT_TIMED(lds_barrier(), waited);
-            if (i + 1 < nsteps) {
-                if (i + 2 < nsteps) fetch(o0);
-                if (!no_mma) mma(o1);
-                SPLIT_TIMED(lds_barrier(), waited);
-            }
+            fetch(o0);
+            mma(o1);
+            SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
+            SPLIT_TIMED(lds_barrier(), waited);
         }
+        if (i < nsteps) {
+            mma(o0);
+            SPLIT_TIMED(lds_barrier(), waited);
+        }
+        for (int k = nsteps; k < nsteps_pad; ++k) lds_barrier();
     }
     if (a.trace && tid == 0) { a.trace[wg * 8 + 2] = clock64(); a.trace[wg * 8 + 4] = waited; }
 
     // -------------------------------------------------------------------------------------- epilogue (as k_conv)
-    const int cb = (blockIdx.y * NBLK + wc * MC) * 32;
+    const int cb = (blockIdx.x * NBLK + wc * MC) * 32;
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
     if (a.ksplit > 1) {
         const long plane_o = (long)a.OH * a.OW;
@@ -469,14 +495,14 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
     best.ok = false; best.cost = 1e30;
     int f_mp = 0, f_mc = 0, f_wpx = 0, f_tw = -1, f_tg = 0, f_ks = 0, f_wring = 0;
     if (const char *e = getenv("LAV_SPLIT_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &f_mp, &f_mc, &f_wpx, &f_tw, &f_tg, &f_ks, &f_wring);
-    static const double c_fixed = [] { const char *e = getenv("LAV_SPLIT_C_FIXED"); return e ? atof(e) : 5.0; }();
-    static const double c_mma = [] { const char *e = getenv("LAV_SPLIT_C_MMA"); return e ? atof(e) : 0.1; }();
-    static const double c_stage = [] { const char *e = getenv("LAV_SPLIT_C_STAGE"); return e ? atof(e) : 0.05; }();
+    static const double c_fixed = [] { const char *e = getenv("LAV_SPLIT_C_FIXED"); return e ? atof(e) : 11.0; }();
+    static const double c_mma = [] { const char *e = getenv("LAV_SPLIT_C_MMA"); return e ? atof(e) : 0.105; }();
+    static const double c_stage = [] { const char *e = getenv("LAV_SPLIT_C_STAGE"); return e ? atof(e) : 0.18; }();
     static const double c_chunk = [] { const char *e = getenv("LAV_SPLIT_C_CHUNK"); return e ? atof(e) : 1.2; }();
     const long ncu = c.target_cus >= 16 && c.target_cus <= 256 ? c.target_cus : 256;
     const int nchunks = p.cin_pad / 16;
     const size_t LDS_MAX = 160 * 1024;
-    const int shapes[6][3] = {{2, 2, 4}, {1, 2, 4}, {1, 1, 4}, {2, 2, 2}, {1, 2, 2}, {1, 1, 2}};   // MP, MC, WPX
+    const int shapes[6][3] = {{2, 2, 2}, {2, 2, 4}, {1, 2, 4}, {1, 2, 2}, {1, 1, 4}, {1, 1, 2}};   // MP, MC, WPX (ties: first wins)
     for (auto &sh : shapes) {
         const int MP = sh[0], MC = sh[1], WPX = sh[2], WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
         if ((f_mp && MP != f_mp) || (f_mc && MC != f_mc) || (f_wpx && WPX != f_wpx)) continue;
@@ -582,7 +608,8 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
         LAV_HIP(hipMemsetAsync(d_trace, 0, (size_t)65536 * 8 * sizeof(long long), st));
         s.trace = d_trace;
     }
-    dim3 grid(sp.tiles, (c.cout + NBLK * 32 - 1) / (NBLK * 32), c.batch * p.nclasses * sp.ksplit);
+    // x = cout tile (fastest): workgroup b lands on XCD b % 8, so an XCD's L2 streams the weights of few cout tiles
+    dim3 grid((c.cout + NBLK * 32 - 1) / (NBLK * 32), sp.tiles, c.batch * p.nclasses * sp.ksplit);
     const int tok = timer_begin("conv2d", st);
     int rc = LAV_EINVAL;
     switch (sp.MP * 100 + sp.MC * 10 + sp.WPX) {

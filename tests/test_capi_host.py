@@ -242,8 +242,8 @@ def test_direct_plan_is_chosen_where_it_was_measured_faster():
     lib = _lib.load()
     info = (C.c_int * 9)()
 
-    def plan(B, cin, cout, k, s, p, H, W, tr=False):
-        d = Conv(B, cin, 0, cin, H, W, cout, k, k, s, p, p, 1, 1, int(tr), 0, cout, 0, 0, 0, 0)
+    def plan(B, cin, cout, k, s, p, H, W, tr=False, precision=_lib.CONV_F32):
+        d = Conv(B, cin, 0, cin, H, W, cout, k, k, s, p, p, 1, 1, int(tr), 0, cout, 0, 0, 0, 0, 0, 0.0, precision)
         assert lib.lav_conv_tile_info(C.byref(d), info) == 0, lib.lav_last_error().decode()
         return list(info)
 
@@ -266,6 +266,33 @@ def test_direct_plan_is_chosen_where_it_was_measured_faster():
     i = plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)
     assert i[0] == 0 and i[2] == 2
     assert plan(1, 128, 128, 4, 4, 0, 40, 40, tr=True)[:3] == [0, 4, 1]
+
+
+def test_split_plan_takes_the_matrix_bound_layers_only():
+    """Precision bf16x6 (the default): the split kernel (info[0] == -1; info[1..4] = MP, MC, pixel waves, tile width; info[5] LDS
+    bytes; info[6] split-K) takes the layers that are bound by the matrix pipes - the fused 384->256 head convolution, the
+    64-channel BEV layers at 160x160, the 4x4 up-convolution - and leaves the small ResNet maps to the exact fp32 direct kernel;
+    with precision f32 it never runs."""
+    lib = _lib.load()
+    info = (C.c_int * 9)()
+
+    def plan(B, cin, cout, k, s, p, H, W, tr=False, precision=_lib.CONV_BF16X6):
+        d = Conv(B, cin, 0, cin, H, W, cout, k, k, s, p, p, 1, 1, int(tr), 0, cout, 0, 0, 0, 0, 0, 0.0, precision)
+        assert lib.lav_conv_tile_info(C.byref(d), info) == 0, lib.lav_last_error().decode()
+        return list(info)
+
+    head = plan(1, 384, 256, 3, 1, 1, 160, 160)
+    assert head[0] == -1 and (head[1], head[2]) == (2, 2) and head[5] <= 160 * 1024 and head[4] % 32 == 0
+    assert plan(1, 64, 64, 3, 1, 1, 160, 160)[0] == -1
+    assert plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)[0] == -1
+    for shp in [(1, 64, 64, 3, 1, 1, 24, 24), (1, 128, 128, 3, 1, 1, 12, 12), (7, 256, 256, 3, 1, 1, 6, 6), (1, 512, 512, 3, 1, 1, 3, 3)]:
+        assert plan(*shp)[0] == 0, f"{shp}: small maps stay on the direct kernel"
+    assert plan(1, 384, 256, 3, 1, 1, 160, 160, precision=_lib.CONV_F32)[0] >= 1
+    # the packed weights of a split-capable layer carry both layouts
+    d32 = Conv(1, 64, 0, 64, 64, 64, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, 64, 0, 0, 0, 0, 0, 0.0, _lib.CONV_F32)
+    d16 = Conv(1, 64, 0, 64, 64, 64, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, 64, 0, 0, 0, 0, 0, 0.0, _lib.CONV_BF16X6)
+    n32, n16 = lib.lav_conv_packed_weight_floats(C.byref(d32)), lib.lav_conv_packed_weight_floats(C.byref(d16))
+    assert n32 == 64 * 64 * 9 and n16 == n32 + 64 * 64 * 9 * 3 // 2
 
 
 def test_grouped_deconv_rejects_unsupported_geometry_before_any_launch():
