@@ -103,7 +103,9 @@ struct SplitOps {
 // NT: staged positions per activation-loader thread (plane <= 192 * NT); every loader thread issues all 16 * NT loads
 // of a chunk unconditionally (clamped addresses, values selected afterwards): loads behind branches make the compiler
 // drain the queue at each join, one memory round trip per position
-template <int MP, int MC, int WPX, int NT>
+// G: taps per barrier.  A barrier costs ~300 cycles of skew between the eight waves whatever the work between two of
+// them; a 2x2 wave tile has 24 matrix instructions (~1000 cycles) per tap, a 1x1 tile only 6.
+template <int MP, int MC, int WPX, int NT, int G>
 __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     constexpr int WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -127,7 +129,9 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     unsigned char *s_in = smem_raw, *s_w = smem_raw + 2 * ibuf_bytes;
     const int chunk_lo = ks * a.nchunks / a.ksplit, chunk_hi = (ks + 1) * a.nchunks / a.ksplit;
     const int nchunk = chunk_hi - chunk_lo, nsteps = nchunk * ntaps;   // a step = one tap of one 16-channel chunk
-    const int nsteps_pad = (nsteps + 3) & ~3;                 // barriers every role executes (the weight waves' loop is unrolled by 4)
+    constexpr int WFM = 4 / G;                                 // groups of G taps the weight waves keep in flight in registers
+    const int ngroups = (nsteps + G - 1) / G;                 // a group = the G taps between two barriers
+    const int ngroups_pad = (ngroups + WFM - 1) / WFM * WFM;  // barriers every role executes (the weight waves' loop is unrolled by WFM)
     const int *toff = a.toff + cls * a.taps_per_class;
     const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         // LDS DMA (global_load_lds) saturates at ~25 GB/s per CU on this part; a 128-cout tile needs 12 KB per ~0.35 us of
         // matrix work.  WF steps of requests are in flight in registers (the compiler counts vmcnt for them), so the LDS
         // ring is just two slots: step i+2 is written while the compute waves fetch step i+1 and multiply step i.
-        constexpr int WF = 4, NPW = (NBLK * 3 + 1) / 2;
+        constexpr int NPW = (NBLK * 3 + 1) / 2;
         const int lw = wid - 4;
         const unsigned char *wcls = a.w + a.cls_woff[cls];
         // Everything below is unconditional straight-line code per step (a dead piece of an odd piece count repeats the
@@ -158,8 +162,8 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             rel[k] = (unsigned)((blk * ntaps * a.nchunks * 3 + pl) * 1024) + lane * 16;
             doff[k] = pc * 1024 + lane * 16;
         }
-        u32x4 wreg[WF][NPW];
-        int r_t = 0, r_chunk = chunk_lo;   // next step to request
+        u32x4 wreg[WFM][G][NPW];
+        int r_t = 0, r_chunk = chunk_lo;   // next tap to request
         auto request = [&](u32x4 (&dst)[NPW]) {
             const unsigned char *base = wcls + ((long)r_t * a.nchunks + min(r_chunk, chunk_hi - 1)) * 3072;
 #pragma unroll
@@ -168,29 +172,37 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             r_t = wrap ? 0 : r_t + 1;
             r_chunk += wrap ? 1 : 0;
         };
-        int w_slot = 0;                                  // LDS slot of the next step to write
-        auto deposit = [&](const u32x4 (&src)[NPW]) {
-            unsigned char *dst = s_w + w_slot * WSLOT;
+        // LDS ring of 3 groups: while group k is multiplied (its taps, and the first tap of group k+1, are fetched during
+        // it), group k+2 is written
+        int w_grp = 0;
+        auto deposit = [&](const u32x4 (&src)[G][NPW]) {
+            unsigned char *dst = s_w + w_grp * (G * WSLOT);
 #pragma unroll
-            for (int k = 0; k < NPW; ++k) *reinterpret_cast<u32x4 *>(dst + doff[k]) = src[k];
-            w_slot ^= 1;
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < NPW; ++k) *reinterpret_cast<u32x4 *>(dst + g * WSLOT + doff[k]) = src[g][k];
+            w_grp = w_grp == 2 ? 0 : w_grp + 1;
         };
         long long waited = 0;
-        // prologue: steps 0 and 1 into the two slots, steps 2 .. WF+1 requested
-        request(wreg[0]);
-        request(wreg[1]);
-        deposit(wreg[0]);
-        deposit(wreg[1]);
+        // prologue: groups 0 and 1 into the ring, groups 2 .. WFM+1 requested (set f holds group 2 + f)
 #pragma unroll
-        for (int f = 0; f < WF; ++f) request(wreg[f]);   // set f holds step 2 + f
+        for (int f = 0; f < 2; ++f) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) request(wreg[0][g]);
+            deposit(wreg[0]);
+        }
+#pragma unroll
+        for (int f = 0; f < WFM; ++f)
+#pragma unroll
+            for (int g = 0; g < G; ++g) request(wreg[f][g]);
         lds_barrier();
-        lds_barrier();   // the compute waves have fetched step 0's operands: slot 0 may be overwritten
-        // step i: deposit step i+2 (set i % WF) into slot i % 2, then request step i+2+WF into the same set
-        for (int i = 0; i < nsteps_pad; i += WF) {
+        // group k: deposit group k+2 (set k % WFM), then request group k+2+WFM into the same set
+        for (int k = 0; k < ngroups_pad; k += WFM) {
 #pragma unroll
-            for (int f = 0; f < WF; ++f) {
+            for (int f = 0; f < WFM; ++f) {
                 deposit(wreg[f]);
-                request(wreg[f]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) request(wreg[f][g]);
                 SPLIT_TIMED(lds_barrier(), waited);
             }
         }
@@ -255,22 +267,29 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         // Chunk c+2 is converted into the buffer of chunk c during the LAST tap of chunk c (the compute waves fetched that
         // tap's operands a step earlier) from registers whose loads were issued a whole chunk before; the same registers
         // then take the loads of chunk c+3.
+        // During group k the compute waves fetch taps kG+1 .. (k+1)G, so the chunks below the one of tap kG+1 are free, and the
+        // barrier that closes the group promises the chunks up to tap (k+2)G.  Host: 2G <= taps + 1, i.e. those 2G taps touch
+        // at most two chunks - the two LDS buffers.  A chunk is converted as soon as its buffer is free, from registers whose
+        // loads were issued when the previous chunk was converted (about a chunk of matrix work earlier).
         long long waited = 0, conv = 0;
         if (nchunk > 0) { issue_loads(0); convert_store(0); }
         if (nchunk > 1) { issue_loads(1); convert_store(1); }
         if (nchunk > 2) issue_loads(2);
+        int conv_next = 2;
         lds_barrier();
-        lds_barrier();
-        int c = 0, t = 0;
-        for (int i = 0; i < nsteps; ++i) {
-            if (t == ntaps - 1 && !(a.debug & 2)) {
-                if (c + 2 < nchunk) SPLIT_TIMED(convert_store(c + 2), conv);
-                if (c + 3 < nchunk) issue_loads(c + 3);
+        int m_c = 0, m_t = 1;   // chunk / tap of micro-step kG+1
+        if (m_t >= ntaps) { m_t -= ntaps; ++m_c; }
+        for (int k = 0; k < ngroups; ++k) {
+            if (conv_next < nchunk && conv_next <= m_c + 1 && !(a.debug & 2)) {
+                SPLIT_TIMED(convert_store(conv_next), conv);
+                if (conv_next + 1 < nchunk) issue_loads(conv_next + 1);
+                ++conv_next;
             }
             SPLIT_TIMED(lds_barrier(), waited);
-            if (++t == ntaps) { t = 0; ++c; }
+            m_t += G;
+            while (m_t >= ntaps) { m_t -= ntaps; ++m_c; }
         }
-        for (int i = nsteps; i < nsteps_pad; ++i) lds_barrier();
+        for (int k = ngroups; k < ngroups_pad; ++k) lds_barrier();
         if (a.trace && tid == 384) { a.trace[wg * 8 + 5] = conv; a.trace[wg * 8 + 6] = waited; }
         return;
     }
@@ -335,37 +354,44 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     lds_barrier();
     if (a.trace && tid == 0) a.trace[wg * 8 + 1] = clock64();
     {
-        // operands of the NEXT step: tap f_t of chunk parity f_par, weight slot f_slot
+        // operands of the NEXT tap: tap f_t of chunk parity f_par, weight slot f_slot of the 3G-slot ring
         int f_t = 0, f_par = 0, f_slot = 0;
         const unsigned char *bw_lane = s_w + (wc * MC * 3 * 64 + lane) * 16;
         auto fetch = [&](SplitOps<MP, MC> &o) {
             load_ops(o, s_in + f_par * ibuf_bytes, bw_lane + f_slot * WSLOT, tap_off(f_t));
             if (++f_t == ntaps) { f_t = 0; f_par ^= 1; }
-            f_slot ^= 1;
+            if (++f_slot == 3 * G) f_slot = 0;
         };
         SplitOps<MP, MC> o0, o1;
         if (nsteps > 0) fetch(o0);
-        lds_barrier();   // step 0's operands are in registers before the loaders reuse its weight slot
-        // Two steps per iteration (static register sets).  The operand fetch is unconditional - past the last step it reads
-        // stale LDS that nobody uses - so that fetch and matrix instructions share one basic block, and the LDS reads of the
-        // next step are spread between this step's matrix instructions (one read per NM / NR of them): issued as one burst
-        // they leave the matrix pipe idle after every barrier.
-        int i = 0;
-        for (; i + 1 < nsteps; i += 2) {
-            fetch(o1);
-            mma(o0);
-            SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
-            SPLIT_TIMED(lds_barrier(), waited);
-            fetch(o0);
-            mma(o1);
-            SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
-            SPLIT_TIMED(lds_barrier(), waited);
+        // U taps per iteration (static register sets, a barrier after every G-th).  The operand fetch is unconditional - past
+        // the last tap it reads stale LDS that nobody uses - so that fetch and matrix instructions share one basic block, and
+        // the LDS reads of the next tap are spread between this tap's matrix instructions (one read per NM / NR of them):
+        // issued as one burst they leave the matrix pipe idle.
+        constexpr int U = G > 2 ? G : 2;
+        int i = 0, bars = 0;
+        for (; i + U <= nsteps; i += U) {
+#pragma unroll
+            for (int j = 0; j < U; j += 2) {
+                fetch(o1);
+                mma(o0);
+                SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
+                if ((j + 1) % G == 0) { SPLIT_TIMED(lds_barrier(), waited); ++bars; }
+                fetch(o0);
+                mma(o1);
+                SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
+                if ((j + 2) % G == 0) { SPLIT_TIMED(lds_barrier(), waited); ++bars; }
+            }
         }
-        if (i < nsteps) {
-            mma(o0);
-            SPLIT_TIMED(lds_barrier(), waited);
+        // tail: fewer than U taps left (the sets keep alternating from o0)
+#pragma unroll
+        for (int j = 0; j < U - 1; ++j) {
+            if (i + j < nsteps) {
+                if (j % 2 == 0) { fetch(o1); mma(o0); } else { fetch(o0); mma(o1); }
+                if ((i + j + 1) % G == 0) { lds_barrier(); ++bars; }
+            }
         }
-        for (int k = nsteps; k < nsteps_pad; ++k) lds_barrier();
+        for (; bars < ngroups_pad; ++bars) lds_barrier();
     }
     if (a.trace && tid == 0) { a.trace[wg * 8 + 2] = clock64(); a.trace[wg * 8 + 4] = waited; }
 
@@ -501,6 +527,8 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
     static const double c_chunk = [] { const char *e = getenv("LAV_SPLIT_C_CHUNK"); return e ? atof(e) : 1.2; }();
     const long ncu = c.target_cus >= 16 && c.target_cus <= 256 ? c.target_cus : 256;
     const int nchunks = p.cin_pad / 16;
+    int min_taps = p.taps_per_class;   // transposed convolutions: the output-parity classes have different tap counts
+    for (auto &t : p.taps) min_taps = std::min<int>(min_taps, (int)t.size());
     const size_t LDS_MAX = 160 * 1024;
     const int shapes[6][3] = {{2, 2, 2}, {2, 2, 4}, {1, 2, 4}, {1, 2, 2}, {1, 1, 4}, {1, 1, 2}};   // MP, MC, WPX (ties: first wins)
     for (auto &sh : shapes) {
@@ -529,22 +557,25 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
             const int plane = (ROWS * Wst + 63) / 64 * 64;
             if (plane > SPLIT_LOADERS * SPLIT_NT) continue;
             {
-                // LDS: two activation chunk buffers + two weight slots (one tap of the tile each)
-                const size_t lds_in = (size_t)2 * 6 * plane * 16, wslot = (size_t)NBLK * 3 * 1024;
-                const int wring = 2;
-                const size_t lds = lds_in + wring * wslot;
-                if (lds > LDS_MAX) continue;
-                const long wgs1 = tiles * ((c.cout + NBLK * 32 - 1) / (NBLK * 32)) * c.batch * p.nclasses;
-                const int ks_max = f_ks ? f_ks : (nchunks >= 4 ? std::min(16, nchunks / 2) : 1);
-                const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
-                for (int ks = f_ks ? f_ks : 1; ks <= ks_max; ++ks) {
-                    const long wgs = wgs1 * ks;
-                    const int nch = (nchunks + ks - 1) / ks;
-                    // per chunk: matrix work + one barrier per tap, and the loaders' floor (a chunk's loads + conversion)
-                    const double chunk_us = std::max(p.taps_per_class * (MP * MC * c_mma + c_stage), c_chunk * plane / 384.0);
-                    const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
-                    if (t < best.cost * (ks > 1 ? 0.97 : 1.0) - 1e-9) {
-                        best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, 1, ks, wring, lds, t};
+                // LDS: two activation chunk buffers + a ring of three groups of G taps of weights
+                for (int G : {2, 1}) {
+                    if (f_tg && G != f_tg) continue;
+                    if (2 * G > min_taps + 1 && G > 1) continue;   // 2G consecutive taps must touch at most two chunks (in every class)
+                    const size_t lds_in = (size_t)2 * 6 * plane * 16, wslot = (size_t)NBLK * 3 * 1024;
+                    const size_t lds = lds_in + 3 * G * wslot;
+                    if (lds > LDS_MAX) continue;
+                    const long wgs1 = tiles * ((c.cout + NBLK * 32 - 1) / (NBLK * 32)) * c.batch * p.nclasses;
+                    const int ks_max = f_ks ? f_ks : (nchunks >= 4 ? std::min(16, nchunks / 2) : 1);
+                    const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
+                    for (int ks = f_ks ? f_ks : 1; ks <= ks_max; ++ks) {
+                        const long wgs = wgs1 * ks;
+                        const int nch = (nchunks + ks - 1) / ks;
+                        // per chunk: matrix work + one barrier per G taps, and the loaders' floor (a chunk's loads + conversion)
+                        const double chunk_us = std::max(p.taps_per_class * (MP * MC * c_mma + c_stage / G), c_chunk * plane / 384.0);
+                        const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
+                        if (t < best.cost * (ks > 1 ? 0.97 : 1.0) - 1e-9) {
+                            best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, G, ks, 3 * G, lds, t};
+                        }
                     }
                 }
             }
@@ -553,21 +584,21 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
     return best;
 }
 
-template <int MP, int MC, int WPX, int NT>
-int launch_split_nt(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
+template <int MP, int MC, int WPX, int NT, int G>
+int launch_split_g(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split<MP, MC, WPX, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split<MP, MC, WPX, NT, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT>), grid, dim3(512), lds, st, sa);
+    hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT, G>), grid, dim3(512), lds, st, sa);
     return LAV_OK;
 }
 template <int MP, int MC, int WPX>
 int launch_split_t(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
-    if (sa.plane <= SPLIT_LOADERS * 2) return launch_split_nt<MP, MC, WPX, 2>(sa, grid, lds, st);
-    if (sa.plane <= SPLIT_LOADERS * 4) return launch_split_nt<MP, MC, WPX, 4>(sa, grid, lds, st);
-    return launch_split_nt<MP, MC, WPX, SPLIT_NT>(sa, grid, lds, st);
+    const bool small = sa.plane <= SPLIT_LOADERS * 2;
+    if (sa.tap_group == 2) return small ? launch_split_g<MP, MC, WPX, 2, 2>(sa, grid, lds, st) : launch_split_g<MP, MC, WPX, SPLIT_NT, 2>(sa, grid, lds, st);
+    return small ? launch_split_g<MP, MC, WPX, 2, 1>(sa, grid, lds, st) : launch_split_g<MP, MC, WPX, SPLIT_NT, 1>(sa, grid, lds, st);
 }
 
 // `a`: the epilogue / output description already filled in by lav_conv2d (pointers, sizes, flags, partial slab)
