@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 14
+#define LAV_ABI_VERSION 16
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -133,6 +133,19 @@ int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int num_cmds, in
                  const float *mlp_w, const float *mlp_b, float *out,
                  void *workspace, size_t workspace_bytes, void *stream);
 size_t lav_gru_cast_workspace_bytes(int B, int embd_dim, int H, int num_cmds, int T);
+/*
+ * embed + cast: the tail of the embedder and everything that hangs on it, in one launch per batch
+ * (uniplanner.py:36-40 AdaptiveAvgPool2d + Flatten, :50-53 cast_cmd_pred, :288-308 cast;
+ * model_inference.py:164-165, 240-251 transform_points + translate).
+ * feat [B][embd_dim][hw]: the embedder's last feature map (hw pixels per channel; hw = 1: the embedding itself);
+ * embd_out [B][embd_dim] or NULL: its spatial mean; cmd_w [num_cmds][embd_dim], cmd_b [num_cmds], cmds_out [B][num_cmds]
+ * (all three or none): sigmoid(cmd_w . embd + cmd_b); oris [B], locs [B][2] (each optional): every decoded waypoint
+ * (x, y) becomes (x cos o - y sin o, x sin o + y cos o) + loc.  Everything else as lav_gru_cast; honours lav_batch_limit.
+ */
+int lav_embed_cast(const float *feat, int B, int embd_dim, int hw, float *embd_out, int H, int num_cmds, int T,
+                   const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                   const float *mlp_w, const float *mlp_b, const float *cmd_w, const float *cmd_b, float *cmds_out,
+                   const float *oris, const float *locs, float *out, void *stream);
 
 /*
  * plan: GRU(I=4 -> H), h0 = embd[b]; iteration it, command c:
@@ -248,7 +261,8 @@ int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const f
 /* Grouped ConvTranspose2d with few output channels (memory bound, vector-ALU kernel): group g maps input channels
  * [g*cin/groups, (g+1)*cin/groups) to cout_per_group[g] (1..8) output channels; y is [batch][sum cout][oh][ow] with the
  * groups' channels in order.  weight: the groups' PyTorch-layout ConvTranspose2d weights [cin/groups][cout_g][k][k]
- * concatenated (device).  bias: [sum cout] device or NULL.  sigmoid_from: output channels >= it get a sigmoid, -1 = none.
+ * concatenated (device).  bias: [sum cout] device or NULL.  sigmoid_from: output channels >= it get a sigmoid, -1 = none,
+ * -2 = softmax over each group's channels (the class probabilities the agent takes from ERFNet, lav_agent_fast.py:264).
  * (kernel, stride) = (3, 2) or (2, 2).  cout_per_group is a host array.  Replaces the four head tails
  * ConvTranspose2d(64, out, 3, 2, 1, 1) of team_code_v2/models/lidar.py:30-33 (one launch for all heads) and ERFNet's
  * output layer lav/models/erfnet.py:137. */
@@ -319,6 +333,11 @@ int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max
  * ------------------------------------------------------------------------------------------ */
 int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const float *u, const float *dots_bias,
                   const float *w_v, const float *b_v, float *out, void *stream);
+
+/* Small dense layer out[b][o] = act(bias[o] + sum_k weight[o][k] x[b][k]) (weight in nn.Linear layout [out][in], bias or NULL;
+ * act 0 = none, 1 = sigmoid): the brake classifier nn.Sequential(Linear(1024, 1), Sigmoid) of team_code_v2/models/rgb.py:62,79. */
+int lav_linear_act(const float *x, int batch, int in_features, const float *weight, const float *bias, int out_features,
+                   int act, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 6c. Fixed-capacity, device-resident "other vehicles" batch.  The reference reads every detection back

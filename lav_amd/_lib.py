@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 14
+ABI_VERSION = 16
 MAX_CAM = 4
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "lav_paint": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, C.POINTER(Camera), _P, _P, _P]),
     "lav_gru_cast": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_cast_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "lav_embed_cast": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lav_gru_plan": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_plan_steps": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_plan_status": (_I, [_P, _Z, _I, _I, _I, _I, C.POINTER(_I), _P]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     "lav_gru_seq_backward_workspace_bytes": (_Z, [_I, _I]),
     "lav_gru_seq_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "lav_attn_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "lav_linear_act": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P]),
     "lav_det_decode": (_I, [_P, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "lav_batch_limit": (_I, [_P]),
     "lav_pool_affine": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),

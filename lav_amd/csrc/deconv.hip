@@ -85,6 +85,27 @@ __global__ __launch_bounds__(256) void k_deconv_grouped(DeconvArgs a) {
         }
     }
     const long oplane = (long)a.OH * a.OW;
+    if (a.sigmoid_from == -2) {   // softmax over the group's channels (ERFNet's class scores, lav_agent_fast.py:264): all in registers
+#pragma unroll
+        for (int ry = 0; ry < S; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < S; ++rx) {
+                const int oy = S * qy + ry - a.pad, ox = S * qx + rx - a.pad;
+                if (oy < 0 || oy >= a.OH || ox < 0 || ox >= a.OW) continue;
+                float v[NC], m = -INFINITY, sum = 0.f;
+#pragma unroll
+                for (int co = 0; co < NC; ++co) {
+                    v[co] = co < nc ? acc[ry][rx][co] + (a.bias ? a.bias[co0 + co] : 0.f) : -INFINITY;
+                    m = fmaxf(m, v[co]);
+                }
+#pragma unroll
+                for (int co = 0; co < NC; ++co) { v[co] = co < nc ? expf(v[co] - m) : 0.f; sum += v[co]; }
+#pragma unroll
+                for (int co = 0; co < NC; ++co)
+                    if (co < nc) a.y[((long)n * a.cout + co0 + co) * oplane + (long)oy * a.OW + ox] = v[co] / sum;
+            }
+        return;
+    }
 #pragma unroll
     for (int co = 0; co < NC; ++co) {
         if (co >= nc) break;

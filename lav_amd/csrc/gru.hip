@@ -36,19 +36,42 @@ constexpr int CAST_H = 64;
 
 constexpr int CAST_THREADS = 768;  // 12 waves share the 192x512 input projection; waves 0-2 run the recurrence
 
+// Extras of lav_embed_cast (each optional): the input is a feature map [B][embd_dim][hw] whose spatial mean is the embedding
+// (AdaptiveAvgPool2d + Flatten of the embedder, uniplanner.py:36-40) and is written to embd_out; the command scores
+// sigmoid(cmd_w . embd + cmd_b) (cast_cmd_pred, :50-53); the decoded waypoints rotated by the actor's heading and moved to
+// its position (transform_points + translate, model_inference.py:164-165).
+struct CastExtra {
+    int hw;
+    float *embd_out;
+    const float *cmd_w, *cmd_b;
+    float *cmds_out;
+    const float *oris, *locs;
+};
+
 __global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restrict__ embd, int embd_dim, int num_cmds, int T,
                                                   const float *__restrict__ w_ih, const float *__restrict__ w_hh,
                                                   const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                                   const float *__restrict__ mlp_w, const float *__restrict__ mlp_b,
-                                                  float *__restrict__ out, const int *__restrict__ n_valid) {
+                                                  float *__restrict__ out, const int *__restrict__ n_valid, CastExtra x) {
     constexpr int H = CAST_H, G = 3 * H;
     __shared__ float gi[G];
     __shared__ float gh[G];
     __shared__ float h[H];
+    __shared__ float s_e[1024];   // the embedding (embd_dim <= 1024)
     const int cmd = blockIdx.x, b = blockIdx.y;
     if (n_valid && b >= *n_valid) return;   // lav_batch_limit
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float *e = embd + (long)b * embd_dim;
+    // the embedding: given, or the spatial mean of the feature map (sum in pixel order, then one division - torch's mean)
+    for (int c = tid; c < embd_dim; c += CAST_THREADS) {
+        const float *src = embd + ((long)b * embd_dim + c) * x.hw;
+        float sum = src[0];
+        for (int i = 1; i < x.hw; ++i) sum += src[i];
+        const float m = x.hw > 1 ? sum / (float)x.hw : sum;
+        s_e[c] = m;
+        if (x.embd_out && cmd == 0) x.embd_out[(long)b * embd_dim + c] = m;
+    }
+    __syncthreads();
+    const float *e = s_e;
     const float *wih = w_ih + (long)cmd * G * embd_dim;
     // input projection, once: wave `wid` owns 16 rows, done 8 at a time with independent accumulators so the
     // 64 coalesced row loads and the 8 butterfly reductions of a batch are all in flight together
@@ -70,6 +93,12 @@ __global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restri
             for (int j = 0; j < 8; ++j) gi[r0 + j] = acc[j] + b_ih[cmd * G + r0 + j];
         }
     }
+    if (x.cmds_out && wid == 11) {   // this command's score: one more row on the last helper wave
+        float acc = 0.f;
+        for (int k = lane; k < embd_dim; k += 64) acc = fmaf(x.cmd_w[(long)cmd * embd_dim + k], e[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) x.cmds_out[(long)b * num_cmds + cmd] = sigmoidf_(acc + x.cmd_b[cmd]);
+    }
     __syncthreads();  // gi[] complete and visible
     if (tid >= G) return;  // the nine helper waves are done (terminated waves drop out of later barriers)
     float w[H];
@@ -83,6 +112,11 @@ __global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restri
     const float m0 = tid < H ? mlp_w[(cmd * 2 + 0) * H + tid] : 0.f;
     const float m1 = tid < H ? mlp_w[(cmd * 2 + 1) * H + tid] : 0.f;
     float run0 = 0.f, run1 = 0.f;
+    // (x, y) @ [[cos, sin], [-sin, cos]] + loc
+    float rc = 1.f, rs = 0.f, lx = 0.f, ly = 0.f;
+    if (x.oris) { const float o = x.oris[b]; rc = cosf(o); rs = sinf(o); }
+    if (x.locs) { lx = x.locs[2 * b]; ly = x.locs[2 * b + 1]; }
+    const bool xform = x.oris != nullptr || x.locs != nullptr;
     __syncthreads();
     float *o = out + (((long)b * num_cmds + cmd) * T) * 2;
     for (int t = 0; t < T; ++t) {
@@ -101,8 +135,8 @@ __global__ __launch_bounds__(CAST_THREADS) void k_gru_cast(const float *__restri
             if (tid == 0) {
                 run0 += s0 + mlp_b[cmd * 2 + 0];
                 run1 += s1 + mlp_b[cmd * 2 + 1];
-                o[t * 2 + 0] = run0;
-                o[t * 2 + 1] = run1;
+                o[t * 2 + 0] = xform ? (run0 * rc + run1 * -rs) + lx : run0;
+                o[t * 2 + 1] = xform ? (run0 * rs + run1 * rc) + ly : run1;
             }
         }
         __syncthreads();
@@ -491,8 +525,27 @@ extern "C" int lav_gru_cast(const float *embd, int B, int embd_dim, int H, int n
     if (B == 0) return LAV_OK;
     LAV_REQUIRE(embd && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_gru_cast: null argument");
     const int tok = timer_begin("gru_cast", static_cast<hipStream_t>(stream));
+    LAV_REQUIRE(embd_dim <= 1024, "lav_gru_cast: embedding of %d > 1024 values", embd_dim);
     hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(CAST_THREADS), 0, static_cast<hipStream_t>(stream), embd, embd_dim,
-                       num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out, lav::batch_limit());
+                       num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out, lav::batch_limit(), CastExtra{1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+    timer_end(tok, static_cast<hipStream_t>(stream));
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_embed_cast(const float *feat, int B, int embd_dim, int hw, float *embd_out, int H, int num_cmds, int T,
+                              const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *mlp_w,
+                              const float *mlp_b, const float *cmd_w, const float *cmd_b, float *cmds_out, const float *oris,
+                              const float *locs, float *out, void *stream) {
+    LAV_REQUIRE(B >= 0 && embd_dim > 0 && embd_dim <= 1024 && hw >= 1 && num_cmds > 0 && T > 0, "lav_embed_cast: bad sizes");
+    LAV_REQUIRE(H == CAST_H, "lav_embed_cast: hidden size %d not instantiated (%d)", H, CAST_H);
+    LAV_REQUIRE(B <= 65535, "lav_embed_cast: B too large");
+    LAV_REQUIRE((cmd_w == nullptr) == (cmds_out == nullptr) && (cmd_w == nullptr) == (cmd_b == nullptr), "lav_embed_cast: cmd_w, cmd_b and cmds_out come together");
+    if (B == 0) return LAV_OK;
+    LAV_REQUIRE(feat && w_ih && w_hh && b_ih && b_hh && mlp_w && mlp_b && out, "lav_embed_cast: null argument");
+    const int tok = timer_begin("gru_cast", static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(k_gru_cast, dim3(num_cmds, B), dim3(CAST_THREADS), 0, static_cast<hipStream_t>(stream), feat, embd_dim,
+                       num_cmds, T, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, out, lav::batch_limit(), CastExtra{hw, embd_out, cmd_w, cmd_b, cmds_out, oris, locs});
     timer_end(tok, static_cast<hipStream_t>(stream));
     LAV_LAUNCH_CHECK();
     return LAV_OK;

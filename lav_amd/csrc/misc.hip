@@ -106,3 +106,38 @@ extern "C" int lav_profile_read(const char *kernel, double *total_ms, int *launc
     }
     return LAV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Small dense layer: out[b][o] = act(bias[o] + sum_k w[o][k] x[b][k]); one wave per output (rows of a few hundred to a
+// few thousand values: a library GEMM launch costs more than the arithmetic - the brake classifier Linear(1024 -> 1) +
+// sigmoid of team_code_v2/models/rgb.py:62,79 showed up as a 55 us hipBLASLt kernel on the frame's side stream).
+namespace {
+__global__ __launch_bounds__(256) void k_linear_act(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                    int B, int K, int O, int act, float *__restrict__ out) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * O) return;
+    const int b = wave / O, o = wave - b * O;
+    const float *xr = x + (long)b * K, *wr = w + (long)o * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], xr[k], acc);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[o] : 0.f);
+        if (act == 1) v = 1.f / (1.f + expf(-v));
+        out[(long)b * O + o] = v;
+    }
+}
+}  // namespace
+
+extern "C" int lav_linear_act(const float *x, int batch, int in_features, const float *weight, const float *bias, int out_features,
+                              int act, float *out, void *stream) {
+    LAV_REQUIRE(x && weight && out && batch >= 0 && in_features >= 1 && out_features >= 1, "lav_linear_act: bad argument");
+    LAV_REQUIRE(act == 0 || act == 1, "lav_linear_act: act %d (0 none, 1 sigmoid)", act);
+    if (batch == 0) return LAV_OK;
+    const long waves = (long)batch * out_features;
+    hipLaunchKernelGGL(k_linear_act, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, weight, bias, batch,
+                       in_features, out_features, act, out);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}

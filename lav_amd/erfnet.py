@@ -164,25 +164,27 @@ class ERFNet(nn.Module):
         self._drop()
         return super()._load_from_state_dict(*a, **k)
 
-    def _engine(self, device, input_affine=None):
-        if self._eng is None or self._eng[0] != (device, input_affine):
+    def _engine(self, device, input_affine=None, softmax=False):
+        if self._eng is None or self._eng[0] != (device, input_affine, softmax):
             stages = [self.encoder.initial_block.engine(device, input_affine)]
             stages += [m.engine(device) for m in self.encoder.layers]
             stages += [m.engine(device) for m in self.decoder.layers]
-            stages.append(GroupedDeconv([self.decoder.output_conv], device=device))   # 16 -> classes, k2 s2: memory bound
-            object.__setattr__(self, "_eng", ((device, input_affine), stages))
+            stages.append(GroupedDeconv([self.decoder.output_conv], softmax=softmax, device=device))   # 16 -> classes, k2 s2: memory bound
+            object.__setattr__(self, "_eng", ((device, input_affine, softmax), stages))
         return self._eng[1]
 
-    def forward(self, x, input_affine=None):
+    def forward(self, x, input_affine=None, softmax=False):
         """input_affine=(s, t): x is the raw input and the network behaves as on s*x + t (folded into the first block in
-        the HIP path, applied explicitly in the torch path)."""
+        the HIP path, applied explicitly in the torch path).  softmax: return the class probabilities instead of the scores
+        (computed in the output layer's epilogue in the HIP path)."""
         if self.training:      # autograd path (torch ops)
             if input_affine is not None:
                 x = x * input_affine[0] + input_affine[1]
-            return self.decoder(self.encoder(x))
+            y = self.decoder(self.encoder(x))
+            return torch.softmax(y, dim=1) if softmax else y
         if not x.is_cuda:
             raise RuntimeError("ERFNet: eval-mode forward needs a tensor in HBM - lav_amd has no CPU path "
                                "(CPU evaluation for tests and baselines: oracle/camera.py)")
-        for stage in self._engine(x.device, input_affine):
+        for stage in self._engine(x.device, input_affine, softmax):
             x = stage(x)
         return x

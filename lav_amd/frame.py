@@ -56,6 +56,12 @@ class FramePipeline:
         self.lidars, self.locs, self.oris = deque(), deque(), deque()
         self.prev_lidar = None
 
+    def _sem_probs(self, all_rgbs):
+        """Class probabilities of the three cameras (lav_agent_fast.py:264); lav_amd's segmenter has the softmax in its
+        output layer's epilogue, any other module gets torch's."""
+        probs = getattr(self.seg_model, "probs", None)
+        return probs(all_rgbs) if probs is not None else torch.softmax(self.seg_model(all_rgbs), dim=1)
+
     def preprocess(self, lidar):
         """Ego-box removal.  Default: mark dropped points with x = NaN (they fail the pillar range test exactly
         like removed points, every downstream result is independent of point order and count) - no stream
@@ -89,7 +95,7 @@ class FramePipeline:
             return None
         cur_lidar = self.preprocess(torch.cat([lidar, self.prev_lidar]))
         self.prev_lidar = lidar
-        pred_sem = torch.softmax(self.seg_model(all_rgbs), dim=1)
+        pred_sem = self._sem_probs(all_rgbs)
         fused = self.infer_model.forward_paint(cur_lidar, pred_sem)
         self.lidars.append(fused)
         self.locs.append(np.asarray(loc, np.float64))
@@ -192,7 +198,7 @@ class GraphedFramePipeline(FramePipeline):
     def _g_lidar(self):
         im, lm = self.infer_model, self.infer_model.lidar_model
         cur = ops.merge_ticks(self.b_tick, self.b_prev)                 # concat + ego box + prev <- tick: one launch
-        pred_sem = torch.softmax(self.seg_model(self.b_all_rgbs), dim=1)
+        pred_sem = self._sem_probs(self.b_all_rgbs)
         fused = im.forward_paint(cur, pred_sem)
         lidar_points = ops.stack_sweeps(fused, self.ring, self.b_slot, self.b_sweeps, self.b_R, self.b_t)
         canvas = lm.point_pillar_net([lidar_points], [lidar_points.shape[0]])
@@ -221,8 +227,7 @@ class GraphedFramePipeline(FramePipeline):
     def _g_ego(self, cmd_value):
         up, features = self.infer_model.uniplanner, self.b_features
         ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], up.pixels_per_meter / 2, up.crop_size)
-        ego_embd = up.lidar_conv_emb(ego_crop)
-        ego_cast = up.cast(ego_embd, mode="ego")
+        ego_embd, ego_cast, _ = up.embed_cast(ego_crop)
         ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
                            crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
         return dict(ego_embd=ego_embd, ego_plan_locs=ego_plan, ego_cast_locs=ego_cast[0, int(cmd_value)])
@@ -232,11 +237,7 @@ class GraphedFramePipeline(FramePipeline):
         feats = self.b_features
         locs, oris = self.b_locs[:n], self.b_oris[:n]
         crops = up.crop_feature(feats.expand(n, -1, -1, -1), locs, oris, up.pixels_per_meter / 2, up.crop_size)
-        embd = up.lidar_conv_emb(crops)
-        cast = up.cast(embd, mode="other")
-        cmds = up.cast_cmd_pred(embd)
-        from .planner_common import transform_points
-        cast = transform_points(cast, oris[:, None].repeat(1, up.num_cmds)) + locs.view(n, 1, 1, 2)
+        _, cast, cmds = up.embed_cast(crops, oris=oris, locs=locs, want_cmds=True)   # pool, cast GRUs, command scores, ego frame
         return dict(other_cast_locs=cast, other_cast_cmds=cmds)
 
     def _g_others_cap(self):

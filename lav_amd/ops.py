@@ -194,6 +194,27 @@ def gru_cast(embd, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, T: int):
     return out
 
 
+def embed_cast(feat, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, T: int, cmd_w=None, cmd_b=None, oris=None, locs=None, want_embd=True):
+    """feat (B, E, h, w) (the embedder's last map) or (B, E) -> (embd (B,E) or None, cast (B,num_cmds,T,2), cmds (B,num_cmds) or
+    None): spatial mean, the six cast GRUs, the command scores and the rotation / translation of the waypoints into the ego
+    frame in ONE launch (lav_embed_cast)."""
+    lib = _lib.load()
+    feat = _f32c(feat, "feat")
+    B, E = feat.shape[0], feat.shape[1]
+    hw = feat.numel() // max(B * E, 1) if B else 1
+    ncmd, g3, _ = w_ih.shape
+    dev = feat.device
+    out = torch.empty((B, ncmd, T, 2), dtype=torch.float32, device=dev)
+    embd = torch.empty((B, E), dtype=torch.float32, device=dev) if want_embd else None
+    cmds = torch.empty((B, ncmd), dtype=torch.float32, device=dev) if cmd_w is not None else None
+    check(lib.lav_embed_cast(_ptr(feat), B, E, hw, _ptr(embd), g3 // 3, ncmd, T, _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh),
+                             _ptr(mlp_w), _ptr(mlp_b), _ptr(None if cmd_w is None else _f32c(cmd_w, "cmd_w")),
+                             _ptr(None if cmd_b is None else _f32c(cmd_b, "cmd_b")), _ptr(cmds),
+                             _ptr(None if oris is None else _f32c(oris.reshape(-1), "oris")),
+                             _ptr(None if locs is None else _f32c(locs.reshape(-1, 2), "locs")), _ptr(out), _stream()), "lav_embed_cast")
+    return embd, out, cmds
+
+
 def gru_plan(embd, nxp, cast_locs, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, iters: int, cmd: int, ppm: float,
              crop_size: float, impl: str = "auto"):
     """embd (B,H), nxp (B,2), cast_locs (B,num_cmds,T,2) -> (B, iters, num_cmds or 1, T, 2).
@@ -390,7 +411,7 @@ class GroupedDeconv:
     input, as ONE lav_deconv_grouped launch (memory-bound vector kernel): the tails of the detection / segmentation heads
     (4 x 64 channels -> 1 + 2 + 2 + 4), or a single layer (groups = 1: ERFNet's output layer)."""
 
-    def __init__(self, deconvs, sigmoid_from: int = -1, device=None):
+    def __init__(self, deconvs, sigmoid_from: int = -1, softmax: bool = False, device=None):
         ct0 = deconvs[0]
         for ct in deconvs:
             if (ct.kernel_size, ct.stride, ct.padding, ct.output_padding, ct.in_channels) != \
@@ -410,7 +431,7 @@ class GroupedDeconv:
         if ct0.bias is not None:
             self.bias = torch.cat([ct.bias.detach().to(torch.float32).cpu() for ct in deconvs]).to(dev)
         self._outs_c = (C.c_int * self.groups)(*self.outs)
-        self.sigmoid_from = int(sigmoid_from)
+        self.sigmoid_from = -2 if softmax else int(sigmoid_from)     # -2: softmax over each group's channels, in the epilogue
 
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None):
         x = _f32c(x, "x")
@@ -551,11 +572,27 @@ class batch_limit:
         return False
 
 
-def attn_pool(x: torch.Tensor, u: torch.Tensor, dots_bias: torch.Tensor, w_v: torch.Tensor, b_v: torch.Tensor, heads: int) -> torch.Tensor:
-    """x (B,C,h,w) in HBM -> (B,C): single-query multi-head attention pooling with folded projections (lav_attn_pool)."""
+def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, sigmoid: bool = False) -> torch.Tensor:
+    """act(x @ weight.T + bias) for small layers, x (B,K) in HBM, weight (O,K) (lav_linear_act)."""
+    x = _f32c(x, "x")
+    B, K = x.shape
+    O = weight.shape[0]
+    out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    check(_lib.load().lav_linear_act(_ptr(x), B, K, _ptr(_f32c(weight, "weight")), _ptr(None if bias is None else _f32c(bias, "bias")), O,
+                                     int(bool(sigmoid)), _ptr(out), _stream()), "lav_linear_act")
+    return out
+
+
+def attn_pool(x: torch.Tensor, u: torch.Tensor, dots_bias: torch.Tensor, w_v: torch.Tensor, b_v: torch.Tensor, heads: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,C,h,w) in HBM -> (B,C): single-query multi-head attention pooling with folded projections (lav_attn_pool).
+    out: a (B,C) buffer whose rows are C apart (e.g. one half of a (1,2C) concatenation buffer at batch 1)."""
     x = _f32c(x, "x")
     B, Cc, H, W = x.shape
-    out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, Cc) or out.dtype != torch.float32 or not out.is_cuda or (B > 1 and out.stride(0) != Cc) or out.stride(1) != 1:
+        raise RuntimeError("attn_pool: out must be a (B, C) float32 buffer in HBM with rows C apart")
     check(_lib.load().lav_attn_pool(_ptr(x), B, Cc, H * W, int(heads), _ptr(_f32c(u, "u")), _ptr(_f32c(dots_bias, "dots_bias")),
                                     _ptr(_f32c(w_v, "w_v")), _ptr(_f32c(b_v, "b_v")), _ptr(out), _stream()), "lav_attn_pool")
     return out

@@ -31,10 +31,15 @@ class RGBSegmentationModel(nn.Module):
         super().__init__()
         self.erfnet = ERFNet(len(seg_channels) + 1)
 
-    def forward(self, rgb):
+    def forward(self, rgb, softmax=False):
         if not self.training:     # (rgb/255 - .5)*2 folded into the first block: three launches less
-            return self.erfnet(rgb, input_affine=(2.0 / 255.0, -1.0))
-        return self.erfnet((rgb / 255. - .5) * 2)
+            return self.erfnet(rgb, input_affine=(2.0 / 255.0, -1.0), softmax=softmax)
+        return self.erfnet((rgb / 255. - .5) * 2, softmax=softmax)
+
+    def probs(self, rgb):
+        """softmax(forward(rgb), dim=1) - what the agent feeds to point painting (lav_agent_fast.py:264) - with the softmax in
+        the output layer's epilogue."""
+        return self.forward(rgb, softmax=True)
 
 
 class SegmentationHead(nn.Module):
@@ -105,13 +110,13 @@ class Attention(nn.Module):
         self._folded[key] = (ver, folded)
         return folded
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         b, d, h, w = x.shape
         if not self.training:
             if not x.is_cuda:
                 raise RuntimeError("Attention: eval-mode forward needs a tensor in HBM - lav_amd has no CPU path (oracle/camera.py)")
             u, dots_bias, w_v, b_v = self._fold(x.device, h * w)
-            return ops.attn_pool(x, u, dots_bias, w_v, b_v, self.num_heads)
+            return ops.attn_pool(x, u, dots_bias, w_v, b_v, self.num_heads, out=out)
         tok = x.flatten(2).transpose(1, 2)                                        # b (h w) d
         k, v = self.linear_kv(tok).chunk(2, dim=-1)
         k = k.view(b, h * w, self.num_heads, self.dim_head).transpose(1, 2)       # b heads n dh
@@ -154,6 +159,13 @@ class RGBBrakePredictionModel(nn.Module):
     def forward(self, rgb1, rgb2, mask=False):
         x1 = self.conv_backbone(self.normalize(rgb1 / 255.))
         x2 = self.conv_backbone(self.normalize(rgb2 / 255.))
+        if not self.training and x1.is_cuda and x1.shape[0] == 1 and not mask:
+            # both pooled vectors land in one (1, 1024) buffer (no cat), classifier = one small launch (no library GEMM)
+            both = torch.empty((1, 2 * x1.shape[1]), dtype=torch.float32, device=x1.device)
+            C = x1.shape[1]
+            self.attn1(x1, out=both[:, :C]); self.attn2(x2, out=both[:, C:])
+            lin = self.classifier[0]
+            return ops.linear_act(both, lin.weight, lin.bias, sigmoid=True)[:, 0]
         pred = self.classifier(torch.cat([self.attn1(x1), self.attn2(x2)], dim=1))
         if mask:
             return pred[:, 0], F.interpolate(self.seg_head(x1), scale_factor=4), F.interpolate(self.seg_head(x2), scale_factor=4)

@@ -80,6 +80,17 @@ class UniPlanner(DecoderMixin, _Engine):
             return crop_feature_torch(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
         return crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
 
+    def embed_cast(self, crops, oris=None, locs=None, want_cmds=False):
+        """Eval-mode tail of both branches in two steps instead of ~17 launches: the ResNet-18 trunk on the crops, then ONE
+        lav_embed_cast launch = AdaptiveAvgPool2d + Flatten (uniplanner.py:36-40), the six cast GRUs (:288-308), cast_cmd_pred
+        (:50-53) and - for the other vehicles - transform_points + translate into the ego frame (model_inference.py:164-165).
+        crops (B,C,crop,crop) -> (embd (B,512), cast (B,num_cmds,T,2), cmds (B,num_cmds) or None)."""
+        fmap = self.lidar_conv_emb[0](crops)
+        w = self._dec(crops.device)["cast"]
+        lin = self.cast_cmd_pred[0]
+        return ops.embed_cast(fmap, w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"], w["mlp_b"], self.num_plan,
+                              cmd_w=lin.weight if want_cmds else None, cmd_b=lin.bias if want_cmds else None, oris=oris, locs=locs)
+
     def others_from_detections(self, det, H, W):
         """Pixel detections -> ego-frame metres and headings, skipping the ego's own box
         (uniplanner.py:194-212 / model_inference.py:125-144)."""
@@ -160,17 +171,12 @@ class UniPlanner(DecoderMixin, _Engine):
             locs_t = torch.tensor(locs, dtype=torch.float32, device=dev)
             oris_t = torch.tensor(oris, dtype=torch.float32, device=dev)
             crops = self.crop_feature(features.expand(N, *features.size()), locs_t, oris_t, ppm_f, self.crop_size)
-            other_embd = self.lidar_conv_emb(crops)
-            other_cast = self.cast(other_embd, mode="other")
-            other_cmds = self.cast_cmd_pred(other_embd)
-            other_cast = transform_points(other_cast, oris_t[:, None].repeat(1, self.num_cmds))
-            other_cast = other_cast + locs_t.view(N, 1, 1, 2)
+            _, other_cast, other_cmds = self.embed_cast(crops, oris=oris_t, locs=locs_t, want_cmds=True)
         else:  # the reference returns CPU zeros here (model_inference.py:167-168) - keep
             other_cast = torch.zeros((0, self.num_cmds, self.num_plan, 2))
             other_cmds = torch.zeros((0, self.num_cmds))
         ego_crop = self.crop_feature(features[None], features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, self.crop_size)
-        ego_embd = self.lidar_conv_emb(ego_crop)
-        ego_cast = self.cast(ego_embd, mode="ego")
+        ego_embd, ego_cast, _ = self.embed_cast(ego_crop)
         # only the commanded branch of the plan GRU is needed: branches never interact (uniplanner.py:264-275)
         ego_plan = self.plan(ego_embd, nxp[None], cast_locs=ego_cast, pixels_per_meter=self.pixels_per_meter,
                              crop_size=self.crop_size * 2, cmd=int(cmd))[0, -1, 0]
