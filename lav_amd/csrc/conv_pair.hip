@@ -23,6 +23,7 @@
 // Bound: launch/latency (a pair is 0.06-0.45 GFLOP); the design target is the fixed cost, not the matrix pipes.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.hpp"
@@ -222,12 +223,277 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair(PairArgs a) {
     PAIR_STAMP(6);
 #undef PAIR_STAMP
 }
+
+// ------------------------------------------------------------------------------------------------ bf16x6 variant
+// The same pair on the bf16 matrix cores with every fp32 operand split exactly into three bf16 pieces (conv_split.hpp has
+// the arithmetic and its error analysis): six v_mfma_f32_32x32x16_bf16 per 16 channels and tap instead of eight fp32 ones
+// of twice the length - the phases of a 128-channel pair are matrix bound INSIDE the workgroup (1536 fp32 MFMAs on one CU).
+//   input   all C channels of rows y-dA, y, y+dA travel HBM -> registers -> three bf16 pieces -> LDS as
+//           [piece][16-channel chunk][k half][row][pixel] entries of 16 bytes (8 channels = one lane's B operand)
+//   weights pre-split on the host, [tap][chunk][cout block][piece][lane][8 bf16]: three 16-byte loads per tap and chunk
+//           straight from L2 into registers, a ring of chunks ahead
+//   mid     relu(acc + bA) is split in registers and written to LDS in the same entry layout (a lane holds channels
+//           4h..4h+3 of four 8-channel groups of its pixel: one 8-byte store per group and piece), zero halo of dB
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void pair_split3(float x, unsigned &p0, unsigned &p1, unsigned &p2) {
+    p0 = (__float_as_uint(x) + 0x8000u) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(p0);
+    p1 = (__float_as_uint(r1) + 0x8000u) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(p1);
+    p2 = __float_as_uint(r2) + 0x8000u;
+}
+__device__ __forceinline__ unsigned pair_pack(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
+
+struct PairSplitArgs {
+    const float *x, *bA, *bB, *scale, *shift, *res;
+    const unsigned char *wA, *wB;   // split packed weights
+    float *y;
+    int B, C, H, W, dA, dB, relu_post, CP;
+};
+
+template <int KS, int R>
+__global__ __launch_bounds__(256 * KS) void k_conv1d_pair_split(PairSplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int wid = wid8 & 3, kpart = wid8 >> 2;
+    const int C = a.C, W = a.W, H = a.H, CP = a.CP;
+    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    const int NPG = W >> 5, npg_sh = NPG >> 1;
+    const int pg = wid & (NPG - 1), cg = wid >> npg_sh;
+    const int px = pg * 32 + l31;
+    const bool co_ok = cg * 32 < CP;
+    const int WM = W + 2 * a.dB;
+    const int nchunk = C >> 4, nblk = CP >> 5;
+    // LDS: s_in [3 pieces][nchunk][2][3 rows][W] x 16 B, s_mid [3 pieces][nchunk][2][WM] x 16 B
+    const int in_piece = nchunk * 2 * 3 * W * 16, mid_piece = nchunk * 2 * WM * 16;
+    unsigned char *s_in = smem_raw, *s_mid = smem_raw + 3 * in_piece;
+    float *s_red = reinterpret_cast<float *>(smem_raw);   // [4 waves][16][64] partial accumulators (aliases s_in once it is consumed)
+    const int ch_lo = kpart * (nchunk / KS), ch_hi = kpart == KS - 1 ? nchunk : ch_lo + nchunk / KS;
+    const int nch = ch_hi - ch_lo;   // multiple of R
+
+    // first weight fragments travel while the input is staged
+    u32x4 wr[R][3][3];
+    auto load_w = [&](const unsigned char *wp, int t, int chunk, u32x4 (&dst)[3]) {
+        const unsigned char *p = wp + ((((long)t * nchunk + chunk) * nblk + cg) * 3) * 1024 + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const u32x4 *>(p + pl * 1024);
+    };
+    if (co_ok) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) load_w(a.wA, t, ch_lo + i, wr[i][t]);
+    }
+    // ---- stage the three input rows of every channel: task = (chunk, row, pixel), 16 channel loads each
+    {
+        const int ntask = nchunk * 3 * W;
+        const long plane = (long)H * W;
+        const float *xn = a.x + (long)n * C * plane;
+        constexpr int NTK = 3;   // tasks per thread: at most 768 tasks (32 channels x 128 pixels) over 256 threads
+        float v[NTK][16];
+        int task[NTK];
+        bool ok[NTK];
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            task[u] = tid + u * 256 * KS;
+            const int tk = min(task[u], ntask - 1);
+            const int pxs = tk & (W - 1), q = tk >> (5 + npg_sh), c = q / 3, t = q - 3 * c;
+            const int yy = y + (t - 1) * a.dA;
+            ok[u] = task[u] < ntask && yy >= 0 && yy < H;
+            const float *src = xn + ((long)c * 16 * H + (ok[u] ? yy : 0)) * W + pxs;
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch) v[u][ch] = src[ch * plane];
+        }
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            if (task[u] < ntask) {
+                const int pxs = task[u] & (W - 1), q = task[u] >> (5 + npg_sh), c = q / 3, t = q - 3 * c;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 q3[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = ok[u] ? v[u][8 * h + 2 * e] : 0.f, x1 = ok[u] ? v[u][8 * h + 2 * e + 1] : 0.f;
+                        unsigned e0, e1, e2, o0, o1, o2;
+                        pair_split3(x0, e0, e1, e2);
+                        pair_split3(x1, o0, o1, o2);
+                        q3[0][e] = pair_pack(e0, o0); q3[1][e] = pair_pack(e1, o1); q3[2][e] = pair_pack(e2, o2);
+                    }
+                    const int entry = ((c * 2 + h) * 3 + t) * W + pxs;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(s_in + pl * in_piece + entry * 16) = q3[pl];
+                }
+            }
+        }
+    }
+    float bAv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bAv[r] = a.bA[min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1)];
+    // zero halo of the intermediate row (all pieces, all 8-channel groups)
+    {
+        const int ngrp = nchunk * 2, nh = 2 * a.dB;
+        for (int i = tid; i < 3 * ngrp * nh; i += 256 * KS) {
+            const int j = i % nh, g = (i / nh) % ngrp, pl = i / (nh * ngrp);
+            *reinterpret_cast<u32x4 *>(s_mid + pl * mid_piece + (g * WM + (j < a.dB ? j : W + j)) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A: vertical taps
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mma6 = [&](const u32x4 (&w)[3], const u32x4 (&b)[3]) {
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[PA[k]]), __builtin_bit_cast(bf16x8, b[PB[k]]), acc, 0, 0, 0);
+    };
+    if (co_ok) {
+        for (int j0 = 0; j0 < nch; j0 += R) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int ch = ch_lo + j0 + i;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    u32x4 b[3];
+                    const int entry = ((ch * 2 + half) * 3 + t) * W + px;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(s_in + pl * in_piece + entry * 16);
+                    mma6(wr[i][t], b);
+                }
+                // refill the slot: the next phase-A chunk that maps to it, else the phase-B chunk of the same slot
+                const int nxt = j0 + i + R;
+                const unsigned char *wsrc = nxt < nch ? a.wA : a.wB;
+                const int nch_src = nxt < nch ? ch_lo + nxt : ch_lo + nxt - nch;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) load_w(wsrc, t, nch_src, wr[i][t]);
+            }
+        }
+    }
+    if constexpr (KS == 2) {   // combine the two halves of K (s_in is consumed)
+        __syncthreads();
+        if (kpart == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kpart == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+        }
+    }
+    if (co_ok && kpart == 0) {
+        // this lane: pixel px, channels cg*32 + 8*g8 + 4*half + e (g8 = 0..3, e = 0..3) = acc[4*g8 + e]
+#pragma unroll
+        for (int g8 = 0; g8 < 4; ++g8) {
+            unsigned p[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float vv = acc[4 * g8 + e] + bAv[4 * g8 + e];
+                pair_split3(vv > 0.f ? vv : 0.f, p[0][e], p[1][e], p[2][e]);
+            }
+            const int grp = cg * 4 + g8;   // 8-channel group = chunk * 2 + k half
+            if (grp * 8 < C) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<u32x2 *>(s_mid + pl * mid_piece + (grp * WM + a.dB + px) * 16 + half * 8) =
+                        u32x2{pair_pack(p[pl][0], p[pl][1]), pair_pack(p[pl][2], p[pl][3])};
+            }
+        }
+    }
+    __syncthreads();
+
+    // residual and epilogue vectors: all loads in flight together, travelling during phase B
+    const long plane = (long)H * W;
+    const long base = (long)n * C * plane + (long)y * W + px;
+    float rv[16], bBv[16], sv[16], tv[16];
+    const float *res_p = a.res ? a.res : a.x, *scale_p = a.scale ? a.scale : a.bB, *shift_p = a.scale ? a.shift : a.bB;
+    auto load_epilogue = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
+            rv[r] = res_p[base + co * plane];
+            bBv[r] = a.bB[co];
+            sv[r] = scale_p[co];
+            tv[r] = shift_p[co];
+        }
+    };
+    if constexpr (R <= 2) load_epilogue();   // a shallow weight ring leaves registers for them during phase B
+    // ---- phase B: horizontal taps over the intermediate
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (co_ok) {
+        for (int j0 = 0; j0 < nch; j0 += R) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int ch = ch_lo + j0 + i;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    u32x4 b[3];
+                    const int entry = (ch * 2 + half) * WM + px + t * a.dB;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(s_mid + pl * mid_piece + entry * 16);
+                    mma6(wr[i][t], b);
+                }
+                if (j0 + i + R < nch) {   // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) load_w(a.wB, t, ch + R, wr[i][t]);
+                }
+            }
+        }
+    }
+    if constexpr (KS == 2) {
+        if (kpart == 1) {   // s_red aliases s_in, which nobody reads in phase B
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kpart == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+    }
+    if (!co_ok) return;
+    if constexpr (R > 2) {
+        asm volatile("" ::: "memory");   // deep weight ring: keep these loads down here
+        load_epilogue();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] + bBv[r];
+        if (a.scale) v = fmaf(v, sv[r], tv[r]);
+        if (a.res) v += rv[r];
+        if (a.relu_post) v = v > 0.f ? v : 0.f;
+        if (co < C) a.y[base + co * plane] = v;
+    }
+}
+
+// fp32 floats of the exact packing of one convolution of a pair
+inline size_t pair_f32_floats(int channels) {
+    const int CP = (channels + 31) / 32 * 32;
+    return (size_t)3 * (channels / 16) * 2 * CP * 8;
+}
+inline size_t pair_split_bytes(int channels) {
+    const int CP = (channels + 31) / 32 * 32;
+    return (size_t)3 * (channels / 16) * (CP / 32) * 3 * 1024;
+}
+inline bool pair_use_split() {
+    static const bool v = [] {
+        const char *e = getenv("LAV_CONV_PRECISION");
+        return !(e && (!strcmp(e, "f32") || !strcmp(e, "fp32")));
+    }();
+    return v;
+}
 }  // namespace
 
 extern "C" size_t lav_conv1d_pair_packed_weight_floats(int channels) {
     if (channels < 16 || channels % 16) return 0;
-    const int CP = (channels + 31) / 32 * 32;
-    return (size_t)3 * (channels / 16) * 2 * CP * 8;
+    // the exact fp32 packing followed by the three-piece bf16 packing
+    return pair_f32_floats(channels) + pair_split_bytes(channels) / 4;
 }
 
 extern "C" int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_packed) {
@@ -243,10 +509,34 @@ extern "C" int lav_conv1d_pair_pack_weights(int channels, const float *h_weight,
                         const int k = ch * 16 + 2 * cp + half;
                         h_packed[((((size_t)t * nchunk + ch) * 2 + half) * CP + co) * 8 + cp] = co < C ? h_weight[((size_t)co * C + k) * 3 + t] : 0.f;
                     }
+    // split packing: [tap][chunk][cout block][piece][lane = khalf*32 + cout%32][8 channels] bf16
+    unsigned short *o = reinterpret_cast<unsigned short *>(h_packed + pair_f32_floats(C));
+    auto bf = [](float x, float &rest) {
+        unsigned u;
+        memcpy(&u, &x, 4);
+        u = (u + 0x8000u) & 0xffff0000u;
+        float b;
+        memcpy(&b, &u, 4);
+        rest = x - b;
+        return (unsigned short)(u >> 16);
+    };
+    for (int t = 0; t < 3; ++t)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int blk = 0; blk < CP / 32; ++blk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = blk * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + e;
+                        const float w = co < C ? h_weight[((size_t)co * C + ci) * 3 + t] : 0.f;
+                        float r1, r2, r3;
+                        const unsigned short p0 = bf(w, r1), p1 = bf(r1, r2), p2 = bf(r2, r3);
+                        const size_t frag = ((((size_t)t * nchunk + ch) * (CP / 32) + blk) * 3) * 512;
+                        o[frag + lane * 8 + e] = p0; o[frag + 512 + lane * 8 + e] = p1; o[frag + 1024 + lane * 8 + e] = p2;
+                    }
     return LAV_OK;
 }
 
 extern "C" size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b) {
+    if (pair_use_split()) return (size_t)channels * w * 18 + (size_t)channels * (w + 2 * d_b) * 6;   // 16-byte entries of 8 channels, 3 pieces
     return ((size_t)channels * 3 * w + (size_t)channels * (w + 2 * d_b)) * sizeof(float);
 }
 
@@ -265,6 +555,28 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
     if (!zero_page) {
         LAV_HIP(hipMalloc(reinterpret_cast<void **>(&zero_page), 256));
         LAV_HIP(hipMemset(zero_page, 0, 256));
+    }
+    if (pair_use_split()) {
+        PairSplitArgs sa;
+        sa.x = x; sa.bA = bias_a; sa.bB = bias_b; sa.scale = scale; sa.shift = shift; sa.res = residual; sa.y = y;
+        sa.wA = reinterpret_cast<const unsigned char *>(wa_packed + pair_f32_floats(channels));
+        sa.wB = reinterpret_cast<const unsigned char *>(wb_packed + pair_f32_floats(channels));
+        sa.B = batch; sa.C = channels; sa.H = h; sa.W = w; sa.dA = d_a; sa.dB = d_b; sa.relu_post = relu_post;
+        sa.CP = (channels + 31) / 32 * 32;
+        hipStream_t sst = static_cast<hipStream_t>(stream);
+        const int ks2 = channels >= 64 ? 2 : 1;
+        const int nch2 = channels / 16 / ks2;
+        const int ring2 = nch2 % 4 == 0 ? 4 : nch2 % 2 == 0 ? 2 : 1;
+        const int tok2 = timer_begin("conv1d_pair", sst);
+#define LAV_PAIRS_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
+        static bool attr = false; \
+        if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_split<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_conv1d_pair_split<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, sst, sa); }
+        LAV_PAIRS_CASE(1, 1) LAV_PAIRS_CASE(1, 2) LAV_PAIRS_CASE(1, 4) LAV_PAIRS_CASE(2, 1) LAV_PAIRS_CASE(2, 2) LAV_PAIRS_CASE(2, 4)
+#undef LAV_PAIRS_CASE
+        timer_end(tok2, sst);
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
     }
     PairArgs a;
     a.x = x; a.wA = wa_packed; a.bA = bias_a; a.wB = wb_packed; a.bB = bias_b; a.scale = scale; a.shift = shift; a.res = residual;

@@ -80,7 +80,7 @@ with torch.no_grad():
         nch = (d.cin + 15) // 16
         print(f"{'T' if d.transposed else 'C'} {d.cin:4d}->{d.cout:4d} k{d.kh}x{d.kw} s{d.stride} d{d.dil_h},{d.dil_w} in {shp[0]}x{shp[2]}x{shp[3]:4d} "
               f"{us:7.1f} us {flops / us / 1e6:6.1f} TF/s  {info[0]}x{info[1]} rb={info[2]} lds={info[5] // 1024:3d}K ks={info[6]} tg={info[7]} cps={info[8]} "
-              f"stages={-(-(-(-nch // info[6])) // info[8])}")
+              f"stages={-(-(-(-nch // max(info[6], 1))) // max(info[8], 1))}")
         tot += us
     print(f"total {tot:.0f} us over {len(records)} conv launches")
     if pairs:
