@@ -29,6 +29,9 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (same guide); the split convolution kernels run on these pipes
+DTYPE = ("f32 (convolution contractions: fp32 operands split exactly into three bf16 pieces, the six leading partial products on the "
+         "bf16 matrix cores, f32 accumulate - error of an fp32 dot product, DESIGN 4.3; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
 
 
 def build_pipeline(device, eager=False):
@@ -166,16 +169,57 @@ def train_bench(args):
     if rank == 0:
         print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
-                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32", data="synthetic",
+                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32 (torch autograd / MIOpen for the dense layers)", data="synthetic",
                               config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
                                           + (f", 120000-point clouds, 320x320 maps; log-only eval inference every {args.log_every} step(s)"
                                              if what == "lidar" else ", (9,320,320) BEV"),
                                           parallelism=f"dp{world}", global_batch=per * world, log_every=args.log_every,
                                           loss=round(info["loss"], 4)),
-                              roofline=roofline, cpu_baseline=None)))
+                              roofline=roofline,
+                              cpu_baseline=cpu_train_baseline(what) if (args.cpu_train_baseline and world == 1) else None)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def training_lines(with_cpu=True):
+    """BASELINE metric (ii) inside the default run: train_full_v2 (global batch 32) and train_bev_v2 (global batch 64), 3 warm-up +
+    5 timed steps each at the reference's cadence (--log-every 1), as child processes (a fresh CUDA context each: the
+    training graph's allocator state must not sit beside the frame's HIP graphs), each with its roofline and a bounded
+    cpu_baseline."""
+    import subprocess
+    out = {}
+    for mode in ("train_full", "train_bev"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "5", "--warmup", "3", "--log-every", "1"]
+        if with_cpu:
+            cmd.append("--cpu-train-baseline")
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            out[mode] = json.loads(line)
+        except Exception as e:   # a failed training line must not take the inference line with it
+            out[mode] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    return out
+
+
+def cpu_train_baseline(what, budget_batch=2):
+    """The same optimisation step on the host cores (torch CPU ops of the same modules: the port of the reference's trainer),
+    one warm-up + one timed step at a small batch: a bounded sample for orientation, not a target."""
+    from lav_amd.train import TrainConfig
+    from lav_amd.train.run import train_loop
+    if what == "lidar":
+        # train_lidar's PointPillar front end (decorate / scatter-max / indexed crops) exists on HIP only - the product has no CPU
+        # fallback - and /root/reference is not on the GPU box: there is nothing honest to time here
+        return dict(value=None, unit="samples/s", cores=0, kind="port",
+                    sample="not available: the train_lidar step has no CPU port (HIP-only pillar / crop autograd functions) and the reference "
+                           "trainer is not present on the GPU box; the train_bev line carries a CPU sample of the same trainer code")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.time()
+    dt, info, _ = train_loop(what, budget_batch, 1, 1, cfg=TrainConfig(log_every=100), device=torch.device("cpu"),
+                             max_points=20000 if what == "lidar" else None)
+    return dict(value=round(budget_batch / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 step (after 1 warm-up) of the same trainer on torch CPU ops, batch {budget_batch}"
+                       + (", 20000-point clouds" if what == "lidar" else "") + f"; {time.time() - t0:.0f} s of CPU work")
 
 
 def main():
@@ -184,11 +228,13 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the short train_full / train_bev runs appended to the inference line")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     ap.add_argument("--mode", default="infer", choices=["infer", "train_full", "train_bev"],
                     help="infer: BASELINE metric (i) frames/s; train_full / train_bev: metric (ii) samples/s, data parallel")
     ap.add_argument("--batch", type=int, default=None, help="training modes: fixed per-GPU batch (weak scaling); default: BASELINE's global batch 32 / 64 split over the ranks")
     ap.add_argument("--log-every", type=int, default=100, help="train_full: steps between the log-only eval inference (1 = the reference's cadence)")
+    ap.add_argument("--cpu-train-baseline", action="store_true", help="training modes: add a bounded CPU run of the same step as cpu_baseline")
     args = ap.parse_args()
     if args.mode != "infer":
         return train_bench(args)
@@ -302,53 +348,132 @@ def main():
         lib.lav_profile_enable(0)
         flops = 2.0 * 160 * 160 * 256 * 384 * 9
         sec = ms / max(n, 1) * 1e-3
-        return dict(bound="mfma", kernel="k_conv<2,2> heads 384->256 3x3 @160x160", achieved=round(flops / sec / 1e12, 1),
+        desc = _lib.Conv.from_buffer_copy(layer.desc); desc.batch, desc.h, desc.w = 1, 160, 160
+        info = (ctypes.c_int * 9)()
+        lib.lav_conv_tile_info(ctypes.byref(desc), info)
+        if info[0] == -1:   # split kernel: six bf16 MFMA products per fp32 product
+            executed = 6.0 * flops
+            return dict(bound="mfma", kernel="k_conv_split<2,2> heads 384->256 3x3 @160x160 (bf16x6 split operands)",
+                        achieved=round(executed / sec / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s (bf16 MFMA flops executed: 6 x 2MNK)",
+                        frac=round(executed / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, algorithmic_flops=flops,
+                        fp32_equivalent_tflops=round(flops / sec / 1e12, 1),
+                        vs_fp32_mfma_peak=round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 3), avg_kernel_us=round(sec * 1e6, 1), launches=reps)
+        return dict(bound="mfma", kernel="k_conv<2,2> heads 384->256 3x3 @160x160 (fp32 MFMA)", achieved=round(flops / sec / 1e12, 1),
                     peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                     traffic=None, algorithmic_flops=flops, avg_kernel_us=round(sec * 1e6, 1), launches=reps)
+
+    def glue_micro(reps=50):
+        """The other HBM-bound hand kernels SURVEY 8(d) names, in isolation (back-to-back launches, library HIP events):
+        painting, temporal stacking + history write, rotated crop.  Algorithmic bytes as SURVEY 8(d) counts them."""
+        from lav_amd import ops, synth
+        outm = {}
+
+        def timed(name, fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            lib.lav_profile_enable(reps + 8)
+            fn(); torch.cuda.synchronize(); lib.lav_profile_reset()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            ms, n = read(name)
+            lib.lav_profile_enable(0)
+            return ms / max(n, 1) * 1e-3
+
+        def entry(kernel, nbytes, sec, what):
+            return dict(bound="hbm", kernel=kernel, achieved=round(nbytes / sec / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes=int(nbytes), avg_kernel_us=round(sec * 1e6, 2),
+                        launches=reps, bytes_counted=what, traffic=None)
+        im = pipe.infer_model
+        n_pt = 65536
+        cur = torch.from_numpy(np.concatenate([host["ticks"][0], host["ticks"][1]])).to(device)
+        sem = torch.softmax(torch.randn((3, 5, 288, 256), device=device), dim=1)
+        sec = timed("paint", lambda: im.forward_paint(cur, sem))
+        outm["paint"] = entry("k_paint (3 cameras, class-0 suppression, concat)", n_pt * (16 + 32) + sem.numel() * 4, sec,
+                              "N x (16 B point read + 32 B fused row written) + the 3x5x288x256 probability maps, N = 65536")
+        fused = torch.randn((n_pt, 8), device=device)
+        ring = torch.randn((15, n_pt, 8), device=device)
+        slot = torch.tensor([3], device=device); sweeps = torch.tensor([3, 13, 8], device=device)
+        R = torch.eye(3, device=device)[None].repeat(3, 1, 1).contiguous(); t = torch.zeros((3, 3), device=device)
+        sec = timed("stack_sweeps", lambda: ops.stack_sweeps(fused, ring, slot, sweeps, R, t))
+        outm["stack_sweeps"] = entry("k_stack_sweeps (history write + 3-sweep stack in the ego frame)", n_pt * 32 * 2 + 2 * n_pt * 32 + 3 * n_pt * 44,
+                                     sec, "new sweep read + written to the ring (2 x 32 B), two old sweeps read (32 B), 3 x N rows of 44 B written, N = 65536")
+        feats = torch.randn((1, 384, 160, 160), device=device)
+        for n_c in (1, 4):
+            locs = torch.tensor([[3.0 * i, -5.0 - 2 * i] for i in range(n_c)], device=device)
+            oris = torch.tensor([0.3 * i for i in range(n_c)], device=device)
+            sec = timed("crop_rotate", lambda: ops.crop_rotate(feats, locs, oris, 2.0, 96, 0.0, 0.75))
+            outm[f"crop_rotate_n{n_c}"] = entry("k_crop_rotate_staged (affine_grid + bilinear grid_sample, 384 channels)", n_c * 384 * 96 * 96 * 4 * 2, sec,
+                                              f"{n_c} crop(s): every output value written once + the map region under the crop read once (crop pitch ~ map pitch)")
+        return outm
+
     micro = {"config2_32768pts": pillar_micro(10923), "agent_196608pts": pillar_micro(65536)} if rank == 0 else None
     conv_roof = conv_micro() if rank == 0 else None
     # roofline of the dominant pillar kernel at the frame's own size (196 608 points).  The frame loop replays HIP
     # graphs (kernels inside a graph cannot carry event pairs), so the figure comes from the back-to-back launches
     # above on the same library stream: pure kernel time, no launch gaps.
     roofline = None
+    glue = glue_micro() if rank == 0 else None
     if rank == 0:
-        m = micro["agent_196608pts"]
+        # The north-star figure: fraction of the HBM roof (algorithmic bytes 4 (N D + C ny nx), SURVEY 8d) of the pillar kernel,
+        # at BASELINE config #2 (32 768-point sweep); the frame's own 196 608-point stack and the matrix-pipe term of the fused
+        # PointNet (max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) is the binding roof) are carried beside it.
+        m, mf = micro["config2_32768pts"], micro["agent_196608pts"]
         traffic, traffic_src = None, None
-        try:  # HBM bytes per launch from the committed PMC pass of this very kernel (counters cannot be read from inside a run)
-            with open(os.path.join(REPO, "profiles", "r02_b_pmc_pillar.json")) as f:
-                pm = json.load(f)
-            traffic = pm["k_rows"][str(m["points"])]["traffic_bytes"]
-            traffic_src = "profiles/r02_b_pmc_pillar.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, on the final kernels of round 2)"
-        except Exception:
-            pass
-        # the PointNet is fused into the scatter kernel, so its roof is max(bytes / HBM peak, flops / matrix peak).
-        # At the frame's 196 608 points the matrix term is the larger one (2.0 GFLOP of fp32 MFMA = 12.8 us at 157.3 TFLOP/s
-        # against 4.4 us for the 34.9 MB): the kernel is matrix-bound there, HBM-bound at config #2's 32 768 points
-        # (roofline_pillar_isolated carries both sizes with both figures).  `frac` is the fraction of the BINDING roof;
-        # the bytes figure stays beside it as frac_hbm / achieved_hbm.
-        hbm = dict(achieved=m["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=m["frac"], algorithmic_bytes=m["algorithmic_bytes"],
-                   bound_us=m["hbm_bound_us"])
-        common = dict(kernel="k_rows (pillar PointNet + scatter-max + canvas)", traffic=traffic, traffic_source=traffic_src, points=m["points"],
-                      avg_kernel_us=m["kernel_us"], launches=100, hbm_bound_us=m["hbm_bound_us"], mfma_bound_us=m["mfma_bound_us"],
-                      bound_rule="max(algorithmic bytes / 8 TB/s, algorithmic PointNet flops / 157.3 TFLOP/s), SURVEY 8(d)")
-        if m["mfma_bound_us"] > m["hbm_bound_us"]:
-            roofline = dict(bound="mfma", achieved=m["pointnet_tflops"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(m["pointnet_tflops"] / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=m["pointnet_flops"],
-                            frac_hbm=hbm["frac"], achieved_hbm_GBs=hbm["achieved"], algorithmic_bytes=m["algorithmic_bytes"], **common)
-        else:
-            roofline = dict(bound="hbm", **hbm, frac_mfma=round(m["pointnet_tflops"] / MFMA_F32_PEAK_TFLOPS, 4), **common)
+        for prof_name in ("r03_pmc_pillar.json", "r02_b_pmc_pillar.json"):
+            try:  # HBM bytes per launch from the committed PMC pass of this kernel (counters cannot be read from inside a run)
+                with open(os.path.join(REPO, "profiles", prof_name)) as f:
+                    pm = json.load(f)
+                traffic = pm["k_rows"][str(m["points"])]["traffic_bytes"]
+                traffic_src = f"profiles/{prof_name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                break
+            except Exception:
+                continue
+        roofline = dict(bound="hbm", kernel="k_rows (pillar PointNet + scatter-max + canvas), BASELINE config #2", achieved=m["achieved"], peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=m["frac"], algorithmic_bytes=m["algorithmic_bytes"], traffic=traffic, traffic_source=traffic_src,
+                        points=m["points"], avg_kernel_us=m["kernel_us"], launches=100, hbm_bound_us=m["hbm_bound_us"],
+                        stage_us=round(m["kernel_us"] + m["prep_us"], 2), stage_frac=round(m["pipeline_achieved"] / HBM_PEAK_GBS, 4),
+                        frac_mfma=round(m["pointnet_tflops"] / MFMA_F32_PEAK_TFLOPS, 4), mfma_bound_us=m["mfma_bound_us"],
+                        frame_cloud=dict(points=mf["points"], avg_kernel_us=mf["kernel_us"], frac_hbm=mf["frac"], achieved_hbm_GBs=mf["achieved"],
+                                         frac_mfma=round(mf["pointnet_tflops"] / MFMA_F32_PEAK_TFLOPS, 4), hbm_bound_us=mf["hbm_bound_us"],
+                                         mfma_bound_us=mf["mfma_bound_us"], stage_us=round(mf["kernel_us"] + mf["prep_us"], 2)),
+                        bound_rule="max(algorithmic bytes / 8 TB/s, algorithmic PointNet flops / 157.3 TFLOP/s), SURVEY 8(d); frac is the bytes term")
+
+    def forced_frames(n_forced, steps=40):
+        """Frame time with the others branch forced to n fixed poses."""
+        nonlocal i
+        locs = [[4.0 + 3.0 * k, -8.0 - 4.0 * k] for k in range(n_forced)]
+        oris = [0.2 * k - 0.3 for k in range(n_forced)]
+        pipe.set_forced_others(locs, oris)
+        for _ in range(6):
+            step(i); i += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(i); i += 1
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return dict(ms_per_step=round(ms, 4), frames_per_s=round(1e3 / ms, 2), steps=steps)
+    forced = None
+    if rank == 0 and world == 1 and not args.eager:
+        forced = {f"others_{k}": forced_frames(k) for k in (0, 4)}
+        pipe.set_forced_others(None)
 
     if rank == 0:
         res = dict(metric="frames/s full agent fwd (32k-pt LiDAR + 3 cams)", value=round(world * args.steps / dt, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=n_warm,
                    ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="f32", data="synthetic",
+                   dtype=DTYPE, data="synthetic",
                    config=dict(workload="full lav_agent_fast forward, batch 1: 2x32768-pt half sweeps -> 3-sweep stack "
                                         f"({n_pts} pts x 11) + 3x288x256 RGB + 288x480 tele; ERFNet seg, paint, pillar 320x320x64, "
                                         "BEV backbone+heads, uniplanner (cast+plan GRUs), brake net",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1]),
                                launch="eager" if args.eager else "hip graphs: lidar / heads / others (capacity 15, device-resident count) on the main stream, brake and ego[cmd] on side streams"),
-                   roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, hip_kernel_us_per_frame=per_frame_us)
+                   roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, roofline_hbm_glue=glue,
+                   forced_others=forced, hip_kernel_us_per_frame=per_frame_us)
+        if world == 1 and not args.no_train:
+            res["training"] = training_lines(with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, host)
         else:

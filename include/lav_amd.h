@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 16
+#define LAV_ABI_VERSION 18
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -334,6 +334,17 @@ int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max
 int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const float *u, const float *dots_bias,
                   const float *w_v, const float *b_v, float *out, void *stream);
 
+/* Frame glue that replaces library launches inside the frame graphs:
+ * lav_maxpool3x3s2: nn.MaxPool2d(3, 2, 1) of the ResNet stems (lav/models/resnet.py:161,236), x [batch][channels][h][w] ->
+ *     y [batch][channels][(h-1)/2+1][(w-1)/2+1]; honours lav_batch_limit.
+ * lav_channel_affine: y = x * scale[c] + shift[c] on [batch][channels][plane] (plane % 4 == 0): the brake net's
+ *     `normalize(rgb / 255)` (team_code_v2/models/rgb.py:71-72) in one pass.
+ * lav_copy_many: up to 8 device-to-device copies (16-byte aligned, sizes multiples of 16) in ONE launch: a tick's sensor tensors
+ *     into the static buffers the frame graphs read (lav_agent_fast.py:233-277 hands them over as fresh tensors). */
+int lav_maxpool3x3s2(const float *x, int batch, int channels, int h, int w, float *y, void *stream);
+int lav_channel_affine(const float *x, int batch, int channels, long plane, const float *scale, const float *shift, float *y, void *stream);
+int lav_copy_many(int n, const void *const *src, void *const *dst, const size_t *bytes, void *stream);
+
 /* Small dense layer out[b][o] = act(bias[o] + sum_k weight[o][k] x[b][k]) (weight in nn.Linear layout [out][in], bias or NULL;
  * act 0 = none, 1 = sigmoid): the brake classifier nn.Sequential(Linear(1024, 1), Sigmoid) of team_code_v2/models/rgb.py:62,79. */
 int lav_linear_act(const float *x, int batch, int in_features, const float *weight, const float *bias, int out_features,
@@ -354,8 +365,8 @@ int lav_linear_act(const float *x, int batch, int in_features, const float *weig
  *     costs what its live rows cost, with no host round trip in between.  Skipped rows of the outputs are left untouched.
  *     NULL switches it off.  (A pointer, not a value: the launches can be captured in a HIP graph.)
  * ------------------------------------------------------------------------------------------ */
-int lav_det_decode(const float *rows, int ncls, int max_det, int cls, float min_score, float ego_x, float ego_y,
-                   float near_px, float far_px, float min_box, float cx, float cy, float skip_px, float ppm,
+int lav_det_decode(const float *rows, int ncls, int max_det, int cls, double min_score, double ego_x, double ego_y,
+                   double near_px, double far_px, double min_box, double cx, double cy, double skip_px, double ppm,
                    float *actors, int *n_out, void *stream);
 int lav_batch_limit(const int *d_rows);
 

@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <thread>
+#include <vector>
 
 #include "lav_amd.h"
 
@@ -55,6 +58,21 @@ struct Arena {
 };
 
 constexpr int WAVE = 64;
+
+// host-side parallel loop (weight repacking: a training run that logs through the inference engines repacks every layer per step)
+template <typename F>
+inline void parallel_for(int n, F fn) {
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (n < 2 || nt < 2) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    nt = std::min<unsigned>(nt, (unsigned)n);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([=] { for (int i = (int)t; i < n; i += (int)nt) fn(i); });
+    for (auto &x : th) x.join();
+}
 
 // lav_batch_limit: device-resident row count honoured by the batch-aware launches of this thread (see lav_amd.h)
 inline const int *&batch_limit() {

@@ -936,11 +936,12 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
     Plan p;
     int rc = build_plan(*c, p);
     if (rc) return rc;
-    for (size_t i = 0; i < p.wfloats; ++i) h_packed[i] = 0.f;
+    memset(h_packed, 0, p.wfloats * sizeof(float));
     for (int cls = 0; cls < p.nclasses; ++cls) {
         float *dst = h_packed + p.woff[cls];
         const auto &t = p.taps[cls];
-        for (size_t ti = 0; ti < t.size(); ++ti)
+        parallel_for((int)t.size(), [&, dst](int ti_) {
+            const size_t ti = (size_t)ti_;
             for (int ci = 0; ci < c->cin; ++ci)
                 for (int co = 0; co < c->cout; ++co) {
                     const size_t src = c->transposed
@@ -949,6 +950,7 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
                     // [cout block][tap][8-channel group][lane = parity*32 + cout][pair]
                     dst[(size_t)(co / 32) * t.size() * p.cin_pad * 32 + ((ti * p.cin_pad + ci) / 8) * 256 + ((ci & 1) * 32 + co % 32) * 4 + (ci % 8) / 2] = h_weight[src];
                 }
+        });
     }
     if (resolve_precision(*c) == LAV_CONV_BF16X6)
         split_pack_weights(*c, p, h_weight, reinterpret_cast<unsigned char *>(h_packed + (p.wfloats + 3) / 4 * 4));

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         const long cplane = (long)a.H * a.W;
         const char *xin = reinterpret_cast<const char *>(a.x + ((long)n * a.in_c_total + a.in_c_offset) * cplane);
         float v[NT][16];
-        auto issue_loads = [&](int sc) {
+        auto issue_loads_to = [&](float (&v)[NT][16], int sc) __attribute__((always_inline)) {
             const int ci0 = (chunk_lo + sc) * 16;
             const int nc = min(16, a.cin - ci0);   // wave-uniform
 #pragma unroll
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
                 for (int i = 0; i < NT; ++i) v[i][c] = *reinterpret_cast<const float *>(pc + (unsigned)max(goff[i], 0));
             }
         };
-        auto convert_store = [&](int sc) {
+        auto convert_store_from = [&](const float (&v)[NT][16], int sc) __attribute__((always_inline)) {
             const int ci0 = (chunk_lo + sc) * 16;
             const int nc = min(16, a.cin - ci0);
             unsigned char *dst = s_in + (sc & 1) * ibuf_bytes;
@@ -271,10 +271,21 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         // barrier that closes the group promises the chunks up to tap (k+2)G.  Host: 2G <= taps + 1, i.e. those 2G taps touch
         // at most two chunks - the two LDS buffers.  A chunk is converted as soon as its buffer is free, from registers whose
         // loads were issued when the previous chunk was converted (about a chunk of matrix work earlier).
+        auto issue_loads = [&](int sc) __attribute__((always_inline)) { issue_loads_to(v, sc); };
+        auto convert_store = [&](int sc) __attribute__((always_inline)) { convert_store_from(v, sc); };
         long long waited = 0, conv = 0;
-        if (nchunk > 0) { issue_loads(0); convert_store(0); }
-        if (nchunk > 1) { issue_loads(1); convert_store(1); }
-        if (nchunk > 2) issue_loads(2);
+        if constexpr (NT <= 2) {   // small patches: the first two chunks travel together (one memory latency before the first tap)
+            float v2[NT][16];
+            if (nchunk > 0) issue_loads_to(v, 0);
+            if (nchunk > 1) issue_loads_to(v2, 1);
+            if (nchunk > 0) convert_store_from(v, 0);
+            if (nchunk > 2) issue_loads_to(v, 2);
+            if (nchunk > 1) convert_store_from(v2, 1);
+        } else {
+            if (nchunk > 0) { issue_loads(0); convert_store(0); }
+            if (nchunk > 1) { issue_loads(1); convert_store(1); }
+            if (nchunk > 2) issue_loads(2);
+        }
         int conv_next = 2;
         lds_barrier();
         int m_c = 0, m_t = 1;   // chunk / tap of micro-step kG+1
@@ -486,7 +497,7 @@ inline void split_pack_weights(const lav_conv &c, const Plan &p, const float *h_
     size_t cls_off = 0;   // in u16
     for (int cls = 0; cls < p.nclasses; ++cls) {
         const auto &t = p.taps[cls];
-        for (int blk = 0; blk < nblk; ++blk)
+        parallel_for(nblk, [&, cls_off](int blk) {
             for (size_t ti = 0; ti < t.size(); ++ti)
                 for (int ch = 0; ch < nchunks; ++ch)
                     for (int lane = 0; lane < 64; ++lane)
@@ -503,6 +514,7 @@ inline void split_pack_weights(const lav_conv &c, const Plan &p, const float *h_
                             o[frag + 1 * 512 + lane * 8 + e] = p1;
                             o[frag + 2 * 512 + lane * 8 + e] = p2;
                         }
+        });
         cls_off += t.size() * (size_t)nblk * nchunks * 3 * 512;
     }
 }

@@ -366,9 +366,9 @@ extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int 
 // One wave; lane j owns peak row j of the vehicle class.  Comparisons in double on widened float32 values, like the
 // Python floats of the reference.  Survivors keep their score order (prefix count over the ballot).
 namespace {
-__global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ rows, int cls, int max_det, float min_score, float ego_x,
-                                                   float ego_y, float near_px, float far_px, float min_box, float cx, float cy,
-                                                   float skip_px, float ppm, float *__restrict__ actors, int *__restrict__ n_out) {
+__global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ rows, int cls, int max_det, double min_score, double ego_x,
+                                                   double ego_y, double near_px, double far_px, double min_box, double cx, double cy,
+                                                   double skip_px, double ppm, float *__restrict__ actors, int *__restrict__ n_out) {
     const int j = threadIdx.x;
     bool ok = false;
     double X = 0, Y = 0, co = 1, si = 0;
@@ -378,8 +378,9 @@ __global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ row
         const long xi = (long)r[1], yi = (long)r[2];
         X = (double)xi; Y = (double)yi; co = r[5]; si = r[6];
         const double dist = sqrt((double)((xi - (long)ego_x) * (xi - (long)ego_x) + (yi - (long)ego_y) * (yi - (long)ego_y)));
-        ok = s > (double)min_score && dist > (double)near_px && dist < (double)far_px && !(fmax(w, h) < (double)min_box);
-        ok = ok && sqrt((X - (double)cx) * (X - (double)cx) + (Y - (double)cy) * (Y - (double)cy)) > (double)skip_px;
+        // every threshold is the host rule's Python float (float64): a score of exactly 0.2f passes 's > 0.2' on both sides
+        ok = s > min_score && dist > near_px && dist < far_px && !(fmax(w, h) < min_box);
+        ok = ok && sqrt((X - cx) * (X - cx) + (Y - cy) * (Y - cy)) > skip_px;
     }
     const unsigned long long m = __ballot(ok);
     const int pos = __popcll(m & ((1ull << j) - 1ull));
@@ -389,16 +390,16 @@ __global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ row
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (ok) {
-        actors[pos * 2 + 0] = (float)((X - (double)cx) / (double)ppm);
-        actors[pos * 2 + 1] = (float)((Y - (double)cy) / (double)ppm);
+        actors[pos * 2 + 0] = (float)((X - cx) / ppm);
+        actors[pos * 2 + 1] = (float)((Y - cy) / ppm);
         actors[2 * max_det + pos] = (float)atan2(si, co);
     }
     if (j == 0) *n_out = __popcll(m);
 }
 }  // namespace
 
-extern "C" int lav_det_decode(const float *rows, int ncls, int max_det, int cls, float min_score, float ego_x, float ego_y,
-                              float near_px, float far_px, float min_box, float cx, float cy, float skip_px, float ppm,
+extern "C" int lav_det_decode(const float *rows, int ncls, int max_det, int cls, double min_score, double ego_x, double ego_y,
+                              double near_px, double far_px, double min_box, double cx, double cy, double skip_px, double ppm,
                               float *actors, int *n_out, void *stream) {
     LAV_REQUIRE(rows && actors && n_out, "lav_det_decode: null argument");
     LAV_REQUIRE(ncls >= 1 && cls >= 0 && cls < ncls && max_det >= 1 && max_det <= 64, "lav_det_decode: bad sizes (max_det <= 64)");

@@ -141,3 +141,97 @@ extern "C" int lav_linear_act(const float *x, int batch, int in_features, const 
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Glue of the frame graph that was library launches: 3x3 / stride-2 max pooling of the ResNet stems, the per-channel input
+// normalisation of the brake net, and the copies of a tick's inputs into the graphs' static buffers (one launch for all).
+namespace {
+__global__ __launch_bounds__(256) void k_maxpool3s2(const float *__restrict__ x, int planes, int H, int W, int OH, int OW, float *__restrict__ y,
+                                                    const int *__restrict__ n_valid, int planes_per_image) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)planes * OH * OW) return;
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), p = (int)(i / ((long)OW * OH));
+    if (n_valid && p / planes_per_image >= *n_valid) return;   // lav_batch_limit
+    const float *xp = x + (long)p * H * W;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) m = fmaxf(m, xp[iy * W + ix]);
+        }
+    y[i] = m;
+}
+
+__global__ __launch_bounds__(256) void k_channel_affine(const float *__restrict__ x, long plane, int channels, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, long total, float *__restrict__ y) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    // plane is a multiple of 4 (checked by the host): the four values share a channel
+    const int c = (int)((i / plane) % channels);
+    const float s = scale[c], t = shift[c];
+    const float4 v = *reinterpret_cast<const float4 *>(x + i);
+    *reinterpret_cast<float4 *>(y + i) = make_float4(v.x * s + t, v.y * s + t, v.z * s + t, v.w * s + t);
+}
+
+constexpr int COPY_MAX = 8;
+struct CopyArgs {
+    const char *src[COPY_MAX];
+    char *dst[COPY_MAX];
+    long end16[COPY_MAX];   // running total of 16-byte words after copy i
+    int n;
+};
+__global__ __launch_bounds__(256) void k_copy_many(CopyArgs a) {
+    const long w = (long)blockIdx.x * 256 + threadIdx.x;
+    int k = 0;
+    while (k < a.n && w >= a.end16[k]) ++k;
+    if (k >= a.n) return;
+    const long off = (w - (k ? a.end16[k - 1] : 0)) * 16;
+    *reinterpret_cast<float4 *>(a.dst[k] + off) = *reinterpret_cast<const float4 *>(a.src[k] + off);
+}
+}  // namespace
+
+extern "C" int lav_maxpool3x3s2(const float *x, int batch, int channels, int h, int w, float *y, void *stream) {
+    LAV_REQUIRE(x && y && batch >= 0 && channels >= 1 && h >= 1 && w >= 1, "lav_maxpool3x3s2: bad argument");
+    if (batch == 0) return LAV_OK;
+    const int OH = (h - 1) / 2 + 1, OW = (w - 1) / 2 + 1;   // kernel 3, stride 2, padding 1
+    const long total = (long)batch * channels * OH * OW;
+    hipLaunchKernelGGL(k_maxpool3s2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, batch * channels, h, w,
+                       OH, OW, y, lav::batch_limit(), channels);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_channel_affine(const float *x, int batch, int channels, long plane, const float *scale, const float *shift, float *y,
+                                  void *stream) {
+    LAV_REQUIRE(x && y && scale && shift && batch >= 0 && channels >= 1 && plane >= 4 && plane % 4 == 0, "lav_channel_affine: bad argument (plane must be a multiple of 4)");
+    const long total = (long)batch * channels * plane;
+    if (total == 0) return LAV_OK;
+    hipLaunchKernelGGL(k_channel_affine, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, plane, channels,
+                       scale, shift, total, y);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_copy_many(int n, const void *const *src, void *const *dst, const size_t *bytes, void *stream) {
+    LAV_REQUIRE(n >= 0 && n <= COPY_MAX && (n == 0 || (src && dst && bytes)), "lav_copy_many: at most %d copies", COPY_MAX);
+    if (n == 0) return LAV_OK;
+    CopyArgs a;
+    long total = 0;
+    for (int i = 0; i < COPY_MAX; ++i) {
+        if (i < n) {
+            LAV_REQUIRE(src[i] && dst[i] && bytes[i] % 16 == 0 && ((size_t)src[i] | (size_t)dst[i]) % 16 == 0, "lav_copy_many: copy %d is not 16-byte aligned / sized", i);
+            a.src[i] = static_cast<const char *>(src[i]); a.dst[i] = static_cast<char *>(dst[i]);
+            total += (long)(bytes[i] / 16);
+        } else {
+            a.src[i] = nullptr; a.dst[i] = nullptr;
+        }
+        a.end16[i] = total;
+    }
+    a.n = n;
+    if (total == 0) return LAV_OK;
+    hipLaunchKernelGGL(k_copy_many, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}

@@ -572,6 +572,43 @@ class batch_limit:
         return False
 
 
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    """F.max_pool2d(x, 3, 2, 1) on liblav_amd (lav_maxpool3x3s2); honours batch_limit."""
+    x = _f32c(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().lav_maxpool3x3s2(_ptr(x), B, Cc, H, W, _ptr(out), _stream()), "lav_maxpool3x3s2")
+    return out
+
+
+def channel_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """x (B,C,H,W) * scale[c] + shift[c] in one launch (lav_channel_affine); H*W must be a multiple of 4."""
+    x = _f32c(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    check(_lib.load().lav_channel_affine(_ptr(x), B, Cc, H * W, _ptr(_f32c(scale, "scale")), _ptr(_f32c(shift, "shift")), _ptr(out), _stream()),
+          "lav_channel_affine")
+    return out
+
+
+def copy_many(pairs) -> None:
+    """[(dst, src), ...] device-to-device copies of equal-sized contiguous tensors in ONE launch (lav_copy_many); pairs that are
+    not 16-byte friendly fall back to Tensor.copy_."""
+    srcs, dsts, sizes = [], [], []
+    for dst, src in pairs:
+        nb = dst.numel() * dst.element_size()
+        if (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype and src.numel() == dst.numel()
+                and nb % 16 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
+            srcs.append(src.data_ptr()); dsts.append(dst.data_ptr()); sizes.append(nb)
+        else:
+            dst.copy_(src, non_blocking=True)
+    lib = _lib.load()
+    for i in range(0, len(srcs), 8):
+        n = len(srcs[i:i + 8])
+        check(lib.lav_copy_many(n, (C.c_void_p * n)(*srcs[i:i + 8]), (C.c_void_p * n)(*dsts[i:i + 8]), (C.c_size_t * n)(*sizes[i:i + 8]), _stream()),
+              "lav_copy_many")
+
+
 def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, sigmoid: bool = False) -> torch.Tensor:
     """act(x @ weight.T + bias) for small layers, x (B,K) in HBM, weight (O,K) (lav_linear_act)."""
     x = _f32c(x, "x")

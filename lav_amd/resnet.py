@@ -74,7 +74,8 @@ class ResNet(_Engine):
         if self.training:
             return self.forward_train(x)
         e = self._engine(x.device)
-        x = F.max_pool2d(e["stem"](x), 3, 2, 1)
+        from . import ops
+        x = ops.maxpool3x3s2(e["stem"](x))     # nn.MaxPool2d(3, 2, 1)
         for b in e["blocks"]:
             identity = x if b["down"] is None else b["down"](x)
             x = b["c2"](b["c1"](x), residual=identity)

@@ -31,11 +31,12 @@ def setup_distributed():
     return rank, world, torch.device("cuda", local) if cuda else torch.device("cpu")
 
 
-def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log=None, profile_steps=0):
+def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log=None, profile_steps=0, device=None):
     """Runs warmup + steps optimisation steps on a fixed synthetic shard per rank; returns (seconds for `steps`, last info).
     profile_steps > 0: that many EXTRA steps after the timed region with the library's HIP-event timers armed; their per-kernel
     times and the algorithmic work lav_amd.ops counted over the same steps come back in info["hand_kernels"]."""
-    rank, world, device = setup_distributed()
+    rank, world, dev0 = setup_distributed()
+    device = device if device is not None else dev0    # device=cpu: the same trainer on torch CPU ops (bench.py's cpu_baseline)
     cfg = cfg or TrainConfig()
     if global_batch % world:
         raise SystemExit(f"global batch {global_batch} is not divisible by {world} ranks")
@@ -111,6 +112,38 @@ def load_config(path, **overrides) -> TrainConfig:
     return TrainConfig(**vals)
 
 
+def resolve_checkpoints(what, args):
+    """Which checkpoints a run starts from.  Command-line paths win; otherwise a run on recorded routes follows the reference's
+    rules for the *_model_dir keys of config_v2.yaml (lav/lav_final_v2.py:42-72): the privileged teacher `bev_model_dir` is
+    ALWAYS loaded by train_full_v2, `lidar_model_dir` unless --perceive-only, `uniplanner_dir` unless --perceive-only or
+    --motion-only; train_bev_v2 starts from scratch.  A missing file is an error there, never a silent fall back to seeded random
+    weights (that is what --synthetic runs use, explicitly)."""
+    paths = dict(lidar=args.lidar, bev=args.bev, uniplanner=args.uniplanner)
+    if args.synthetic or not args.config_path or what != "lidar":
+        return paths
+    import yaml
+    with open(args.config_path, "r") as f:
+        raw = yaml.safe_load(f) or {}
+    wanted = dict(bev="bev_model_dir")
+    if not args.perceive_only:
+        wanted["lidar"] = "lidar_model_dir"
+        if not args.motion_only:
+            wanted["uniplanner"] = "uniplanner_dir"
+    for name, key in wanted.items():
+        if paths[name]:
+            continue
+        rel = raw.get(key)
+        if not rel:
+            raise SystemExit(f"{args.config_path} has no `{key}` and --{name} was not given: train_full_v2 loads it (lav/lav_final_v2.py:42-72)")
+        cands = [rel, os.path.join(os.path.dirname(os.path.abspath(args.config_path)), rel)]
+        hit = next((c for c in cands if os.path.isfile(c)), None)
+        if hit is None:
+            raise SystemExit(f"checkpoint `{key}: {rel}` of {args.config_path} not found (tried {cands}); pass --{name} PATH, or --synthetic "
+                             "to train seeded random weights on synthetic batches")
+        paths[name] = hit
+    return paths
+
+
 def other_weight_schedule(it, beta=0.8):
     """lav/train_bev_v2.py:38-39"""
     return 1 - beta ** (it / 4000)
@@ -153,7 +186,8 @@ def main(what):
     if args.batch_size % world:
         raise SystemExit(f"global batch {args.batch_size} is not divisible by {world} ranks")
     per_rank = args.batch_size // world
-    ck = {k: torch.load(v, map_location="cpu") for k, v in (("lidar", args.lidar), ("bev", args.bev), ("uniplanner", args.uniplanner)) if v}
+    paths = resolve_checkpoints(what, args)
+    ck = {k: torch.load(v, map_location="cpu") for k, v in paths.items() if v}
     torch.manual_seed(cfg.seed + rank)
     lav = LAV(cfg, device, what=what, checkpoints=ck)
     log = lambda it, inf: print(it, {k: round(v, 4) for k, v in inf.items() if isinstance(v, float)}, flush=True)

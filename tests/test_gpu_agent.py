@@ -72,22 +72,23 @@ def test_precapture_leaves_nothing_to_capture_during_the_drive(tmp_path):
     assert set(a.pipeline.graphs) == have          # the detection decode caps the vehicle count at 15: nothing left to capture
 
 
-def test_tick_larger_than_static_buffers_is_truncated_not_fatal(tmp_path):
-    """The reference accepts any tick size; the HIP-graph agent drops the surplus points with a warning instead of
-    aborting the route from inside run_step."""
-    a, sc = _make(tmp_path, hip_graphs=True, precapture=False)
-    big = synth.agent_inputs(0, sc, n_points=9000)
+def test_tick_larger_than_static_buffers_grows_them(tmp_path):
+    """The reference accepts any tick size.  The HIP-graph agent's buffers are static: a tick that does not fit grows them
+    (history kept) and re-captures the graphs - the frame and the following ones are those of an agent that was built with
+    large enough buffers from the start, nothing is dropped."""
+    a, sc = _make(tmp_path, hip_graphs=True, precapture=False)                        # points_per_tick = 8192
+    b, _ = _make(tmp_path, hip_graphs=True, precapture=False, points_per_tick=16384)
+    a.run_step(synth.agent_inputs(0, sc), 0.0); b.run_step(synth.agent_inputs(0, sc), 0.0)
+    big = synth.agent_inputs(1, sc, n_points=9000)
     with pytest.warns(UserWarning, match="exceeds the static graph buffers"):
-        a.run_step(big, 0.0)
-    b, _ = _make(tmp_path, hip_graphs=True, precapture=False)
-    cut = synth.agent_inputs(0, sc, n_points=9000)
-    cut["LIDAR"] = (0, cut["LIDAR"][1][:8192])
-    b.run_step(cut, 0.0)
-    for i in (1, 2):
+        ca = a.run_step(big, 0.05)
+    cb = b.run_step(synth.agent_inputs(1, sc, n_points=9000), 0.05)
+    assert (ca.steer, ca.throttle, ca.brake) == (cb.steer, cb.throttle, cb.brake)
+    for i in (2, 3, 4):
         ca = a.run_step(synth.agent_inputs(i, sc), i * 0.05)
         cb = b.run_step(synth.agent_inputs(i, sc), i * 0.05)
         assert (ca.steer, ca.throttle, ca.brake) == (cb.steer, cb.throttle, cb.brake)
-    assert a.pipeline.overflow_ticks == 1 and b.pipeline.overflow_ticks == 0
+    assert a.pipeline.overflow_ticks == 1 and a.pipeline.P == 16384 and b.pipeline.overflow_ticks == 0
 
 
 @pytest.mark.parametrize("hip_graphs", [True, False])

@@ -252,8 +252,20 @@ def test_train_full_driver_reads_recorded_routes(tmp_path):
     from tests.util import dataset_fixture_config
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = dataset_fixture_config(str(tmp_path), routes=1, frames=23)
-    out = subprocess.run([sys.executable, os.path.join(repo, "train_full_v2.py"), "--config-path", cfg, "--batch-size", "2", "--num-epoch", "1",
-                          "--num-workers", "0", "--save-dir", str(tmp_path / "ck")], capture_output=True, text=True, timeout=900)
+    base = [sys.executable, os.path.join(repo, "train_full_v2.py"), "--config-path", cfg, "--batch-size", "2", "--num-epoch", "1",
+            "--num-workers", "0", "--save-dir", str(tmp_path / "ck")]
+    # a run on recorded routes follows the reference's checkpoint rules (lav_final_v2.py:42-72): the teacher, the LiDAR model and
+    # the planner come from the config's *_model_dir keys or the command line - never silently from seeded random weights
+    out = subprocess.run(base, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "bev_model_dir" in (out.stdout + out.stderr)
+    import torch
+    from lav_amd.train import LAV, TrainConfig
+    seeded = LAV(TrainConfig(), torch.device("cpu"), what="lidar")
+    names = dict(bev=seeded.bev_planner.state_dict(), lidar=seeded.state_dict("lidar"), uniplanner=seeded.state_dict("uniplanner"))
+    for k, sd in names.items():
+        torch.save(sd, tmp_path / f"{k}_seed.th")
+    out = subprocess.run(base + ["--bev", str(tmp_path / "bev_seed.th"), "--lidar", str(tmp_path / "lidar_seed.th"),
+                                 "--uniplanner", str(tmp_path / "uniplanner_seed.th")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert '"steps": 1' in out.stdout and "3 recorded frames" in out.stdout
     assert os.path.exists(tmp_path / "ck" / "lidar_1.th") and os.path.exists(tmp_path / "ck" / "uniplanner_1.th")
