@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 18
+#define LAV_ABI_VERSION 19
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -397,6 +397,29 @@ int lav_scatter_max(const float *src, const int *index, int n, int channels, int
                     void *stream);
 int lav_scatter_max_backward(const float *grad_out, const int *argmax, int n, int channels, int num_segments,
                              float *grad_src, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 7b. Train-mode BatchNorm2d (batch statistics) with the neighbouring ReLU / residual add fused, forward and backward, NCHW
+ *     float32.  Replaces the nn.BatchNorm2d + nn.ReLU (+ add) launches of the student networks in
+ *     lav/lav_final_v2.py:140-259: ConvBackbone's Conv -> ReLU -> BatchNorm (team_code_v2/models/lidar.py:57-108; relu_pre)
+ *     and ResNet-18's Conv -> BatchNorm (-> + identity) -> ReLU (lav/models/resnet.py; relu_post, residual).
+ *
+ *     forward:   t = relu_pre ? max(x, 0) : x;   mean/var over (batch, plane) per channel (biased var, float64 sums);
+ *                y = (t - mean) / sqrt(var + eps) * gamma + beta (+ residual) (-> ReLU if relu_post)
+ *                save_mean / save_var (biased) / save_rstd [channels] are written for the backward and the running statistics
+ *                (the caller updates those: running = (1 - m) * running + m * (mean, var * n / (n - 1))).
+ *     backward:  g = relu_post ? dy * [y > 0] : dy  (written to dres when the forward had a residual: that branch's gradient);
+ *                dbeta = sum g, dgamma = sum g * xhat, dx = gamma * rstd * (g - dbeta / n - xhat * dgamma / n) (* [x > 0] if relu_pre)
+ *     relu_pre excludes relu_post / residual.  y is only read when relu_post.  Two launches each way; sums are reduced in a
+ *     fixed order (bit-reproducible).  workspace: lav_bn_train_workspace_bytes(channels) bytes, no at-rest state.
+ * ------------------------------------------------------------------------------------------ */
+size_t lav_bn_train_workspace_bytes(int channels);
+int lav_bn_train_forward(const float *x, const float *residual, float *y, int batch, int channels, long plane, const float *gamma,
+                         const float *beta, double eps, int relu_pre, int relu_post, float *save_mean, float *save_var,
+                         float *save_rstd, void *workspace, size_t workspace_bytes, void *stream);
+int lav_bn_train_backward(const float *x, const float *y, const float *dy, int batch, int channels, long plane, const float *gamma,
+                          const float *save_mean, const float *save_rstd, int relu_pre, int relu_post, float *dx, float *dres,
+                          float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8. Two stacked 1-D convolutions in one launch - one half of ERFNet's non_bottleneck_1d block

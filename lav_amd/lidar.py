@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from .ops import ConvLayer, GroupedDeconv
 from .point_pillar import PointPillarNet
@@ -96,10 +97,11 @@ class ConvBackbone(_Engine):
 
     def forward_train(self, x):
         """Train mode (autograd, BatchNorm on batch statistics): the nn modules themselves (lidar.py:110-143)."""
-        f1 = self.conv1(x)
-        f2 = self.conv2(f1)
-        f3 = self.conv3(f2)
-        return torch.cat([self.upconv1(f1), self.upconv2(f2), self.upconv3(f3)], dim=1)
+        from .train.hipnn import conv_relu_bn   # ReLU + batch-statistics BatchNorm as one fused forward / backward pair
+        f1 = conv_relu_bn(self.conv1, x)
+        f2 = conv_relu_bn(self.conv2, f1)
+        f3 = conv_relu_bn(self.conv3, f2)
+        return torch.cat([conv_relu_bn(self.upconv1, f1), conv_relu_bn(self.upconv2, f2), conv_relu_bn(self.upconv3, f3)], dim=1)
 
     def forward(self, x, out=None):
         """`out`: optional preallocated (B, 6*num_feature, H/2, W/2) buffer the three up-convolutions write into."""
@@ -145,7 +147,8 @@ class Head(_Engine):
 
     def forward(self, x):
         if self.training:
-            return self.output_activation(self.net(x))
+            from .train.hipnn import bn_act
+            return self.output_activation(self.net[3](bn_act(self.net[2], self.net[0](x), relu_pre=True)))
         if self._eng is None or self._eng["device"] != x.device:
             conv, bn = self.net[0], self.net[2]
             eng = dict(device=x.device,
@@ -201,10 +204,28 @@ class LiDARModel(_Engine):
         asks for the three detection heads first - the others branch waits on them - and for the segmentation head
         on a side stream."""
         if self.training:
-            return tuple(getattr(self, n)(features) for n in names)
+            return self._heads_train(features, names)
         e = self._head_engine(tuple(names), features.device)
         fused = e["deconv"](e["conv"](features))          # (B, sum(outs), 2H, 2W)
         return tuple(torch.split(fused, e["outs"], dim=1))
+
+    def _heads_train(self, features, names):
+        """Train mode: the heads' first convolutions (384 -> 64 each, lidar.py:147-161) as ONE convolution 384 -> 64*len(names)
+        over the concatenated weights - the feature map is read once forward and its gradient is produced by one data-gradient
+        convolution instead of len(names) of them plus their sum; autograd splits the weight gradient back.  BatchNorm is per
+        channel, so normalising the concatenated channels with the concatenated parameters is the heads' own BatchNorms."""
+        hs = [getattr(self, n) for n in names]
+        if len(hs) == 1 or not features.is_cuda:
+            return tuple(h(features) for h in hs)
+        from .train.hipnn import bn_act_many
+        mid = F.conv2d(features, torch.cat([h.net[0].weight for h in hs], dim=0), None, 1, 1)
+        mid = bn_act_many([h.net[2] for h in hs], mid, relu_pre=True)
+        outs, off = [], 0
+        for h in hs:
+            c = h.net[0].out_channels
+            outs.append(h.output_activation(h.net[3](mid[:, off:off + c])))
+            off += c
+        return tuple(outs)
 
     def forward(self, lidars, num_points):
         features = self.backbone(self.point_pillar_net(lidars, num_points))

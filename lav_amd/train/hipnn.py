@@ -1,0 +1,121 @@
+"""Train-mode layers on liblav_amd's hand-written kernels, as torch.autograd Functions over the C ABI.
+
+bn_act(bn, x, relu_pre/relu_post, residual): nn.BatchNorm2d on batch statistics with the ReLU before it (ConvBackbone's
+Conv -> ReLU -> BatchNorm, team_code_v2/models/lidar.py:57-108) or after it and the residual add (ResNet-18's BasicBlock,
+lav/models/resnet.py) in lav_bn_train_forward / lav_bn_train_backward: two launches each way instead of the 3-5 torch /
+MIOpen launches, 8 passes over the activation instead of 13, bit-reproducible sums.  The module's parameters and running
+statistics are the nn.BatchNorm2d's own (state_dict keys unchanged).
+
+On a CPU tensor (the gloo tests, the CPU training baseline) the same function runs the torch modules.
+LAV_TRAIN_BN=torch forces the torch path on the GPU too (A/B timing).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from ..ops import _ptr, _stream, check
+
+_WS = {}
+
+
+def _workspace(channels: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    need = _lib.load().lav_bn_train_workspace_bytes(int(channels))
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, eps, relu_pre, relu_post):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        res = None if residual is None else residual.contiguous()
+        y = torch.empty_like(x)
+        save = torch.empty((3, C), dtype=torch.float32, device=x.device)   # mean, biased var, rstd
+        ws = _workspace(C, x.device)
+        check(_lib.load().lav_bn_train_forward(_ptr(x), _ptr(res), _ptr(y), B, C, H * W, _ptr(gamma.contiguous()), _ptr(beta.contiguous()),
+                                               float(eps), int(relu_pre), int(relu_post), _ptr(save[0]), _ptr(save[1]), _ptr(save[2]),
+                                               _ptr(ws), ws.numel(), _stream()), "lav_bn_train_forward")
+        ctx.save_for_backward(x, y if relu_post else None, gamma, save)
+        ctx.cfg = (bool(relu_pre), bool(relu_post), residual is not None)
+        mean, var = save[0], save[1]
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, y, gamma, save = ctx.saved_tensors
+        relu_pre, relu_post, has_res = ctx.cfg
+        dy = dy.contiguous()
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        # the residual branch's gradient is the masked dy; without relu_post that is dy itself (no extra pass)
+        dres = torch.empty_like(x) if (has_res and relu_post) else None
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        ws = _workspace(C, x.device)
+        check(_lib.load().lav_bn_train_backward(_ptr(x), _ptr(y), _ptr(dy), B, C, H * W, _ptr(gamma.contiguous()), _ptr(save[0]), _ptr(save[2]),
+                                                int(relu_pre), int(relu_post), _ptr(dx), _ptr(dres), _ptr(dgb[0]), _ptr(dgb[1]),
+                                                _ptr(ws), ws.numel(), _stream()), "lav_bn_train_backward")
+        return dx, dgb[0], dgb[1], (dres if dres is not None else dy) if has_res else None, None, None, None
+
+
+def _use_hip(bn, x) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.training and bn.affine and bn.track_running_stats
+            and os.environ.get("LAV_TRAIN_BN", "hip") != "torch")
+
+
+def bn_act(bn: torch.nn.BatchNorm2d, x: torch.Tensor, relu_pre: bool = False, relu_post: bool = False, residual=None) -> torch.Tensor:
+    """relu_post(bn(relu_pre(x)) + residual) with `bn` in train mode (batch statistics, running statistics updated like
+    nn.BatchNorm2d: momentum, unbiased variance, num_batches_tracked)."""
+    if not _use_hip(bn, x):
+        t = F.relu(x) if relu_pre else x
+        y = bn(t)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu_post else y
+    y, mean, var = _BnAct.apply(x, bn.weight, bn.bias, residual, bn.eps, relu_pre, relu_post)
+    _update_running(bn, mean, var, x.shape[0] * x.shape[2] * x.shape[3])
+    return y
+
+
+def _update_running(bn, mean, var, n):
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+        bn.running_var.mul_(1.0 - m).add_(var, alpha=m * n / max(n - 1, 1))
+
+
+def bn_act_many(bns, x: torch.Tensor, relu_pre: bool = False, relu_post: bool = False) -> torch.Tensor:
+    """Several BatchNorm2d modules over consecutive channel blocks of one tensor (BatchNorm is per channel: one launch pair with
+    the concatenated parameters is the modules' own normalisations)."""
+    if not all(_use_hip(bn, x) for bn in bns) or len({bn.eps for bn in bns}) != 1:
+        outs, off = [], 0
+        for bn in bns:
+            outs.append(bn_act(bn, x[:, off:off + bn.num_features], relu_pre, relu_post))
+            off += bn.num_features
+        return torch.cat(outs, dim=1)
+    y, mean, var = _BnAct.apply(x, torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns]), None, bns[0].eps, relu_pre, relu_post)
+    n, off = x.shape[0] * x.shape[2] * x.shape[3], 0
+    for bn in bns:
+        _update_running(bn, mean[off:off + bn.num_features], var[off:off + bn.num_features], n)
+        off += bn.num_features
+    return y
+
+
+def conv_relu_bn(seq, x):
+    """A run of [Conv, ReLU, BatchNorm2d] triples (ConvBackbone's stages and up-convolutions) in train mode."""
+    mods = list(seq)
+    if len(mods) % 3:
+        raise RuntimeError("expected [conv, relu, bn] triples")
+    for j in range(0, len(mods), 3):
+        x = bn_act(mods[j + 2], mods[j](x), relu_pre=True)
+    return x

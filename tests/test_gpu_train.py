@@ -285,3 +285,71 @@ def test_two_rank_data_parallel_step_over_the_hip_autograd_functions(tmp_path):
                          capture_output=True, text=True, timeout=900, env=dict(os.environ, LAV_DIST_BACKEND="gloo"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert '"n_gpus": 2' in out.stdout and '"replicas_in_sync": true' in out.stdout and '"steps": 2' in out.stdout, out.stdout[-1500:]
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 40, 40), (3, 5, 7, 9), (57, 512, 3, 3)])
+@pytest.mark.parametrize("mode", ["plain", "relu_pre", "relu_post", "residual"])
+def test_bn_act_forward_backward_vs_torch(shape, mode):
+    """lav_bn_train_forward / _backward (batch statistics + fused ReLU / residual) against nn.BatchNorm2d + F.relu in float64 on the
+    host: output, running statistics and all four gradients; and bit-reproducible from run to run."""
+    from lav_amd.train.hipnn import bn_act
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    B, C, H, W = shape
+    x = torch.randn(shape) * 1.5 + 0.3
+    res = torch.randn(shape) if mode == "residual" else None
+    dy = torch.randn(shape)
+    kw = dict(relu_pre=mode == "relu_pre", relu_post=mode in ("relu_post", "residual"))
+
+    def run(device, dtype, force_torch=False):
+        bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(device=device, dtype=dtype).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        xx = x.to(device=device, dtype=dtype).requires_grad_(True)
+        rr = None if res is None else res.to(device=device, dtype=dtype).requires_grad_(True)
+        y = bn_act(bn, xx, residual=rr, **kw)
+        y.backward(dy.to(device=device, dtype=dtype))
+        out = [y.detach(), bn.running_mean, bn.running_var, xx.grad, bn.weight.grad, bn.bias.grad]
+        if rr is not None:
+            out.append(rr.grad)
+        return [t.detach().double().cpu() for t in out], int(bn.num_batches_tracked)
+
+    ref, nb_ref = run("cpu", torch.float64)
+    got, nb = run(dev, torch.float32)
+    again, _ = run(dev, torch.float32)
+    assert nb == nb_ref == 1
+    names = ["y", "running_mean", "running_var", "dx", "dgamma", "dbeta", "dres"]
+    for n, a, b, c in zip(names, got, ref, again):
+        assert torch.equal(a, c), f"{n}: two runs differ"
+        scale = max(b.abs().max().item(), 1.0)
+        assert (a - b).abs().max().item() <= 1e-4 * scale, (n, (a - b).abs().max().item(), scale)
+
+
+def test_heads_train_mode_fused_first_convolution_matches_per_head_modules():
+    """LiDARModel.heads in train mode (one 384 -> 256 convolution + one BatchNorm launch pair over the four heads) against the
+    four Head modules run one by one through torch ops: outputs, feature gradient, every parameter gradient, running stats."""
+    import copy
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    lm = lav_amd.LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **CFG)
+    lm.load_state_dict(state_dicts()[0])
+    lm = lm.to(dev).train()
+    ref = copy.deepcopy(lm)
+    feats = torch.randn((2, 384, 40, 40), device=dev)
+    fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    outs = lm.heads(fa)
+    outs_ref = tuple(torch.sigmoid(h.net(fb)) if h._sigmoid else h.net(fb) for h in (getattr(ref, n) for n in lm.ALL_HEADS))
+    gs = [torch.randn_like(o) for o in outs]
+    torch.autograd.backward(outs, gs)
+    torch.autograd.backward(outs_ref, gs)
+    for a, b in zip(outs, outs_ref):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    assert (fa.grad - fb.grad).abs().max().item() <= 1e-4 * fb.grad.abs().max().item()
+    pa, pb = dict(lm.named_parameters()), dict(ref.named_parameters())
+    for k, v in pb.items():
+        if "_head" in k:
+            assert (pa[k].grad - v.grad).abs().max().item() <= 2e-4 * max(v.grad.abs().max().item(), 1e-3), k
+    ba, bb = dict(lm.named_buffers()), dict(ref.named_buffers())
+    for k, v in bb.items():
+        if "_head" in k:
+            assert (ba[k].double() - v.double()).abs().max().item() <= 1e-5 * max(1.0, v.double().abs().max().item()), k
