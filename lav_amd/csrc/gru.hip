@@ -325,10 +325,17 @@ __global__ __launch_bounds__(64 * OUT_WAVES) void k_plan_out(PlanArgs a, int it)
 // still being read.  Every workgroup re-derives the waypoints (Linear(512->2) + cumsum) itself because it needs them
 // as GRU inputs in the next iteration; workgroup 0 also writes them out.  Spins are bounded: a workgroup that times out
 // (its peers are not co-resident, e.g. the chip is oversubscribed by other streams) stops waiting, sets the status word
-// of the workspace (lav_gru_plan_status) and overwrites the WHOLE output with NaN, so that a plan that was not computed
-// can never be mistaken for one: the reference agent's own rule for NaN waypoints (no steering, no throttle,
-// lav_agent_fast.py:325-328) applies, and lav_gru_plan_steps recomputes it without any co-residency requirement.
+// of the workspace (lav_gru_plan_status) and returns; k_plan_poison, enqueued right behind the persistent kernel, then
+// overwrites the WHOLE output with NaN if the status word is set (one agent, after every workgroup has left: status and output
+// always agree), so that a plan that was not computed can never be mistaken for one: the reference agent's own rule for NaN
+// waypoints (no steering, no throttle, lav_agent_fast.py:325-328) applies, and lav_gru_plan_steps recomputes it without any
+// co-residency requirement.
 constexpr long long PLAN_SPIN_LIMIT = 1ll << 22;
+
+__global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ status, float *__restrict__ out, long n_out) {
+    if (*status == 0) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (long)gridDim.x * 256) out[i] = __uint_as_float(0x7fc00000u);
+}
 
 __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status,
                                                          long long spin_limit) {
@@ -426,11 +433,7 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                         __builtin_amdgcn_s_sleep(2);
                     }
                 } while (!ok);
-                if (*(volatile int *)&abort_s) {  // give up: never hang the device, never return a plan that was not computed
-                    const long n_out = (long)a.B * a.iters * a.NC * T * 2;
-                    for (long i = tid; i < n_out; i += 256) a.out[i] = __uint_as_float(0x7fc00000u);
-                    return;
-                }
+                if (*(volatile int *)&abort_s) return;   // give up: never hang the device (k_plan_poison, next on the stream, voids the output)
                 // waypoint t-1 of this iteration from h_{t-1} (every workgroup needs it as next iteration's input)
                 if (wid == 0) {
 #pragma unroll
@@ -592,6 +595,8 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
         const char *lim = getenv("LAV_PLAN_SPIN_LIMIT");   // test knob: 1 forces the time-out path
         const long long spin_limit = lim && atoll(lim) > 0 ? atoll(lim) : PLAN_SPIN_LIMIT;
         hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit);
+        const long n_out = (long)a.B * a.iters * a.NC * T * 2;
+        hipLaunchKernelGGL(k_plan_poison, dim3((unsigned)std::min<long>((n_out + 255) / 256, 64)), dim3(256), 0, st, status, a.out, n_out);
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
         return LAV_OK;

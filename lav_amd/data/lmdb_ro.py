@@ -9,7 +9,9 @@ values.  Sub-databases, duplicate-sorted keys and LEAF2 pages do not occur in th
 
 PARITY UNPINNED for the file format: no liblmdb exists in this image to write or read a file with, so the reader is checked
 against files from this module's own writer only (tests/test_data_host.py: tree depths 1-3, overflow values, every key
-found, absent keys rejected).  The surface mirrors py-lmdb's: open(path, ...).begin(write=False).get(key).
+found, absent keys rejected).  NO FILE WRITTEN BY liblmdb / py-lmdb HAS EVER BEEN READ BY THIS MODULE (a search of the image
+found no .mdb file and no lmdb or cv2 package to produce a fixture with): treat the recorded-route path of the trainers as
+experimental until one has.  The surface mirrors py-lmdb's: open(path, ...).begin(write=False).get(key).
 """
 from __future__ import annotations
 

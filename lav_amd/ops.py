@@ -53,6 +53,12 @@ def _workspace(key, nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+def _drop_workspace(key, device):
+    ws = _workspaces.pop((key, device, torch.cuda.current_stream().cuda_stream), None)
+    if ws is not None:
+        _retired.append(ws)   # (captured graphs may still hold its address)
+
+
 # ------------------------------------------------------------------------------------------ pillar
 def make_grid(min_x, max_x, min_y, max_y, ppm) -> Grid:
     nx = int((max_x - min_x) * ppm)
@@ -86,9 +92,13 @@ def pillar_scatter(points: torch.Tensor, num_points: Sequence[int], grid: Grid, 
         uc = torch.empty((max(total, 1), 3), dtype=torch.int32, device=dev)
         inv = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
         cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
-    check(lib.lav_pillar_scatter(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), C.byref(net),
-                                 _ptr(canvas), _ptr(uc), _ptr(inv), _ptr(cnt), _ptr(ws), ws.numel(), _stream()),
-          "lav_pillar_scatter")
+    rc = lib.lav_pillar_scatter(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), C.byref(net),
+                                _ptr(canvas), _ptr(uc), _ptr(inv), _ptr(cnt), _ptr(ws), ws.numel(), _stream())
+    if rc != 0:
+        # the workspace's zero-at-rest state (arrival counters, epoch words) may be half-updated: never reuse it (lav_amd.h, workspace
+        # contract) - the next call zero-fills a fresh one
+        _drop_workspace(("pillar", B, grid.nx, grid.ny), dev)
+    check(rc, "lav_pillar_scatter")
     if want_indices:
         p, k = [int(v) for v in cnt.tolist()]
         return canvas, uc[:p], inv[:k]

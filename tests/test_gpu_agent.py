@@ -100,6 +100,7 @@ def test_agent_vs_reference_agent_golden(golden, tmp_path, hip_graphs):
     g = golden["agent_fast"]
     a, sc = _make(tmp_path, hip_graphs=hip_graphs)
     ticks, npts = int(g["ticks"][0]), int(g["n_points"][0])
+    dev_plan, dev_cast, dev_other, flipped = {}, {}, {}, {}
     for i in range(ticks):
         ctl = a.run_step(synth.agent_inputs(i, sc, n_points=npts), i * 0.05)
         want = g["controls"][i]
@@ -126,10 +127,19 @@ def test_agent_vs_reference_agent_golden(golden, tmp_path, hip_graphs):
             # pixel-boundary flips of the projection (sgemm association, see oracle/paint.py)
             flips = np.abs(pts[:, 4:8] - ref[:, 4:8]).max(1) > 1e-4
             assert flips.mean() < 2e-3, f"tick {i}: {flips.sum()} painted rows differ"
-            np.testing.assert_allclose(out["other_cast_locs"].cpu().numpy(), g[f"t{i}/other_cast"], rtol=0, atol=2e-4)
+            flipped[i] = int(flips.sum())
+            dev_other[i] = float(np.abs(out["other_cast_locs"].cpu().numpy() - g[f"t{i}/other_cast"]).max())
             np.testing.assert_allclose(out["other_cast_cmds"].cpu().numpy(), g[f"t{i}/other_cmds"], rtol=0, atol=1e-5)
         ref_det = g[f"t{i}/det1"]
         assert [tuple(d[:2]) for d in out["det"][1]] == [tuple(r[:2]) for r in ref_det], f"tick {i}: vehicle detections"
-        np.testing.assert_allclose(out["ego_plan_locs"].cpu().numpy(), g[f"t{i}/ego_plan"], rtol=0, atol=2e-4)
-        np.testing.assert_allclose(out["ego_cast_locs"].cpu().numpy(), g[f"t{i}/ego_cast"], rtol=0, atol=2e-4)
+        dev_plan[i] = float(np.abs(out["ego_plan_locs"].cpu().numpy() - g[f"t{i}/ego_plan"]).max())
+        dev_cast[i] = float(np.abs(out["ego_cast_locs"].cpu().numpy() - g[f"t{i}/ego_cast"]).max())
     a.destroy()
+    # Waypoints: north_star's 1e-4 on every tick, including the two whose stacked cloud shows painted rows on the other side of
+    # a pixel boundary (sgemm association, oracle/paint.py: 60-70 of 24k rows) - measured max 5.3e-5 (plan), 1.1e-5 (cast).
+    print("agent waypoints: max |diff| per tick, plan", {k: round(v, 6) for k, v in dev_plan.items()}, "cast",
+          {k: round(v, 6) for k, v in dev_cast.items()}, "others", {k: round(v, 6) for k, v in dev_other.items()}, "painted rows flipped", flipped)
+    for i in dev_plan:
+        assert dev_plan[i] <= 1e-4 and dev_cast[i] <= 1e-4, (i, dev_plan[i], dev_cast[i])
+    for i in dev_other:
+        assert dev_other[i] <= 1e-4, (i, dev_other[i])
