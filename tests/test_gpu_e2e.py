@@ -157,3 +157,41 @@ def test_graphed_frame_pipeline_matches_eager(models):
         for k in ("ego_plan_locs", "ego_cast_locs", "other_cast_locs", "other_cast_cmds", "pred_bra"):
             assert_close(b[k].cpu().numpy(), a[k].cpu().numpy(), atol=2e-5, rtol=2e-6, what=f"frame {i} {k}")
         assert_close(b["pred_bev"].cpu().numpy(), a["pred_bev"].cpu().numpy(), atol=1e-5, what=f"frame {i} pred_bev")
+
+
+def test_forced_others_hook_runs_the_others_branch_on_the_given_poses(models):
+    """set_forced_others (frame time at a fixed number of other vehicles): the others branch's outputs are those of the
+    given poses - crop_feature + embedder + cast on this frame's feature map - whatever the heads detect; n = 0 gives the
+    reference's empty outputs; None restores the detections."""
+    from lav_amd.frame import GraphedFramePipeline
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    lm, up = models
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval().to(DEV)
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]); bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra.")); bra.eval().to(DEV)
+    pipe = GraphedFramePipeline(lm, up, seg, bra, 1.5, 2.4, device=DEV, points_per_tick=8192)
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]
+    all_rgb = torch.tensor(np.stack(rgbs, 0).copy()).permute(0, 3, 1, 2).float().to(DEV)
+    wide = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float().to(DEV)
+    tel_rgb = torch.tensor(tel[..., :3][..., ::-1][:-96][None].copy()).permute(0, 3, 1, 2).float().to(DEV)
+    nxp = torch.tensor([1.0, -9.0], device=DEV)
+    step = lambda i: pipe.step(torch.from_numpy(synth.lidar_sweep(8192, name=f"f{i}")).to(DEV), all_rgb, wide, tel_rgb,
+                               np.array([0.3 * i, 0.05 * i]), 0.02 * i, nxp, 3)
+    locs = np.array([[4.0, -12.0], [-3.5, -20.0], [0.5, 8.0], [7.0, -30.0]], np.float32)
+    oris = np.array([0.1, -0.2, 3.0, 0.0], np.float32)
+    pipe.set_forced_others(locs, oris)
+    for i in range(3):
+        out = step(i)
+    assert out["other_cast_locs"].shape[:1] == (4,) and out["other_cast_cmds"].shape == (4, up.num_cmds)
+    dl, do = torch.from_numpy(locs).to(DEV), torch.from_numpy(oris).to(DEV)
+    crops = up.crop_feature(pipe.b_features.expand(4, -1, -1, -1), dl, do, up.pixels_per_meter / 2, up.crop_size)
+    _, cast, cmds = up.embed_cast(crops, oris=do, locs=dl, want_cmds=True)
+    # (the capacity-15 graph and this 4-row call get different convolution plans: float summation order)
+    assert_close(out["other_cast_locs"].cpu().numpy(), cast.cpu().numpy(), atol=2e-5, rtol=2e-6, what="forced others cast")
+    assert_close(out["other_cast_cmds"].cpu().numpy(), cmds.cpu().numpy(), atol=2e-6, what="forced others cmds")
+    pipe.set_forced_others(locs[:0], oris[:0])
+    out0 = step(3)
+    assert out0["other_cast_locs"].shape[0] == 0 and out0["other_cast_cmds"].shape[0] == 0
+    pipe.set_forced_others(None)
+    free = step(4)
+    assert free["other_cast_locs"].shape[0] == min(len(up.others_from_detections(free["det"][1], 320, 320)[0]), 15)

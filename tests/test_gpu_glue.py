@@ -1,0 +1,117 @@
+"""The small fused kernels that replaced torch / library launches inside the frame graphs, each against
+the torch ops it stands in for, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lav_amd import _lib, ops
+from lav_amd.planner_common import transform_points
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 48, 48), (7, 64, 96, 96), (2, 3, 5, 7)])
+def test_maxpool3x3s2_is_max_pool2d(shape):
+    """nn.MaxPool2d(3, 2, 1) of the ResNet-18 stem (lav/models/resnet.py:165,237)."""
+    torch.manual_seed(1)
+    x = torch.randn(shape, device=DEV)
+    assert torch.equal(ops.maxpool3x3s2(x), F.max_pool2d(x, 3, 2, 1))
+
+
+def test_channel_affine_is_the_brake_normalisation():
+    """normalize(rgb / 255) (team_code_v2/models/rgb.py:71-72) as one per-channel affine."""
+    torch.manual_seed(2)
+    x = torch.rand((1, 3, 288, 768), device=DEV) * 255
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    s, t = (1.0 / (255.0 * std.double())).float().to(DEV), (-mean.double() / std.double()).float().to(DEV)
+    want = (x.double().cpu() / 255.0 - mean.double()[None, :, None, None]) / std.double()[None, :, None, None]
+    got = ops.channel_affine(x, s, t).double().cpu()
+    assert (got - want).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,K,O,sig", [(1, 1024, 1, True), (5, 512, 6, True), (3, 100, 7, False)])
+def test_linear_act_vs_torch(B, K, O, sig):
+    """nn.Sequential(Linear, Sigmoid): the brake classifier (rgb.py:62,79) and cast_cmd_pred (uniplanner.py:50-53)."""
+    torch.manual_seed(3)
+    x, w, b = torch.randn(B, K), torch.randn(O, K) / K ** 0.5, torch.randn(O)
+    want = F.linear(x.double(), w.double(), b.double())
+    want = torch.sigmoid(want) if sig else want
+    got = ops.linear_act(x.to(DEV), w.to(DEV), b.to(DEV), sigmoid=sig).double().cpu()
+    assert (got - want).abs().max().item() < 2e-6
+
+
+def test_copy_many_copies_every_pair_in_one_launch():
+    torch.manual_seed(4)
+    srcs = [torch.randn(n, device=DEV) for n in (4, 1024, 3 * 288 * 256, 36, 8, 16, 20, 400, 12, 64)]   # 10 pairs: two launches
+    dsts = [torch.zeros_like(s) for s in srcs]
+    odd_src, odd_dst = torch.randn(7, device=DEV), torch.zeros(7, device=DEV)                            # not 16-byte sized: copy_ fallback
+    ops.copy_many(list(zip(dsts, srcs)) + [(odd_dst, odd_src)])
+    for d, s in zip(dsts + [odd_dst], srcs + [odd_src]):
+        assert torch.equal(d, s)
+
+
+def test_grouped_deconv_softmax_epilogue_is_softmax_of_the_transposed_convolution():
+    """ERFNet's output layer ConvTranspose2d(16, 5, 2, stride 2) + softmax over the classes (erfnet.py:140-142,
+    lav_agent_fast.py:258) in one launch."""
+    torch.manual_seed(5)
+    ct = torch.nn.ConvTranspose2d(16, 5, 2, stride=2)
+    x = torch.randn(3, 16, 36, 32)
+    want = torch.softmax(ct.double()(x.double()), dim=1)
+    ct = ct.float()
+    got = ops.GroupedDeconv([ct], softmax=True, device=DEV)(x.to(DEV)).double().cpu()
+    assert (got - want).abs().max().item() < 2e-6
+    assert (got.sum(1) - 1).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("B,hw,with_pose", [(1, 9, False), (4, 9, True), (15, 1, True)])
+def test_embed_cast_is_pool_cast_cmd_pred_and_transform(B, hw, with_pose):
+    """lav_embed_cast against its parts: AdaptiveAvgPool2d + Flatten (uniplanner.py:36-40), the six cast GRUs through
+    lav_gru_cast (itself pinned by the reference goldens, :288-308), Linear + Sigmoid (:50-53) and transform_points + translate
+    (model_inference.py:164-165,240-251)."""
+    torch.manual_seed(6)
+    E, H, ncmd, T = 512, 64, 6, 10
+    side = int(round(hw ** 0.5))
+    feat = torch.randn(B, E, side, side, device=DEV)
+    w = dict(w_ih=torch.randn(ncmd, 3 * H, E, device=DEV) / E ** 0.5, w_hh=torch.randn(ncmd, 3 * H, H, device=DEV) / H ** 0.5,
+             b_ih=torch.randn(ncmd, 3 * H, device=DEV) * 0.1, b_hh=torch.randn(ncmd, 3 * H, device=DEV) * 0.1,
+             mlp_w=torch.randn(ncmd, 2, H, device=DEV) / H ** 0.5, mlp_b=torch.randn(ncmd, 2, device=DEV) * 0.1)
+    cmd_w, cmd_b = torch.randn(ncmd, E, device=DEV) / E ** 0.5, torch.randn(ncmd, device=DEV)
+    oris = torch.randn(B, device=DEV) if with_pose else None
+    locs = torch.randn(B, 2, device=DEV) * 10 if with_pose else None
+    embd, cast, cmds = ops.embed_cast(feat, w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"], w["mlp_b"], T,
+                                      cmd_w=cmd_w, cmd_b=cmd_b, oris=oris, locs=locs)
+    want_embd = feat.double().mean((2, 3))
+    assert (embd.double() - want_embd).abs().max().item() < 1e-6
+    want_cast = ops.gru_cast(want_embd.float(), w["w_ih"], w["w_hh"], w["b_ih"], w["b_hh"], w["mlp_w"], w["mlp_b"], T)
+    if with_pose:
+        want_cast = transform_points(want_cast, oris[:, None].expand(B, ncmd)) + locs[:, None, None]
+    assert (cast - want_cast).abs().max().item() < 2e-5
+    want_cmds = torch.sigmoid(F.linear(want_embd, cmd_w.double(), cmd_b.double()))
+    assert (cmds.double() - want_cmds).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("case", [("head", 1, 384, 256, 3, 1, 1, 40, False), ("s2", 2, 64, 128, 3, 2, 1, 40, False),
+                                  ("up", 2, 128, 64, 3, 2, 1, 20, True), ("res", 7, 128, 128, 3, 1, 1, 12, False)])
+def test_split_operand_convolution_is_as_accurate_as_fp32(case):
+    """precision bf16x6 (three bf16 pieces per operand, the six leading products on the bf16 matrix cores, fp32 accumulation)
+    against a float64 convolution: its error stays at the fp32 kernel's level (both ~1e-6 of sum |a||b|), so the 1e-4 / 3e-5
+    parity bars of the frame are met with either; LAV_CONV_PRECISION / lav_conv.precision selects."""
+    name, B, cin, cout, k, s, p, H, tr = case
+    torch.manual_seed(7)
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k)) / (cin * k * k) ** 0.5
+    x = torch.randn(B, cin, H, H)
+    if tr:
+        want = F.conv_transpose2d(x.double(), w.double(), None, s, p, 1)
+        mag = F.conv_transpose2d(x.double().abs(), w.double().abs(), None, s, p, 1)
+    else:
+        want = F.conv2d(x.double(), w.double(), None, s, p)
+        mag = F.conv2d(x.double().abs(), w.double().abs(), None, s, p)
+    kw = dict(stride=s, padding=(p, p), transposed=tr, output_padding=1 if tr else 0, device=DEV)
+    errs = {}
+    for prec, label in ((_lib.CONV_F32, "f32"), (_lib.CONV_BF16X6, "bf16x6")):
+        y = ops.ConvLayer(w, precision=prec, **kw)(x.to(DEV)).double().cpu()
+        errs[label] = ((y - want).abs() / mag).max().item()
+    print(name, errs)
+    assert errs["f32"] < 2e-6 and errs["bf16x6"] < 2e-6, errs

@@ -201,16 +201,18 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     alternating seeded batches (tests/golden/make_golden.py:gold_train_curve, tests/golden/train_curve.npz); the MI355X
     trainer runs the same 500 steps from the same weights.
 
-    What "match" can mean: step 0 is the same arithmetic (2e-3).  From then on two float32 implementations separate -
-    Adam's first updates are lr*sign(g), so rounding-level gradient differences flip signs where g ~ 0 - and the MI355X
-    trainer is not even bit-reproducible against ITSELF (fp32 atomics in the crop / scatter backward, MIOpen's algorithm
-    choice): two runs of this test's loop differ by up to 29 % in the 100-step moving average of the total loss and by
-    47 % in the 25-step one (measured, tools/curve_run.py).  The reference curve (50 -> 8.5 over the 500 steps) lies INSIDE
-    that spread: 26 % / 42 %.  The bars below are therefore on the curve's shape - the first 60 smoothed steps within 10 %
-    (measured 1-3 %), the 100-step moving average within 50 % everywhere (measured over six runs of this test: 0.17-0.37), the
-    level of the last 100 steps no more than 35 % ABOVE the reference's and not below half of it (measured 5.5-7.8 against the
-    reference's 8.7: since the planners' GRUs and the crop gradient left fp32 atomics the MI355X runs tend to end lower,
-    which is not a failure of the match) - not on per-step values."""
+What "match" can mean: step 0 is the same arithmetic (2e-3).  From then on two float32 implementations separate -
+    Adam's first updates are lr*sign(g), so rounding-level gradient differences (oneDNN's convolutions on the reference's CPU
+    run, MIOpen's here) flip signs where g ~ 0 - and the trajectories decorrelate like any chaotic system's.  The MI355X
+    trainer itself IS reproducible: every liblav_amd kernel reduces in a fixed order, and with torch / MIOpen switched to their
+    deterministic algorithms (lav_amd.train.run.set_deterministic, as this test does) two runs agree bit for bit
+    (test_train_lidar_step_is_bit_reproducible_with_deterministic_algorithms; without the switch torch's atomics-based
+    backward kernels and MIOpen's algorithm choice make two runs differ by up to 29 % in the 100-step moving average - measured,
+    tools/determinism_probe.py, tools/curve_run.py).  So this test's curve is ONE fixed curve, measured: first 60 smoothed steps
+    within 1.5 % of the reference's, 100-step moving average within 29.4 % everywhere, final level 6.2 against the reference's
+    8.7 (the reference's single CPU run is one sample of the same spread; MI355X runs tend to end lower).  The bars are those
+    values with a margin for library updates - 5 %, 35 %, final level within 0.6-1.2x - on the curve's shape, not on per-step
+    values."""
     from lav_amd.train.run import set_deterministic
     ref = golden["train_curve"]["terms"]                       # (steps, 8)
     keys = [str(k) for k in golden["train_curve"]["keys"]]
@@ -240,9 +242,9 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     print(f"loss curve over {steps} steps: reference {smooth(tot_r, 25)[0]:.1f} -> {final_r:.1f}, MI355X {smooth(tot_o, 25)[0]:.1f} -> {final_o:.1f}; "
           f"deviation of the smoothed total: first 60 steps {early.max():.3f}, 100-step average {whole.max():.3f}")
     assert final_r < 0.3 * smooth(tot_r, 25)[0], "the reference run must actually learn for the comparison to mean something"
-    assert early.max() < 0.10, f"the first 60 smoothed steps leave the band: {early.max():.3f}"
-    assert whole.max() < 0.50, f"the 100-step moving average leaves the band: {whole.max():.3f}"
-    assert 0.5 * final_r < final_o < 1.35 * final_r, f"final level {final_o:.2f} vs the reference's {final_r:.2f}"
+    assert early.max() < 0.05, f"the first 60 smoothed steps leave the band: {early.max():.3f}"
+    assert whole.max() < 0.35, f"the 100-step moving average leaves the band: {whole.max():.3f}"
+    assert 0.6 * final_r < final_o < 1.2 * final_r, f"final level {final_o:.2f} vs the reference's {final_r:.2f}"
     # the loss terms that training drives down go down here too (detection heat-map, box, orientation, motion terms)
     for j, k in enumerate(keys):
         if ref[-100:, j].mean() < 0.5 * ref[:20, j].mean():
