@@ -201,7 +201,7 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     alternating seeded batches (tests/golden/make_golden.py:gold_train_curve, tests/golden/train_curve.npz); the MI355X
     trainer runs the same 500 steps from the same weights.
 
-What "match" can mean: step 0 is the same arithmetic (2e-3).  From then on two float32 implementations separate -
+    What "match" can mean: step 0 is the same arithmetic (2e-3).  From then on two float32 implementations separate -
     Adam's first updates are lr*sign(g), so rounding-level gradient differences (oneDNN's convolutions on the reference's CPU
     run, MIOpen's here) flip signs where g ~ 0 - and the trajectories decorrelate like any chaotic system's.  The MI355X
     trainer itself IS reproducible: every liblav_amd kernel reduces in a fixed order, and with torch / MIOpen switched to their
