@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 19
+#define LAV_ABI_VERSION 20
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -245,6 +245,17 @@ size_t lav_conv_packed_weight_floats(const lav_conv *c);
  * [cin][cout][kh][kw]) into the kernel's layout [class][cout block of 32][tap][8-channel group][lane][channel pair] -
  * the order in which the MFMA A operands are consumed, so both kernels fetch 16 bytes per lane.  Pure host code. */
 int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed);
+/* Re-packing on the device, for callers whose weights change in HBM (a training run that evaluates its student through these
+ * kernels after every optimiser step, lav/lav_final_v2.py:228-236): lav_conv_pack_map (host, once per layer) fills
+ * lav_conv_pack_map_ints(c) ints - for every slot of the packed buffer the index of the PyTorch-layout weight it holds, -1 for
+ * padding; lav_conv_repack gathers (and, for LAV_CONV_BF16X6, splits) the packed buffer from the device-resident weight with
+ * that map in one launch: bit-identical to lav_conv_pack_weights + upload.  lav_bn_fold: the eval-mode BatchNorm affine
+ * scale = gamma / sqrt(var + eps), shift = beta - mean * scale (float64 arithmetic) of n channels, on the device. */
+size_t lav_conv_pack_map_ints(const lav_conv *c);
+int lav_conv_pack_map(const lav_conv *c, int *h_map);
+int lav_conv_repack(const lav_conv *c, const float *d_weight, const int *d_map, float *d_packed, void *stream);
+int lav_bn_fold(const float *mean, const float *var, const float *gamma, const float *beta, double eps, int n, float *scale,
+                float *shift, void *stream);
 /* introspection of the launch plan (host only, no device access): info[0..8] = { MP, MC, row-blocked tiles,
  * staged tile width, staged tile rows, LDS bytes, split-K factor, taps per weight slab, chunks per stage }; small layers
  * that take the direct kernel (whole batch in one GEMM dimension, operands straight from L2, no LDS staging) report

@@ -957,6 +957,99 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
     return LAV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Re-packing on the device: where every slot of the packed buffer comes from, computed ONCE on the host by running the packers
+// above over a weight tensor that holds its own indices (exact in fp32 below 2^24, and - the split packing stores x as three bf16
+// pieces that sum to x exactly - also through the bf16x6 layout); a training run that evaluates its student through these
+// kernels after every optimiser step then re-packs each layer with one gather launch from the live parameter in HBM.
+extern "C" size_t lav_conv_pack_map_ints(const lav_conv *c) {
+    if (!c) return 0;
+    Plan p;
+    if (build_plan(*c, p)) return 0;
+    if (resolve_precision(*c) != LAV_CONV_BF16X6) return p.wfloats;
+    return (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 6;   // one entry per fp32 slot, then one per bf16 triple
+}
+
+extern "C" int lav_conv_pack_map(const lav_conv *c, int *h_map) {
+    LAV_REQUIRE(c && h_map, "lav_conv_pack_map: null");
+    Plan p;
+    int rc = build_plan(*c, p);
+    if (rc) return rc;
+    const size_t nw = (size_t)c->cout * c->cin * c->kh * c->kw;
+    LAV_REQUIRE(nw < (1u << 24), "lav_conv_pack_map: more than 2^24 weights");
+    std::vector<float> iota(nw), packed(lav_conv_packed_weight_floats(c));
+    for (size_t i = 0; i < nw; ++i) iota[i] = (float)(i + 1);
+    rc = lav_conv_pack_weights(c, iota.data(), packed.data());
+    if (rc) return rc;
+    const bool split = resolve_precision(*c) == LAV_CONV_BF16X6;
+    const size_t nf = split ? (p.wfloats + 3) / 4 * 4 : p.wfloats;
+    for (size_t i = 0; i < nf; ++i) h_map[i] = i < p.wfloats ? (int)packed[i] - 1 : -1;
+    if (split) {
+        const unsigned short *o = reinterpret_cast<const unsigned short *>(packed.data() + nf);
+        const size_t ntrip = split_weight_bytes(p) / 6;
+        auto bf = [](unsigned short h) { const unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        for (size_t j = 0; j < ntrip; ++j) {
+            const size_t frag = j / 512, within = j % 512;
+            const float v = (bf(o[frag * 1536 + within]) + bf(o[frag * 1536 + 512 + within])) + bf(o[frag * 1536 + 1024 + within]);
+            h_map[nf + j] = (int)v - 1;
+        }
+    }
+    return LAV_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_conv_repack(const float *__restrict__ w, const int *__restrict__ map, long nf, long ntrip,
+                                                     float *__restrict__ packed) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nf) {
+        const int m = map[i];
+        packed[i] = m >= 0 ? w[m] : 0.f;
+    } else if (i < nf + ntrip) {
+        const long j = i - nf;
+        const int m = map[i];
+        unsigned p0, p1, p2;
+        split3(m >= 0 ? w[m] : 0.f, p0, p1, p2);
+        unsigned short *o = reinterpret_cast<unsigned short *>(packed + nf);
+        const long frag = j / 512, within = j % 512;
+        o[frag * 1536 + within] = (unsigned short)(p0 >> 16);
+        o[frag * 1536 + 512 + within] = (unsigned short)(p1 >> 16);
+        o[frag * 1536 + 1024 + within] = (unsigned short)(p2 >> 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_fold(const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ gamma,
+                                                 const float *__restrict__ beta, double eps, int n, float *__restrict__ scale,
+                                                 float *__restrict__ shift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double s = (double)gamma[i] / sqrt((double)var[i] + eps);
+    scale[i] = (float)s;
+    shift[i] = (float)((double)beta[i] - (double)mean[i] * s);
+}
+}  // namespace
+
+extern "C" int lav_conv_repack(const lav_conv *c, const float *d_weight, const int *d_map, float *d_packed, void *stream) {
+    LAV_REQUIRE(c && d_weight && d_map && d_packed, "lav_conv_repack: null");
+    Plan p;
+    int rc = build_plan(*c, p);
+    if (rc) return rc;
+    const bool split = resolve_precision(*c) == LAV_CONV_BF16X6;
+    const long nf = split ? (long)((p.wfloats + 3) / 4 * 4) : (long)p.wfloats, ntrip = split ? (long)(split_weight_bytes(p) / 6) : 0;
+    hipLaunchKernelGGL(k_conv_repack, dim3((unsigned)((nf + ntrip + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_weight, d_map, nf,
+                       ntrip, d_packed);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_bn_fold(const float *mean, const float *var, const float *gamma, const float *beta, double eps, int n, float *scale,
+                           float *shift, void *stream) {
+    LAV_REQUIRE(mean && var && gamma && beta && scale && shift && n >= 1, "lav_bn_fold: bad argument");
+    hipLaunchKernelGGL(k_bn_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), mean, var, gamma, beta, eps, n,
+                       scale, shift);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
 extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     if (!c) return 0;
     Plan p;

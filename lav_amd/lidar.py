@@ -18,11 +18,42 @@ from .point_pillar import PointPillarNet
 _NORM = dict(eps=1e-3, momentum=0.01)
 
 
+def _refreshable(obj):
+    """Every layer object with a refresh() inside an engine (nested dicts / lists / tuples)."""
+    if isinstance(obj, dict):
+        for v in obj.values():
+            yield from _refreshable(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _refreshable(v)
+    elif hasattr(obj, "refresh"):
+        yield obj
+
+
 class _Engine(nn.Module):
-    """Mixin: cache of packed ConvLayers, dropped whenever parameters may have changed."""
+    """Mixin: cache of packed ConvLayers.  When the parameters may have changed IN PLACE (a train()/eval() toggle around optimiser
+    steps, load_state_dict) the cached engine is marked stale and re-packed on the device from the live parameters at its next use
+    (ConvLayer.refresh: one gather launch per layer - the trainer's per-step log inference, lav_final_v2.py:228-236, used to rebuild
+    ~45 layers on the host per step); when the tensors themselves may have been replaced (_apply: .to() / .float()) it is dropped."""
 
     def _drop(self):
         object.__setattr__(self, "_eng", None)
+        object.__setattr__(self, "_stale", False)
+
+    def _mark_stale(self):
+        if self.__dict__.get("_eng") is not None:
+            object.__setattr__(self, "_stale", True)
+
+    def _fresh(self, device):
+        """The cached engine for `device`, brought up to date; None when there is none."""
+        eng = self.__dict__.get("_eng")
+        if eng is None or eng.get("device") != device:
+            return None
+        if self.__dict__.get("_stale"):
+            for layer in _refreshable(eng):
+                layer.refresh()
+            object.__setattr__(self, "_stale", False)
+        return eng
 
     def _apply(self, fn, *a, **k):
         self._drop()
@@ -30,11 +61,11 @@ class _Engine(nn.Module):
 
     def train(self, mode: bool = True):
         if mode != self.training:     # packed engines only go stale when the mode really changes (or weights do: _apply / load)
-            self._drop()
+            self._mark_stale()
         return super().train(mode)
 
     def _load_from_state_dict(self, *a, **k):
-        self._drop()
+        self._mark_stale()
         return super()._load_from_state_dict(*a, **k)
 
     def _need_eval(self):
@@ -74,8 +105,9 @@ class ConvBackbone(_Engine):
         self._drop()
 
     def _engine(self, device):
-        if self._eng is not None and self._eng["device"] == device:
-            return self._eng
+        eng = self._fresh(device)
+        if eng is not None:
+            return eng
         def stage(seq):
             out = []
             for j in range(0, len(seq), 3):
@@ -149,7 +181,7 @@ class Head(_Engine):
         if self.training:
             from .train.hipnn import bn_act
             return self.output_activation(self.net[3](bn_act(self.net[2], self.net[0](x), relu_pre=True)))
-        if self._eng is None or self._eng["device"] != x.device:
+        if self._fresh(x.device) is None:
             conv, bn = self.net[0], self.net[2]
             eng = dict(device=x.device,
                        conv=ConvLayer(conv.weight, padding=1, bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True, device=x.device),
@@ -178,7 +210,7 @@ class LiDARModel(_Engine):
         """Fused engine of a subset of the heads: ONE convolution 384 -> 64*len(names) (the 39 MB feature map is read once)
         and ONE grouped transposed convolution 64*len -> sum(outputs) (lav_deconv_grouped: every head's tail reads its own
         64 channels); a sigmoid head must come last (lidar.py:30-33,159-161)."""
-        eng = self._eng if self._eng is not None and self._eng.get("device") == device else dict(device=device)
+        eng = self._fresh(device) or dict(device=device)
         if names not in eng:
             hs = [getattr(self, n) for n in names]
             for h in hs:
@@ -187,8 +219,8 @@ class LiDARModel(_Engine):
             sig = [h._sigmoid for h in hs]
             if any(sig[:-1]):
                 raise RuntimeError("fused head deconvolution expects the sigmoid head last")
-            w = torch.cat([h.net[0].weight.detach() for h in hs], dim=0)
-            bn = tuple(torch.cat([getattr(h.net[2], n).detach() for h in hs]) for n in ("running_mean", "running_var", "weight", "bias"))
+            w = lambda: torch.cat([h.net[0].weight.detach() for h in hs], dim=0)     # (callables: re-assembled by ConvLayer.refresh)
+            bn = lambda: tuple(torch.cat([getattr(h.net[2], n).detach() for h in hs]) for n in ("running_mean", "running_var", "weight", "bias"))
             cts = [h.net[3] for h in hs]
             outs = [ct.weight.shape[1] for ct in cts]
             eng[names] = dict(outs=outs,

@@ -331,6 +331,17 @@ class ConvLayer:
                  relu_pre=False, relu_post=False, sigmoid=False, in_c_total=None, in_c_offset=0, out_c_total=None, target_cus=0, pad_value=0.0,
                  out_c_offset=0, precision=0, device=None):
         lib = _lib.load()
+        # the sources are kept by reference (tensors, or callables that assemble them): refresh() re-packs from their current values
+        self._src = dict(weight=weight, bias=bias, bn=bn, bn_eps=float(bn_eps))
+        self._map = None
+        src_dev = None
+        if callable(weight):
+            weight = weight()
+        if callable(bias):
+            bias = bias()
+        if callable(bn):
+            bn = bn()
+        src_dev = weight.device
         w = weight.detach().to("cpu", torch.float32).contiguous()
         if transposed:
             cin, cout, kh, kw = w.shape
@@ -354,7 +365,7 @@ class ConvLayer:
             raise RuntimeError("lav_conv_packed_weight_floats: " + lib.lav_last_error().decode())
         packed = torch.empty(nfl, dtype=torch.float32)
         check(lib.lav_conv_pack_weights(C.byref(probe), w.data_ptr(), packed.data_ptr()), "lav_conv_pack_weights")
-        dev = device if device is not None else weight.device
+        dev = device if device is not None else src_dev
         self.w = packed.to(dev)
         self.bias = None if bias is None else bias.detach().to(dev, torch.float32).contiguous()
         self._ws_bytes = {}
@@ -364,6 +375,47 @@ class ConvLayer:
             scale = gamma / torch.sqrt(var + bn_eps)
             self.scale = scale.to(torch.float32).to(dev)
             self.shift = (beta - mean * scale).to(torch.float32).to(dev)
+
+    def refresh(self):
+        """Re-pack the weights and re-fold the epilogue vectors from the CURRENT values of the tensors this layer was built from
+        (parameters that an optimiser step or load_state_dict changed in place).  With everything resident in HBM this is one
+        gather launch (lav_conv_repack through the layer's index map) plus lav_bn_fold - no host round trip, bit-identical to
+        building the layer anew; anything else falls back to the host packer."""
+        lib = _lib.load()
+        src = self._src
+        get = lambda v: v() if callable(v) else v
+        w, bias, bn = get(src["weight"]), get(src["bias"]), get(src["bn"])
+        dev = self.w.device
+        probe = Conv.from_buffer_copy(self.desc)
+        probe.h, probe.w = 64, 64
+        if dev.type == "cuda" and w.device == dev and self._map is not False:
+            if self._map is None:
+                n = lib.lav_conv_pack_map_ints(C.byref(probe))
+                m = torch.empty(max(n, 1), dtype=torch.int32)
+                if n == 0 or lib.lav_conv_pack_map(C.byref(probe), m.data_ptr()) != 0:
+                    self._map = False
+                else:
+                    self._map = m.to(dev)
+        if dev.type == "cuda" and w.device == dev and self._map is not False and self._map is not None:
+            wd = w.detach().to(torch.float32).contiguous()
+            check(lib.lav_conv_repack(C.byref(probe), _ptr(wd), _ptr(self._map), _ptr(self.w), _stream()), "lav_conv_repack")
+        else:
+            packed = torch.empty(self.w.numel(), dtype=torch.float32)
+            wh = w.detach().to("cpu", torch.float32).contiguous()
+            check(lib.lav_conv_pack_weights(C.byref(probe), wh.data_ptr(), packed.data_ptr()), "lav_conv_pack_weights")
+            self.w.copy_(packed)
+        if self.bias is not None:
+            self.bias.copy_(bias.detach())
+        if bn is not None:
+            if dev.type == "cuda" and all(t.device == dev for t in bn):
+                mean, var, gamma, beta = [t.detach().to(torch.float32).contiguous() for t in bn]
+                check(lib.lav_bn_fold(_ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), src["bn_eps"], mean.numel(), _ptr(self.scale),
+                                      _ptr(self.shift), _stream()), "lav_bn_fold")
+            else:
+                mean, var, gamma, beta = [t.detach().to("cpu", torch.float64) for t in bn]
+                scale = gamma / torch.sqrt(var + src["bn_eps"])
+                self.scale.copy_(scale.to(torch.float32))
+                self.shift.copy_((beta - mean * scale).to(torch.float32))
 
     @classmethod
     def from_module(cls, conv, bn=None, bn_slice=None, **kw):
@@ -436,12 +488,24 @@ class GroupedDeconv:
         self.outs = [ct.out_channels for ct in deconvs]
         if max(self.outs) > 8 or self.groups > 8:
             raise RuntimeError("GroupedDeconv: at most 8 groups of at most 8 output channels")
-        self.w = torch.cat([ct.weight.detach().to(torch.float32).reshape(-1).cpu() for ct in deconvs]).to(dev)
-        self.bias = None
-        if ct0.bias is not None:
-            self.bias = torch.cat([ct.bias.detach().to(torch.float32).cpu() for ct in deconvs]).to(dev)
+        self._deconvs, self._dev = list(deconvs), dev
+        self.w = self.bias = None
+        self.refresh()
         self._outs_c = (C.c_int * self.groups)(*self.outs)
         self.sigmoid_from = -2 if softmax else int(sigmoid_from)     # -2: softmax over each group's channels, in the epilogue
+
+    def refresh(self):
+        """(Re-)read the layers' parameters: concatenated where they live, moved once."""
+        w = torch.cat([ct.weight.detach().to(torch.float32).reshape(-1) for ct in self._deconvs]).to(self._dev)
+        b = None
+        if self._deconvs[0].bias is not None:
+            b = torch.cat([ct.bias.detach().to(torch.float32) for ct in self._deconvs]).to(self._dev)
+        if self.w is None:
+            self.w, self.bias = w, b
+        else:   # in place: captured graphs hold these addresses
+            self.w.copy_(w)
+            if b is not None:
+                self.bias.copy_(b)
 
     def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None):
         x = _f32c(x, "x")

@@ -47,8 +47,9 @@ class ResNet(_Engine):
         self._drop()
 
     def _engine(self, device):
-        if self._eng is not None and self._eng["device"] == device:
-            return self._eng
+        eng = self._fresh(device)
+        if eng is not None:
+            return eng
         def cl(conv, bn, **kw):
             return ConvLayer(conv.weight, stride=conv.stride[0], padding=conv.padding, bn=_bn_tuple(bn), bn_eps=bn.eps,
                              device=device, target_cus=getattr(self, "target_cus", 0), **kw)

@@ -304,3 +304,42 @@ def test_grouped_deconv_rejects_unsupported_geometry_before_any_launch():
     outs = (C.c_int * 2)(3, 4)
     assert lib.lav_deconv_grouped(1, 64, 8, 8, 2, outs, 4, 2, 1, 0, dummy, dummy, None, -1, dummy, None) != 0   # 4x4 kernel
     assert lib.lav_deconv_grouped(1, 65, 8, 8, 2, outs, 3, 2, 1, 1, dummy, dummy, None, -1, dummy, None) != 0   # 65 % 2
+
+
+@pytest.mark.parametrize("case", [(64, 128, 3, 2, False), (384, 256, 3, 1, False), (128, 64, 3, 2, True), (3, 64, 7, 2, False), (130, 37, 1, 1, False)])
+def test_pack_map_reproduces_the_host_packing_bit_for_bit(case):
+    """lav_conv_pack_map (the index map lav_conv_repack gathers with on the device) applied to a random weight on the host
+    - gather, then the three-piece bf16 split restated in numpy - gives exactly lav_conv_pack_weights' buffer."""
+    import numpy as np
+    cin, cout, k, s, tr = case
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    w = rng.standard_normal((cin, cout, k, k) if tr else (cout, cin, k, k)).astype(np.float32)
+    for prec in (_lib.CONV_F32, _lib.CONV_BF16X6):
+        d = _lib.Conv(1, cin, 0, cin, 64, 64, cout, k, k, s, k // 2, k // 2, 1, 1, int(tr), 1 if tr else 0, cout, 0, 0, 0, 0, 0, 0.0, prec)
+        nfl = lib.lav_conv_packed_weight_floats(C.byref(d))
+        packed = np.zeros(nfl, np.float32)
+        assert lib.lav_conv_pack_weights(C.byref(d), w.ctypes.data, packed.ctypes.data) == 0
+        nm = lib.lav_conv_pack_map_ints(C.byref(d))
+        m = np.zeros(nm, np.int32)
+        assert lib.lav_conv_pack_map(C.byref(d), m.ctypes.data) == 0
+        flat = np.concatenate([w.reshape(-1), np.zeros(1, np.float32)])          # index -1 -> 0
+        if prec == _lib.CONV_F32:
+            assert nm == nfl
+            assert np.array_equal(flat[m].view(np.uint32), packed.view(np.uint32))
+            continue
+        # nm = nf + ntrip and nfl * 4 = nf * 4 + ntrip * 6
+        ntrip = (nfl * 4 - nm * 4) // 2
+        nf = nm - ntrip
+        assert nf * 4 + ntrip * 6 == nfl * 4
+        assert np.array_equal(flat[m[:nf]].view(np.uint32), packed[:nf].view(np.uint32))
+        v = flat[m[nf:]]
+        def piece(x):
+            u = (x.view(np.uint32).astype(np.uint64) + 0x8000) & 0xffff0000
+            return u.astype(np.uint32)
+        p0 = piece(v); r1 = v - p0.view(np.float32)
+        p1 = piece(r1); r2 = r1 - p1.view(np.float32)
+        p2 = piece(r2)
+        want = packed[nf:].view(np.uint16).reshape(-1, 3, 512)
+        got = np.stack([(p >> 16).astype(np.uint16).reshape(-1, 512) for p in (p0, p1, p2)], axis=1)
+        assert np.array_equal(got, want)

@@ -115,3 +115,55 @@ def test_split_operand_convolution_is_as_accurate_as_fp32(case):
         errs[label] = ((y - want).abs() / mag).max().item()
     print(name, errs)
     assert errs["f32"] < 2e-6 and errs["bf16x6"] < 2e-6, errs
+
+
+@pytest.mark.parametrize("prec", [_lib.CONV_F32, _lib.CONV_BF16X6])
+@pytest.mark.parametrize("case", [(64, 128, 3, 2, False), (128, 64, 4, 2, True), (384, 256, 3, 1, False)])
+def test_conv_layer_refresh_repacks_on_the_device_bit_for_bit(case, prec):
+    """ConvLayer.refresh (lav_conv_repack + lav_bn_fold: the trainer's per-step log inference re-packs its student this way)
+    after an in-place parameter update == a layer built anew from the updated parameters: packed weights, bias, BatchNorm affine."""
+    cin, cout, k, s, tr = case
+    torch.manual_seed(8)
+    w = torch.nn.Parameter(torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device=DEV) * 0.05)
+    bias = torch.nn.Parameter(torch.randn(cout, device=DEV))
+    bn = tuple(t.to(DEV) for t in (torch.randn(cout), torch.rand(cout) + 0.5, torch.rand(cout) + 0.5, torch.randn(cout)))
+    kw = dict(stride=s, padding=(1, 1), transposed=tr, bias=bias, bn=bn, bn_eps=1e-3, relu_pre=True, precision=prec, device=DEV)
+    layer = ops.ConvLayer(w, **kw)
+    with torch.no_grad():
+        w.add_(torch.randn_like(w) * 0.01); bias.mul_(1.1)
+        for t in bn:
+            t.add_(0.01)
+    layer.refresh()
+    fresh = ops.ConvLayer(w, **kw)
+    assert torch.equal(layer.w.view(torch.int32), fresh.w.view(torch.int32))
+    assert torch.equal(layer.bias, fresh.bias) and torch.equal(layer.scale, fresh.scale) and torch.equal(layer.shift, fresh.shift)
+
+
+def test_engines_follow_in_place_parameter_updates_across_train_eval_toggles():
+    """The trainer's pattern (lav_amd/train/lav.py:mot_inference): eval-mode inference, train(), an optimiser step in place,
+    eval() again - the cached engines are re-packed on the device and give what a model built from the new weights gives."""
+    import copy
+    import lav_amd
+    from tests.util import CFG, state_dicts
+    lm = lav_amd.LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **CFG)
+    lm.load_state_dict(state_dicts()[0])
+    lm = lm.to(DEV).eval()
+    x = torch.randn(1, 64, 320, 320, device=DEV).relu()
+    with torch.no_grad():
+        f0 = lm.backbone(x); h0 = lm.heads(f0)
+        lm.train()
+        for p in lm.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+        for m in lm.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.add_(0.05); m.running_var.mul_(1.2)
+        lm.eval()
+        f1 = lm.backbone(x); h1 = lm.heads(f1)
+        ref = lav_amd.LiDARModel(num_input=16, backbone="cnn", num_features=[64, 64], **CFG)
+        ref.load_state_dict(copy.deepcopy(lm.state_dict()))
+        ref = ref.to(DEV).eval()
+        f2 = ref.backbone(x); h2 = ref.heads(f2)
+    assert not torch.equal(f0, f1)
+    assert torch.equal(f1, f2)
+    for a, b in zip(h1, h2):
+        assert torch.equal(a, b)
