@@ -121,8 +121,9 @@ def train_bench(args):
     (strong scaling: 32 / N resp. 64 / N samples per GPU; `--batch B` fixes the per-GPU batch instead = weak scaling).
     One step = forward + backward + Adam, plus - for train_full - the reference's eval-mode inference of sample 0 that
     feeds its log (lav_final_v2.py:228-236) every `--log-every` steps: 1 = the reference's cadence (it runs it on every
-    step and logs every 100th), 100 = only on the steps that are logged.  Dense layers run on torch autograd
-    (MIOpen/rocBLAS): a measured baseline for the training row, not a hand-kernel number."""
+    step and logs every 100th), 100 = only on the steps that are logged.  Convolutions and Linear layers run on torch autograd
+    (MIOpen / rocBLAS); BatchNorm + ReLU (+ residual), the pillar front end, scatter-max, the crops and the GRU recurrences are
+    liblav_amd kernels."""
     from lav_amd.train import TrainConfig
     from lav_amd.train.run import train_loop
     what = "lidar" if args.mode == "train_full" else "bev"
@@ -153,7 +154,7 @@ def train_bench(args):
                         hand_kernels_ms_per_step={n: round(v["ms_per_step"], 3) for n, v in hk["kernels"].items()},
                         gru_seq_tflops={d: round(hk["work_per_step"][f"gru_seq_{d}_flops"] / (hk["kernels"][f"gru_seq_{d}"]["ms_per_step"] * 1e-3) / 1e12, 2)
                                         for d in ("forward", "backward") if f"gru_seq_{d}" in hk["kernels"]},
-                        note="convolutions and BatchNorm of the step run on MIOpen (56 % + 8 % of its GPU time): this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
+                        note="the convolutions of the step run on MIOpen (~55 % of its GPU time, profiles/r03_train_full_kernel_top.txt; BatchNorm + ReLU are the fused lav_bn_train_* pairs): this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
     elif rank == 0 and hk and any(n.startswith("gru_seq") for n in hk["kernels"]):
         # no crop gradient in this step: the sequence GRU (recurrent GEMM on MFMA fused with the gates, one launch per time step)
         name = max((n for n in hk["kernels"] if n.startswith("gru_seq")), key=lambda n: hk["kernels"][n]["ms_per_step"])
@@ -164,12 +165,19 @@ def train_bench(args):
                         algorithmic_flops=hk["work_per_step"][f"{name}_flops"] / max(k["calls_per_step"], 1e-9), avg_kernel_us=round(k["ms_per_call"] * 1e3, 1),
                         launches=int(round(k["calls_per_step"] * 2)),
                         hand_kernels_ms_per_step={n: round(v["ms_per_step"], 3) for n, v in hk["kernels"].items()},
-                        note="a step of these GRUs is a 192..400 x 512 x 1536 GEMM: latency-bound, not matrix-bound; convolutions and BatchNorm of the "
-                             "step run on MIOpen: this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
+                        note="a step of these GRUs is a 192..400 x 512 x 1536 GEMM: latency-bound, not matrix-bound; the convolutions of the "
+                             "step run on MIOpen (BatchNorm + ReLU: the fused lav_bn_train_* pairs): this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
+    if rank == 0 and roofline is not None and hk and "bn_train_fwd" in hk["kernels"]:
+        # the fused train-mode BatchNorm + ReLU (+ residual) pairs (lav_bn_train_*): HBM bound, algorithmic bytes = passes over the activation
+        for d in ("fwd", "bwd"):
+            k = hk["kernels"][f"bn_train_{d}"]
+            gbs = hk["work_per_step"][f"bn_train_{d}_bytes"] / (k["ms_per_step"] * 1e-3) / 1e9
+            roofline[f"bn_train_{d}"] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                                             ms_per_step=round(k["ms_per_step"], 3), launch_pairs_per_step=round(k["calls_per_step"], 1))
     if rank == 0:
         print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
-                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32 (torch autograd / MIOpen for the dense layers)", data="synthetic",
+                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32 (convolutions: torch autograd / MIOpen; BatchNorm+ReLU, pillar, crop, GRU: liblav_amd)", data="synthetic",
                               config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
                                           + (f", 120000-point clouds, 320x320 maps; log-only eval inference every {args.log_every} step(s)"
                                              if what == "lidar" else ", (9,320,320) BEV"),

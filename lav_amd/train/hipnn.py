@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
+from .. import ops as ops_mod
 from ..ops import _ptr, _stream, check
 
 _WS = {}
@@ -44,6 +45,7 @@ class _BnAct(torch.autograd.Function):
         check(_lib.load().lav_bn_train_forward(_ptr(x), _ptr(res), _ptr(y), B, C, H * W, _ptr(gamma.contiguous()), _ptr(beta.contiguous()),
                                                float(eps), int(relu_pre), int(relu_post), _ptr(save[0]), _ptr(save[1]), _ptr(save[2]),
                                                _ptr(ws), ws.numel(), _stream()), "lav_bn_train_forward")
+        ops_mod.train_work["bn_train_fwd_bytes"] += 4 * x.numel() * (3 + (res is not None))     # x twice, y once (+ the residual)
         ctx.save_for_backward(x, y if relu_post else None, gamma, save)
         ctx.cfg = (bool(relu_pre), bool(relu_post), residual is not None)
         mean, var = save[0], save[1]
@@ -64,6 +66,8 @@ class _BnAct(torch.autograd.Function):
         check(_lib.load().lav_bn_train_backward(_ptr(x), _ptr(y), _ptr(dy), B, C, H * W, _ptr(gamma.contiguous()), _ptr(save[0]), _ptr(save[2]),
                                                 int(relu_pre), int(relu_post), _ptr(dx), _ptr(dres), _ptr(dgb[0]), _ptr(dgb[1]),
                                                 _ptr(ws), ws.numel(), _stream()), "lav_bn_train_backward")
+        # x and dy twice, dx once; relu_post reads y (twice without a residual, else once + the masked gradient written and re-read)
+        ops_mod.train_work["bn_train_bwd_bytes"] += 4 * x.numel() * (5 + (2 if relu_post else 0))
         return dx, dgb[0], dgb[1], (dres if dres is not None else dy) if has_res else None, None, None, None
 
 
