@@ -350,7 +350,7 @@ int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const floa
  *     y [batch][channels][(h-1)/2+1][(w-1)/2+1]; honours lav_batch_limit.
  * lav_channel_affine: y = x * scale[c] + shift[c] on [batch][channels][plane] (plane % 4 == 0): the brake net's
  *     `normalize(rgb / 255)` (team_code_v2/models/rgb.py:71-72) in one pass.
- * lav_copy_many: up to 8 device-to-device copies (16-byte aligned, sizes multiples of 16) in ONE launch: a tick's sensor tensors
+ * lav_copy_many: up to 8 device-to-device copies (16-byte aligned pointers, sizes multiples of 4) in ONE launch: a tick's sensor tensors
  *     into the static buffers the frame graphs read (lav_agent_fast.py:233-277 hands them over as fresh tensors). */
 int lav_maxpool3x3s2(const float *x, int batch, int channels, int h, int w, float *y, void *stream);
 int lav_channel_affine(const float *x, int batch, int channels, long plane, const float *scale, const float *shift, float *y, void *stream);

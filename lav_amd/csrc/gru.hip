@@ -558,7 +558,7 @@ extern "C" size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T
     // step-per-launch path: h sequence [T][R][H] floats; persistent path: 2 granule buffers [R][H] u64 + status word
     // (+ many-row path: initial state [R][H] and inputs [R][T][4])
     const size_t seq = ((size_t)T * B * num_cmds * H + (size_t)B * num_cmds * H + (size_t)B * num_cmds * T * 4) * sizeof(float) + 512;
-    const size_t gran = 2 * (size_t)PLAN_RC * H * sizeof(unsigned long long) + 256;
+    const size_t gran = lav::align_up(2 * (size_t)PLAN_RC * H * sizeof(unsigned long long), 256) + 256;
     return lav::align_up(seq > gran ? seq : gran, 256);
 }
 
@@ -588,10 +588,10 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
     if (allow_persistent && a.R <= PLAN_RC && !(impl && impl[0] == 's')) {
         // persistent kernel: needs its H/8 workgroups co-resident (64 of 256 CUs) - always true on an MI355X
         const size_t gbytes = 2 * (size_t)a.R * H * sizeof(unsigned long long);
-        LAV_REQUIRE(workspace_bytes >= gbytes + 256, "lav_gru_plan: workspace too small for the persistent kernel");
+        LAV_REQUIRE(workspace_bytes >= lav::align_up(gbytes, 256) + 256, "lav_gru_plan: workspace too small for the persistent kernel");
         unsigned long long *gran = static_cast<unsigned long long *>(workspace);
         int *status = reinterpret_cast<int *>(static_cast<char *>(workspace) + lav::align_up(gbytes, 256));
-        LAV_HIP(hipMemsetAsync(workspace, 0, lav::align_up(gbytes, 256) + 4, st));  // tags and status start at 0
+        LAV_HIP(hipMemsetAsync(workspace, 0, lav::align_up(gbytes, 256) + 256, st));  // tags and status start at 0 (a whole number of 256-byte lines: one fill kernel)
         const char *lim = getenv("LAV_PLAN_SPIN_LIMIT");   // test knob: 1 forces the time-out path
         const long long spin_limit = lim && atoll(lim) > 0 ? atoll(lim) : PLAN_SPIN_LIMIT;
         hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit);

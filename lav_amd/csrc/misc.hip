@@ -179,7 +179,8 @@ constexpr int COPY_MAX = 8;
 struct CopyArgs {
     const char *src[COPY_MAX];
     char *dst[COPY_MAX];
-    long end16[COPY_MAX];   // running total of 16-byte words after copy i
+    long end16[COPY_MAX];   // running total of 16-byte words (the last one of a copy may be partial) after copy i
+    int tail[COPY_MAX];     // bytes in the last word of copy i (4, 8, 12 or 16)
     int n;
 };
 __global__ __launch_bounds__(256) void k_copy_many(CopyArgs a) {
@@ -188,7 +189,11 @@ __global__ __launch_bounds__(256) void k_copy_many(CopyArgs a) {
     while (k < a.n && w >= a.end16[k]) ++k;
     if (k >= a.n) return;
     const long off = (w - (k ? a.end16[k - 1] : 0)) * 16;
-    *reinterpret_cast<float4 *>(a.dst[k] + off) = *reinterpret_cast<const float4 *>(a.src[k] + off);
+    if (w + 1 < a.end16[k] || a.tail[k] == 16) {
+        *reinterpret_cast<float4 *>(a.dst[k] + off) = *reinterpret_cast<const float4 *>(a.src[k] + off);
+    } else {
+        for (int b = 0; b < a.tail[k]; b += 4) *reinterpret_cast<float *>(a.dst[k] + off + b) = *reinterpret_cast<const float *>(a.src[k] + off + b);
+    }
 }
 }  // namespace
 
@@ -221,11 +226,12 @@ extern "C" int lav_copy_many(int n, const void *const *src, void *const *dst, co
     long total = 0;
     for (int i = 0; i < COPY_MAX; ++i) {
         if (i < n) {
-            LAV_REQUIRE(src[i] && dst[i] && bytes[i] % 16 == 0 && ((size_t)src[i] | (size_t)dst[i]) % 16 == 0, "lav_copy_many: copy %d is not 16-byte aligned / sized", i);
+            LAV_REQUIRE(src[i] && dst[i] && bytes[i] % 4 == 0 && ((size_t)src[i] | (size_t)dst[i]) % 16 == 0, "lav_copy_many: copy %d is not 16-byte aligned / a multiple of 4 bytes", i);
             a.src[i] = static_cast<const char *>(src[i]); a.dst[i] = static_cast<char *>(dst[i]);
-            total += (long)(bytes[i] / 16);
+            total += (long)((bytes[i] + 15) / 16);
+            a.tail[i] = bytes[i] % 16 ? (int)(bytes[i] % 16) : 16;
         } else {
-            a.src[i] = nullptr; a.dst[i] = nullptr;
+            a.src[i] = nullptr; a.dst[i] = nullptr; a.tail[i] = 16;
         }
         a.end16[i] = total;
     }

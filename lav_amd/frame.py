@@ -340,22 +340,23 @@ class GraphedFramePipeline(FramePipeline):
                           f"growing them to {new_p} and re-capturing the frame graphs")
             self.overflow_ticks += 1
             self._grow(new_p)
-        self.b_tick[:n].copy_(lidar[:n], non_blocking=True)
-        if n < self.P:
-            self.b_tick[n:].fill_(float("nan"))
         if self.prev_lidar is None:                      # first frame only stashes the tick (lav_agent_fast.py:235-237)
+            self.b_tick[:n].copy_(lidar[:n], non_blocking=True)
+            if n < self.P:
+                self.b_tick[n:].fill_(float("nan"))
             self.b_prev.copy_(self.b_tick)
             self.prev_lidar = True
             return None
-        # the tick's camera tensors into the graphs' static buffers: one launch (tensors that are not float32 / contiguous /
-        # device resident take Tensor.copy_ inside copy_many)
-        pairs = [(self.b_all_rgbs, all_rgbs), (self.b_rgbs, rgbs), (self.b_tel, tel_rgbs)]
+        # the tick's LiDAR rows, camera tensors and next waypoint into the graphs' static buffers: one launch (tensors that are
+        # not float32 / contiguous / device resident take Tensor.copy_ inside copy_many)
+        pairs = [(self.b_tick[:n], lidar[:n]), (self.b_all_rgbs, all_rgbs), (self.b_rgbs, rgbs), (self.b_tel, tel_rgbs), (self.b_nxp, nxps)]
         if all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.shape == b.shape for b, t in pairs):
             ops.copy_many(pairs)
         else:
             for b, t in pairs:
                 b.copy_(t, non_blocking=True)
-        self.b_nxp.copy_(nxps, non_blocking=True)
+        if n < self.P:
+            self.b_tick[n:].fill_(float("nan"))
         self.poses.append((np.asarray(loc, np.float64), float(ori)))
         if len(self.poses) > self.num_frame_keep:
             self.poses.popleft()

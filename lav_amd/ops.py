@@ -673,7 +673,7 @@ def copy_many(pairs) -> None:
     for dst, src in pairs:
         nb = dst.numel() * dst.element_size()
         if (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype and src.numel() == dst.numel()
-                and nb % 16 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
+                and nb % 4 == 0 and nb > 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
             srcs.append(src.data_ptr()); dsts.append(dst.data_ptr()); sizes.append(nb)
         else:
             dst.copy_(src, non_blocking=True)

@@ -160,8 +160,12 @@ class RGBBrakePredictionModel(nn.Module):
         if not self.training and rgb1.is_cuda and rgb1.dtype == torch.float32 and rgb1.shape[2] * rgb1.shape[3] % 4 == 0 \
                 and rgb2.shape[2] * rgb2.shape[3] % 4 == 0:
             # normalize(rgb / 255) = rgb * (1 / (255 std)) - mean / std: one launch per image instead of three
-            std, mean = self.normalize.std.detach().double(), self.normalize.mean.detach().double()
-            s_, t_ = (1.0 / (255.0 * std)).float(), (-mean / std).float()
+            st = self.__dict__.get("_norm_affine")      # (constants of the module: computed once per device, not per frame)
+            if st is None or st[0].device != rgb1.device:
+                std, mean = self.normalize.std.detach().double(), self.normalize.mean.detach().double()
+                st = ((1.0 / (255.0 * std)).float().reshape(-1).to(rgb1.device), (-mean / std).float().reshape(-1).to(rgb1.device))
+                object.__setattr__(self, "_norm_affine", st)
+            s_, t_ = st
             x1 = self.conv_backbone(ops.channel_affine(rgb1, s_, t_))
             x2 = self.conv_backbone(ops.channel_affine(rgb2, s_, t_))
         else:

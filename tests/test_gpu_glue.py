@@ -44,12 +44,16 @@ def test_linear_act_vs_torch(B, K, O, sig):
 
 def test_copy_many_copies_every_pair_in_one_launch():
     torch.manual_seed(4)
-    srcs = [torch.randn(n, device=DEV) for n in (4, 1024, 3 * 288 * 256, 36, 8, 16, 20, 400, 12, 64)]   # 10 pairs: two launches
-    dsts = [torch.zeros_like(s) for s in srcs]
-    odd_src, odd_dst = torch.randn(7, device=DEV), torch.zeros(7, device=DEV)                            # not 16-byte sized: copy_ fallback
+    srcs = [torch.randn(n, device=DEV) for n in (4, 1024, 3 * 288 * 256, 36, 2, 7, 20, 400, 13, 64)]    # 10 pairs: two launches; 8 / 28 / 52 bytes: partial last word
+    dsts = [torch.full_like(s, 9.0) for s in srcs]
+    guard = [torch.full((s.numel() + 8,), 5.0, device=DEV) for s in srcs]                                # nothing past the end may be written
+    dsts = [g[:s.numel()] for g, s in zip(guard, srcs)]
+    odd_src, odd_dst = torch.randn(9, device=DEV)[1:], torch.zeros(8, device=DEV)                        # misaligned source: copy_ fallback
     ops.copy_many(list(zip(dsts, srcs)) + [(odd_dst, odd_src)])
     for d, s in zip(dsts + [odd_dst], srcs + [odd_src]):
         assert torch.equal(d, s)
+    for g, s in zip(guard, srcs):
+        assert bool((g[s.numel():] == 5.0).all())
 
 
 def test_grouped_deconv_softmax_epilogue_is_softmax_of_the_transposed_convolution():
