@@ -350,7 +350,7 @@ class GraphedFramePipeline(FramePipeline):
         # the tick's LiDAR rows, camera tensors and next waypoint into the graphs' static buffers: one launch (tensors that are
         # not float32 / contiguous / device resident take Tensor.copy_ inside copy_many)
         pairs = [(self.b_tick[:n], lidar[:n]), (self.b_all_rgbs, all_rgbs), (self.b_rgbs, rgbs), (self.b_tel, tel_rgbs), (self.b_nxp, nxps)]
-        if all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.shape == b.shape for b, t in pairs):
+        if all(isinstance(t, torch.Tensor) and t.is_cuda and t.shape == b.shape for b, t in pairs):
             ops.copy_many(pairs)
         else:
             for b, t in pairs:

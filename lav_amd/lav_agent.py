@@ -169,10 +169,13 @@ class LAVAgent(AutonomousAgent):
         # camera images: BGRA uint8 -> RGB float, three views side by side for the brake net, stacked for ERFNet
         bgr = [torch.from_numpy(np.ascontiguousarray(input_data.get(f"RGB_{i}")[1][..., :3])) for i in range(len(CAMERA_YAWS))]
         views = torch.stack(bgr).to(self.device).flip(-1)                             # (3,288,256,3) RGB
-        all_rgbs = views.permute(0, 3, 1, 2).float()
-        rgbs = torch.cat(list(views), dim=1)[None].permute(0, 3, 1, 2).float()        # (1,3,288,768)
+        # The graphed pipeline copies every tensor into a static float32 NCHW buffer anyway: it gets the uint8 HWC views and that
+        # copy is the conversion (one kernel per tensor instead of .float() + a layout copy); the eager pipeline takes floats.
+        as_input = (lambda t: t) if self.hip_graphs else (lambda t: t.float())
+        all_rgbs = as_input(views.permute(0, 3, 1, 2))
+        rgbs = as_input(torch.cat(list(views), dim=1)[None].permute(0, 3, 1, 2))      # (1,3,288,768)
         tel = torch.from_numpy(np.ascontiguousarray(input_data.get("TEL_RGB")[1][..., :3])).to(self.device).flip(-1)
-        tel_rgbs = tel[:-self.crop_tel_bottom][None].permute(0, 3, 1, 2).float()      # (1,3,192,480)
+        tel_rgbs = as_input(tel[:-self.crop_tel_bottom][None].permute(0, 3, 1, 2))    # (1,3,192,480)
 
         # high-level command and next route point (:280-307)
         if self.waypointer is None:
