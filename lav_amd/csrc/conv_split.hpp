@@ -541,6 +541,9 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
     const int nchunks = p.cin_pad / 16;
     int min_taps = p.taps_per_class;   // transposed convolutions: the output-parity classes have different tap counts
     for (auto &t : p.taps) min_taps = std::min<int>(min_taps, (int)t.size());
+    // An output-parity class without taps (kernel < stride, e.g. the adjoint of a 1x1 stride-2 convolution) has no weights:
+    // the loaders' unconditional prologue loads would read past the packed buffer.  Such layers stay on the fp32 kernels.
+    if (min_taps < 1) return best;
     const size_t LDS_MAX = 160 * 1024;
     const int shapes[6][3] = {{2, 2, 2}, {2, 2, 4}, {1, 2, 4}, {1, 2, 2}, {1, 1, 4}, {1, 1, 2}};   // MP, MC, WPX (ties: first wins)
     for (auto &sh : shapes) {

@@ -343,3 +343,15 @@ def test_pack_map_reproduces_the_host_packing_bit_for_bit(case):
         want = packed[nf:].view(np.uint16).reshape(-1, 3, 512)
         got = np.stack([(p >> 16).astype(np.uint16).reshape(-1, 512) for p in (p0, p1, p2)], axis=1)
         assert np.array_equal(got, want)
+
+
+def test_split_kernel_is_never_planned_for_classes_without_taps():
+    """A transposed convolution whose kernel is smaller than its stride has output-parity classes with no tap; the split-operand
+    kernel streams weights unconditionally and must not be chosen for them (any batch / size)."""
+    lib = _lib.load()
+    for cin, cout in ((64, 128), (128, 64), (512, 256)):
+        for B, H in ((1, 12), (57, 12), (16, 48), (4, 160)):
+            d = Conv(B, cin, 0, cin, H, H, cout, 1, 1, 2, 0, 0, 1, 1, 1, 1, cout, 0, 0, 0, 0, 0, 0.0, _lib.CONV_BF16X6)
+            info = (C.c_int * 9)()
+            assert lib.lav_conv_tile_info(C.byref(d), info) == 0
+            assert info[0] != -1, (cin, cout, B, H, list(info))

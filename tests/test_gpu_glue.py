@@ -171,3 +171,23 @@ def test_engines_follow_in_place_parameter_updates_across_train_eval_toggles():
     assert torch.equal(f1, f2)
     for a, b in zip(h1, h2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,cin,cout,H", [(57, 128, 64, 12), (2, 256, 128, 6), (16, 64, 32, 40)])
+def test_transposed_convolution_with_empty_parity_classes(B, cin, cout, H):
+    """ConvTranspose2d(k=1, stride=2, output_padding=1) - the adjoint of ResNet's 1x1 stride-2 down-sampling convolutions: three
+    of the four output-parity classes have no tap at all (zeros).  The split-operand kernel's loaders would read past the packed
+    weights there (found by tools/train_conv_probe.py as a memory fault): such layers must plan onto the fp32 kernels."""
+    torch.manual_seed(9)
+    w = torch.randn(cin, cout, 1, 1) / cin ** 0.5
+    x = torch.randn(B, cin, H, H)
+    want = F.conv_transpose2d(x.double(), w.double(), None, 2, 0, 1)
+    layer = ops.ConvLayer(w, stride=2, padding=(0, 0), transposed=True, output_padding=1, device=DEV)
+    d = _lib.Conv.from_buffer_copy(layer.desc); d.batch, d.h, d.w = B, H, H
+    import ctypes
+    info = (ctypes.c_int * 9)()
+    assert _lib.load().lav_conv_tile_info(ctypes.byref(d), info) == 0 and info[0] != -1
+    for _ in range(3):
+        got = layer(x.to(DEV))
+    torch.cuda.synchronize()
+    assert (got.double().cpu() - want).abs().max().item() < 1e-5

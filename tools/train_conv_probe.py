@@ -18,6 +18,9 @@ from lav_amd.ops import ConvLayer  # noqa: E402
 from lav_amd.train import LAV, TrainConfig, synthetic_lidar_batch  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+SKIP = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # skip the first SKIP shapes (to get at a late one quickly)
+VERBOSE = len(sys.argv) > 3                                   # print every sub-step before it runs (locating a fault)
+say = (lambda *a: print("   ...", *a, flush=True)) if VERBOSE else (lambda *a: None)
 dev = torch.device("cuda")
 lav = LAV(TrainConfig(), dev, what="lidar")
 batch = synthetic_lidar_batch(B, device=dev)
@@ -58,9 +61,10 @@ def ev(fn, reps=3):
 
 tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0, lav_fwd=0.0, lav_dgrad=0.0, bn=0.0)
 print(f"batch {B}: unique shapes {len(seen)}", flush=True)
-for key, cnt in sorted(seen.items(), key=lambda kv: -kv[1]):
-    if cnt == 0:
+for idx, (key, cnt) in enumerate(sorted(seen.items(), key=lambda kv: -kv[1])):
+    if cnt == 0 or idx < SKIP:
         continue
+    say(idx, key)
     if key[0] == "BatchNorm2d":
         x = torch.randn(key[1], device=dev)
         bn = nn.BatchNorm2d(key[1][1]).to(dev).train()
@@ -77,18 +81,23 @@ for key, cnt in sorted(seen.items(), key=lambda kv: -kv[1]):
     x = torch.randn(xs, device=dev)
     w = torch.randn((cin, cout, *k) if tr else (cout, cin, *k), device=dev) / (cin * k[0] * k[1]) ** 0.5
     fn = (lambda a, ww: F.conv_transpose2d(a, ww, None, s, p, op, 1, d)) if tr else (lambda a, ww: F.conv2d(a, ww, None, s, p, d))
+    say("torch forward")
     y = fn(x, w)
+    torch.cuda.synchronize()
     dy = torch.randn_like(y)
     flops = 2.0 * y.numel() * cin * k[0] * k[1] / ((s[0] * s[1]) if tr else 1)
     t_f = ev(lambda: fn(x, w))
     xg = x.clone().requires_grad_(True)
     wg = w.clone().requires_grad_(True)
     yx = fn(xg, w)
+    say("torch dgrad")
     t_d = ev(lambda: torch.autograd.grad(yx, xg, dy, retain_graph=True))
     yw = fn(x, wg)
+    say("torch wgrad")
     t_w = ev(lambda: torch.autograd.grad(yw, wg, dy, retain_graph=True))
     # lav forward, and the data gradient as the adjoint plan
     lf = ConvLayer(w.cpu(), stride=s[0], padding=p, dilation=d, transposed=tr, output_padding=op[0], device=dev)
+    say("lav forward")
     t_lf = ev(lambda: lf(x))
     err_f = (lf(x) - y).abs().max().item()
     if tr:
@@ -97,6 +106,7 @@ for key, cnt in sorted(seen.items(), key=lambda kv: -kv[1]):
         oph = xs[2] - ((y.shape[2] - 1) * s[0] - 2 * p[0] + d[0] * (k[0] - 1) + 1)
         ld = ConvLayer(w.cpu(), stride=s[0], padding=p, dilation=d, transposed=True, output_padding=oph, device=dev)
     gx = torch.autograd.grad(yx, xg, dy, retain_graph=True)[0]
+    say("lav adjoint")
     try:
         t_ld = ev(lambda: ld(dy))
         err_d = (ld(dy) - gx).abs().max().item()
