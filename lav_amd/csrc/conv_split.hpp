@@ -55,18 +55,6 @@ struct SplitArgs {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate); n is rounded DOWN to a multiple
-// of 3 (the DMA wave issues three pieces per fragment), which only waits for a little more
-__device__ __forceinline__ void wait_vmcnt_le(int n) {
-    switch (min(n, 63) / 3) {
-#define LAV_W(k) case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * k) : "memory"); break;
-        LAV_W(0) LAV_W(1) LAV_W(2) LAV_W(3) LAV_W(4) LAV_W(5) LAV_W(6) LAV_W(7) LAV_W(8) LAV_W(9) LAV_W(10)
-        LAV_W(11) LAV_W(12) LAV_W(13) LAV_W(14) LAV_W(15) LAV_W(16) LAV_W(17) LAV_W(18) LAV_W(19) LAV_W(20)
-#undef LAV_W
-        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
-    }
-}
-
 // barrier that adds the cycles spent in it to `acc` (trace builds of the loop only)
 #define SPLIT_TIMED(barrier_call, acc) do { if (a.trace) { const long long t_ = clock64(); barrier_call; acc += clock64() - t_; } else { barrier_call; } } while (0)
 
@@ -134,8 +122,6 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     const int ngroups_pad = (ngroups + WFM - 1) / WFM * WFM;  // barriers every role executes (the weight waves' loop is unrolled by WFM)
     const int *toff = a.toff + cls * a.taps_per_class;
     const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    typedef const __attribute__((address_space(1))) void *gptr_t;
-    typedef __attribute__((address_space(3))) void *lptr_t;
 
     if (wid == 4 || wid == 5) {
         // ------------------------------------------------------------------------------ weight waves (2 x 64 threads)
