@@ -31,7 +31,7 @@ def setup_distributed():
     return rank, world, torch.device("cuda", local) if cuda else torch.device("cpu")
 
 
-def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log=None, profile_steps=0, device=None):
+def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log=None, profile_steps=0, device=None, wrap=None):
     """Runs warmup + steps optimisation steps on a fixed synthetic shard per rank; returns (seconds for `steps`, last info).
     profile_steps > 0: that many EXTRA steps after the timed region with the library's HIP-event timers armed; their per-kernel
     times and the algorithmic work lav_amd.ops counted over the same steps come back in info["hand_kernels"]."""
@@ -56,6 +56,9 @@ def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log
         if world > 1:
             dist.barrier()
 
+    if wrap is not None:      # a context manager factory over the trainer (bench.py's CPU leg swaps the teacher's kernels for torch ops)
+        with wrap(lav):
+            return _run_steps(step, steps, warmup, device, world, rank, log) + ((rank, world),)
     info = None
     for _ in range(warmup):
         info = step()
@@ -94,6 +97,18 @@ def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log
     if world > 1:
         dist.barrier()
     return dt, info, (rank, world)
+
+
+def _run_steps(step, steps, warmup, device, world, rank, log):
+    info = None
+    for _ in range(warmup):
+        info = step()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        info = step()
+        if log and rank == 0:
+            log(i, info)
+    return time.perf_counter() - t0, info
 
 
 def load_config(path, **overrides) -> TrainConfig:

@@ -389,3 +389,26 @@ def test_train_lidar_step_is_bit_reproducible_with_deterministic_algorithms():
         set_deterministic(False)
     assert np.array_equal(a, b), np.abs(a - b).max()
     assert all(torch.equal(x, y) for x, y in zip(pa, pb))
+
+
+def test_cpu_baseline_leg_computes_the_same_step_as_the_gpu_trainer():
+    """The CPU sample bench.py reports beside the train_full line (oracle stand-ins for the HIP-only pieces, torch CPU ops for the
+    rest) is the same optimisation step: all loss terms of step 0 agree with the MI355X trainer's."""
+    from lav_amd.point_pillar import PointPillarNet
+    from oracle import train_cpu
+    batch = synthetic_lidar_batch(2, seed=40, max_points=20000, num_objs=3)
+    g = LAV(TrainConfig(log_inference=False), DEV, what="lidar")
+    torch.manual_seed(1000)
+    gpu = g.train_lidar(*batch)
+    restore = PointPillarNet.forward_train
+    PointPillarNet.forward_train = lambda self, lidars, num_points: train_cpu.pillar_forward_train(self, lidars, num_points)
+    try:
+        lav = LAV(TrainConfig(log_inference=False), torch.device("cpu"), what="lidar")
+        torch.manual_seed(1000)
+        with train_cpu.teacher_on_cpu(lav.bev_planner):
+            cpu = lav.train_lidar(*batch)
+    finally:
+        PointPillarNet.forward_train = restore
+    for k, v in gpu.items():
+        if isinstance(v, float):
+            assert abs(cpu[k] - v) <= 2e-3 * max(1.0, abs(v)), (k, cpu[k], v)

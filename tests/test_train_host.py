@@ -82,3 +82,26 @@ def test_train_driver_epochs_scheduler_checkpoints(tmp_path):
     out2 = subprocess.run(base + ["--num-epoch", "1", "--bev", str(tmp_path / "ck" / "bev_2.th")], capture_output=True, text=True,
                           timeout=900, env=env)
     assert out2.returncode == 0, out2.stderr[-3000:]
+
+
+def test_train_lidar_step_runs_on_the_host_through_the_oracle_stand_ins():
+    """bench.py's cpu_baseline leg of the train_full line: the train_lidar step on torch CPU ops, with the oracle's restatements
+    standing in for the two pieces that exist on HIP only (train-mode PointPillar front end, the frozen teacher's inference)."""
+    import torch
+    from lav_amd.point_pillar import PointPillarNet
+    from lav_amd.train import LAV, TrainConfig, synthetic_lidar_batch
+    from oracle import train_cpu
+    restore = PointPillarNet.forward_train
+    PointPillarNet.forward_train = lambda self, lidars, num_points: train_cpu.pillar_forward_train(self, lidars, num_points)
+    try:
+        torch.manual_seed(0)
+        lav = LAV(TrainConfig(log_inference=False), torch.device("cpu"), what="lidar")
+        batch = synthetic_lidar_batch(1, seed=41, max_points=4000, num_objs=2)
+        with train_cpu.teacher_on_cpu(lav.bev_planner):
+            before = [p.detach().clone() for p in lav.lidar_model.backbone.parameters()]
+            info = lav.train_lidar(*batch)
+        assert all(v == v and abs(v) < 1e6 for v in info.values() if isinstance(v, float)), info
+        assert any(not torch.equal(a, b) for a, b in zip(before, lav.lidar_model.backbone.parameters()))
+        assert "crop_feature" not in lav.bev_planner.__dict__          # the stand-ins are gone again
+    finally:
+        PointPillarNet.forward_train = restore
