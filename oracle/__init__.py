@@ -5,6 +5,9 @@ float32 numpy / torch-CPU functional ops for the floating-point layers, and a C
 file for the pillar path) of the reference algorithm that the HIP kernels in
 lav_amd/csrc implement.  Every function cites the reference file:line it follows.
 
+train_cpu.py: the train-mode PointPillar front end and the frozen teacher of the train_lidar step through torch CPU ops, so that
+bench.py's cpu_baseline leg can time the train_full_v2 step on host cores (the product has HIP kernels only for both).
+
 Who may import this: tests/, __graft_entry__.smoke() and bench.py's
 `cpu_baseline` leg - as the checker, never as the thing measured or shipped.
 Nothing under lav_amd/ imports it; the product path raises if the HIP library
