@@ -43,7 +43,6 @@ struct SplitArgs {
     int tw, th, tiles_x;             // 2-D tile (tw = 0: linearised pixels)
     int Wst, Wsub, ROWS, plane;      // staged patch: ROWS x Wst entries per (piece, k half), Wst = in_s * Wsub
     int tap_group, taps_per_class;
-    int debug;                       // timing experiments (LAV_SPLIT_DEBUG bits: 1 no weight DMA, 2 no activation staging, 4 no MFMA): wrong results
     int wring;                       // weight ring slots in LDS (one tap of the tile each): the DMA runs this many steps ahead
     int relu_pre, relu_post, sigmoid;
     float pad_value;
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         int m_c = 0, m_t = 1;   // chunk / tap of micro-step kG+1
         if (m_t >= ntaps) { m_t -= ntaps; ++m_c; }
         for (int k = 0; k < ngroups; ++k) {
-            if (conv_next < nchunk && conv_next <= m_c + 1 && !(a.debug & 2)) {
+            if (conv_next < nchunk && conv_next <= m_c + 1) {
                 SPLIT_TIMED(convert_store(conv_next), conv);
                 if (conv_next + 1 < nchunk) issue_loads(conv_next + 1);
                 ++conv_next;
@@ -631,7 +630,6 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
             s.toff[cl * p.taps_per_class + t] = dy * sp.Wst + (dx % p.in_s) * sp.Wsub + dx / p.in_s;
         }
     s.trace = nullptr;
-    { const char *e = getenv("LAV_SPLIT_DEBUG"); s.debug = e ? atoi(e) : 0; }
     const int NBLK = (4 / sp.WPX) * sp.MC;
     static const bool want_trace = getenv("LAV_SPLIT_TRACE") != nullptr;
     static long long *d_trace = nullptr;

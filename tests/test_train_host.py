@@ -105,3 +105,34 @@ def test_train_lidar_step_runs_on_the_host_through_the_oracle_stand_ins():
         assert "crop_feature" not in lav.bev_planner.__dict__          # the stand-ins are gone again
     finally:
         PointPillarNet.forward_train = restore
+
+
+def test_train_mode_forwards_on_the_host_are_the_modules_own_torch_ops():
+    """lav_amd/train/hipnn.py on a CPU tensor: ConvBackbone.forward_train and ResNet.forward_train (which route BatchNorm + ReLU
+    through bn_act / conv_relu_bn) are exactly the nn.Sequential / BasicBlock arithmetic of the reference modules
+    (team_code_v2/models/lidar.py:110-143, lav/models/resnet.py:59-80,165-172), running statistics included."""
+    import copy
+    import torch
+    import torch.nn.functional as F
+    from lav_amd.lidar import ConvBackbone
+    from lav_amd.resnet import resnet18
+    torch.manual_seed(2)
+    bb = ConvBackbone(num_feature=8).train()
+    ref = copy.deepcopy(bb)
+    x = torch.randn(2, 8, 32, 32)
+    got = bb(x)
+    f1 = ref.conv1(x); f2 = ref.conv2(f1); f3 = ref.conv3(f2)
+    want = torch.cat([ref.upconv1(f1), ref.upconv2(f2), ref.upconv3(f3)], dim=1)
+    assert torch.equal(got, want)
+    assert all(torch.equal(a, b) for a, b in zip(bb.buffers(), ref.buffers()))
+    rn = resnet18(num_channels=5).train()
+    rr = copy.deepcopy(rn)
+    x = torch.randn(3, 5, 48, 48)
+    got = rn(x)
+    y = rr.maxpool(F.relu(rr.bn1(rr.conv1(x))))
+    for i in range(1, 5):
+        for blk in getattr(rr, f"layer{i}"):
+            idt = y if blk.downsample is None else blk.downsample(y)
+            y = F.relu(blk.bn2(blk.conv2(F.relu(blk.bn1(blk.conv1(y))))) + idt)
+    assert torch.equal(got, y)
+    assert all(torch.equal(a, b) for a, b in zip(rn.buffers(), rr.buffers()))
