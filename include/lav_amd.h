@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 20
+#define LAV_ABI_VERSION 21
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -358,6 +358,11 @@ int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const floa
 int lav_maxpool3x3s2(const float *x, int batch, int channels, int h, int w, float *y, void *stream);
 int lav_channel_affine(const float *x, int batch, int channels, long plane, const float *scale, const float *shift, float *y, void *stream);
 int lav_copy_many(int n, const void *const *src, void *const *dst, const size_t *bytes, void *stream);
+/* lav_stage_many: up to 8 strided tensors of at most 4 dimensions (float32, or uint8 converted to float32) -> contiguous float32
+ *     buffers in ONE launch.  dims[4 n] (outermost first, leading 1s), strides[4 n] in source elements.  The camera tensors
+ *     of a tick are channels-last views (lav_agent_fast.py:252-277: stack / permute / float). */
+int lav_stage_many(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
+                   void *stream);
 
 /* Small dense layer out[b][o] = act(bias[o] + sum_k weight[o][k] x[b][k]) (weight in nn.Linear layout [out][in], bias or NULL;
  * act 0 = none, 1 = sigmoid): the brake classifier nn.Sequential(Linear(1024, 1), Sigmoid) of team_code_v2/models/rgb.py:62,79. */

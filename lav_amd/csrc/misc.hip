@@ -195,7 +195,64 @@ __global__ __launch_bounds__(256) void k_copy_many(CopyArgs a) {
         for (int b = 0; b < a.tail[k]; b += 4) *reinterpret_cast<float *>(a.dst[k] + off + b) = *reinterpret_cast<const float *>(a.src[k] + off + b);
     }
 }
+// Strided (<= 4-D) float32 / uint8 sources -> contiguous float32 destinations, several tensors in one launch: the camera tensors
+// the agent hands over are channels-last views (lav_agent_fast.py:252-277: stack / permute / float), the frame graphs read
+// contiguous NCHW buffers.
+constexpr int STAGE_MAX = 8;
+struct StageArgs {
+    const void *src[STAGE_MAX];
+    float *dst[STAGE_MAX];
+    long end[STAGE_MAX];          // running total of elements after tensor i
+    int dims[STAGE_MAX][4];       // sizes, outermost first (leading dims padded with 1)
+    long strides[STAGE_MAX][4];   // source strides in elements
+    int is_u8[STAGE_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_stage_many(StageArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int k = 0;
+    while (k < a.n && i >= a.end[k]) ++k;
+    if (k >= a.n) return;
+    long r = i - (k ? a.end[k - 1] : 0);
+    const long i3 = r % a.dims[k][3]; r /= a.dims[k][3];
+    const long i2 = r % a.dims[k][2]; r /= a.dims[k][2];
+    const long i1 = r % a.dims[k][1];
+    const long i0 = r / a.dims[k][1];
+    const long off = i0 * a.strides[k][0] + i1 * a.strides[k][1] + i2 * a.strides[k][2] + i3 * a.strides[k][3];
+    const float v = a.is_u8[k] ? (float)static_cast<const unsigned char *>(a.src[k])[off] : static_cast<const float *>(a.src[k])[off];
+    a.dst[k][i - (k ? a.end[k - 1] : 0)] = v;
+}
 }  // namespace
+
+extern "C" int lav_stage_many(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
+                              void *stream) {
+    LAV_REQUIRE(n >= 0 && n <= STAGE_MAX && (n == 0 || (src && dst && dims && strides && src_is_u8)), "lav_stage_many: at most %d tensors", STAGE_MAX);
+    if (n == 0) return LAV_OK;
+    StageArgs a;
+    long total = 0;
+    for (int i = 0; i < STAGE_MAX; ++i) {
+        if (i < n) {
+            LAV_REQUIRE(src[i] && dst[i], "lav_stage_many: null tensor %d", i);
+            long cnt = 1;
+            for (int d = 0; d < 4; ++d) {
+                LAV_REQUIRE(dims[4 * i + d] >= 1, "lav_stage_many: tensor %d has an empty dimension", i);
+                a.dims[i][d] = dims[4 * i + d];
+                a.strides[i][d] = strides[4 * i + d];
+                cnt *= dims[4 * i + d];
+            }
+            a.src[i] = src[i]; a.dst[i] = dst[i]; a.is_u8[i] = src_is_u8[i] ? 1 : 0;
+            total += cnt;
+        } else {
+            a.src[i] = nullptr; a.dst[i] = nullptr; a.is_u8[i] = 0;
+            for (int d = 0; d < 4; ++d) { a.dims[i][d] = 1; a.strides[i][d] = 0; }
+        }
+        a.end[i] = total;
+    }
+    a.n = n;
+    hipLaunchKernelGGL(k_stage_many, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
 
 extern "C" int lav_maxpool3x3s2(const float *x, int batch, int channels, int h, int w, float *y, void *stream) {
     LAV_REQUIRE(x && y && batch >= 0 && channels >= 1 && h >= 1 && w >= 1, "lav_maxpool3x3s2: bad argument");

@@ -667,14 +667,18 @@ def channel_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) ->
 
 
 def copy_many(pairs) -> None:
-    """[(dst, src), ...] device-to-device copies of equal-sized contiguous tensors in ONE launch (lav_copy_many); pairs that are
-    not 16-byte friendly fall back to Tensor.copy_."""
-    srcs, dsts, sizes = [], [], []
+    """[(dst, src), ...] device tensors of equal shape into their destinations in at most two launches: contiguous same-dtype
+    16-byte-aligned pairs through lav_copy_many (16-byte words), strided / uint8 sources of up to four dimensions into contiguous
+    float32 destinations through lav_stage_many (the conversion torch's copy_ would do, for all of them at once); anything else
+    takes Tensor.copy_."""
+    srcs, dsts, sizes, stage = [], [], [], []
     for dst, src in pairs:
         nb = dst.numel() * dst.element_size()
-        if (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype and src.numel() == dst.numel()
-                and nb % 4 == 0 and nb > 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
+        both = src.is_cuda and dst.is_cuda and dst.is_contiguous() and src.shape == dst.shape and nb > 0
+        if (both and src.is_contiguous() and src.dtype == dst.dtype and nb % 4 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
             srcs.append(src.data_ptr()); dsts.append(dst.data_ptr()); sizes.append(nb)
+        elif both and dst.dtype == torch.float32 and src.dtype in (torch.float32, torch.uint8) and 1 <= src.dim() <= 4:
+            stage.append((dst, src))
         else:
             dst.copy_(src, non_blocking=True)
     lib = _lib.load()
@@ -682,6 +686,17 @@ def copy_many(pairs) -> None:
         n = len(srcs[i:i + 8])
         check(lib.lav_copy_many(n, (C.c_void_p * n)(*srcs[i:i + 8]), (C.c_void_p * n)(*dsts[i:i + 8]), (C.c_size_t * n)(*sizes[i:i + 8]), _stream()),
               "lav_copy_many")
+    for i in range(0, len(stage), 8):
+        part = stage[i:i + 8]
+        n = len(part)
+        dims, strides = [], []
+        for dst, src in part:
+            pad = 4 - src.dim()
+            dims += [1] * pad + list(src.shape)
+            strides += [0] * pad + list(src.stride())
+        check(lib.lav_stage_many(n, (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in part]), (C.c_void_p * n)(*[d.data_ptr() for d, _ in part]),
+                                 (C.c_int * (4 * n))(*dims), (C.c_long * (4 * n))(*strides),
+                                 (C.c_int * n)(*[int(s_.dtype == torch.uint8) for _, s_ in part]), _stream()), "lav_stage_many")
 
 
 def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, sigmoid: bool = False) -> torch.Tensor:

@@ -191,3 +191,21 @@ def test_transposed_convolution_with_empty_parity_classes(B, cin, cout, H):
         got = layer(x.to(DEV))
     torch.cuda.synchronize()
     assert (got.double().cpu() - want).abs().max().item() < 1e-5
+
+
+def test_copy_many_stages_strided_and_uint8_tensors_like_copy_():
+    """lav_stage_many: the camera tensors of a tick (channels-last views, float32 or uint8) into contiguous float32 buffers,
+    together with an expanded / sliced 2-D tensor: exactly what Tensor.copy_ gives."""
+    torch.manual_seed(10)
+    hwc = torch.randint(0, 256, (3, 288, 256, 3), dtype=torch.uint8, device=DEV)
+    a_src = hwc.permute(0, 3, 1, 2)                                                    # (3,3,288,256) uint8, channels last
+    b_src = torch.rand(1, 192, 480, 3, device=DEV).permute(0, 3, 1, 2) * 255           # float32, channels last
+    c_src = torch.randn(10, 7, device=DEV)[::2, 1:6]                                   # 2-D strided
+    d_src = torch.randn(5, device=DEV)[1:]                                             # misaligned contiguous 1-D
+    e_src = torch.randn(64, 4, device=DEV)                                             # contiguous: the 16-byte-word path
+    srcs = [a_src, b_src, c_src, d_src, e_src]
+    dsts = [torch.full(s.shape, -7.0, dtype=torch.float32, device=DEV) for s in srcs]
+    ops.copy_many(list(zip(dsts, srcs)))
+    for d, s in zip(dsts, srcs):
+        want = torch.empty_like(d); want.copy_(s)
+        assert torch.equal(d, want)
