@@ -250,6 +250,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the short train_full / train_bev runs appended to the inference line")
+    ap.add_argument("--no-variants", action="store_true", help="skip the exact-fp32 child run of the frame")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     ap.add_argument("--mode", default="infer", choices=["infer", "train_full", "train_bev"],
                     help="infer: BASELINE metric (i) frames/s; train_full / train_bev: metric (ii) samples/s, data parallel")
@@ -300,12 +301,23 @@ def main():
             dist.barrier()
 
     lib.lav_profile_reset()
+    health0 = pipe.health() if hasattr(pipe, "health") else None
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(i); i += 1
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    # every timed frame's outputs were finite and no persistent plan launch gave up: read from the pipeline's sticky device-side
+    # counters AFTER the timed region (the graphs carry the checks; nothing was copied up per frame)
+    health = None
+    if health0 is not None:
+        h1 = pipe.health()
+        health = {k: h1[k] - health0[k] for k in ("nonfinite_outputs", "finite_checks", "plan_launches", "plan_aborts", "plans_recomputed",
+                                                  "decode_mismatches", "overflow_ticks")}
+        health["last_plan_launch"] = h1["last_plan_launch"]
+    host_finite = all(bool(torch.isfinite(out[k]).all()) for k in ("ego_plan_locs", "ego_cast_locs", "ego_embd", "pred_bra", "pred_bev")) \
+        and bool(torch.isfinite(out["other_cast_locs"]).all())
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -481,6 +493,61 @@ def main():
         forced = {f"others_{k}": forced_frames(k) for k in (0, 4)}
         pipe.set_forced_others(None)
 
+    def chain_only(steps=40):
+        """The frame with the two side streams (brake net, ego branch) switched off: the critical chain lidar -> heads -> others alone
+        (their outputs keep their last values).  frame - chain = what the side streams' contention costs."""
+        nonlocal i
+        from lav_amd import frame as frame_mod
+        saved = frame_mod._DIAG_SKIP
+        frame_mod._DIAG_SKIP = {"brake", "ego"}
+        try:
+            for _ in range(6):
+                step(i); i += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(i); i += 1
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / steps * 1e3, 4)
+        finally:
+            frame_mod._DIAG_SKIP = saved
+
+    def graph_times(iters=50):
+        """Stand-alone replay time of each frame graph (nothing else on the GPU): what the streams would take one after the other."""
+        res = {}
+        for key, g in pipe.graphs.items():
+            name = key if isinstance(key, str) else "_".join(str(k) for k in key)
+            state = (pipe.ring.clone(), pipe.b_prev.clone())
+            torch.cuda.synchronize()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                g.replay()
+            torch.cuda.synchronize()
+            res[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+            pipe.ring.copy_(state[0]); pipe.b_prev.copy_(state[1])
+        return res
+    chain_ms = graphs_ms = None
+    if rank == 0 and world == 1 and not args.eager:
+        chain_ms = chain_only()
+        graphs_ms = graph_times()
+
+    def f32_frame():
+        """The same frame with every convolution on the exact-fp32 MFMA kernels (LAV_CONV_PRECISION=f32 is read once per process):
+        a child run of this script, inference line only."""
+        import subprocess
+        env = dict(os.environ, LAV_CONV_PRECISION="f32")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "16", "--no-train", "--no-cpu-baseline", "--no-variants"]
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            return dict(ms_per_step=line["ms_per_step"], frames_per_s=line["value"], steps=line["steps"], health=line.get("health"),
+                        precision="LAV_CONV_PRECISION=f32: v_mfma_f32_32x32x2_f32 everywhere (bit-for-bit fmaf chains)")
+        except Exception as e:   # never lose the headline line to the variant
+            return dict(error=repr(e)[:200])
+
     if rank == 0:
         res = dict(metric="frames/s full agent fwd (32k-pt LiDAR + 3 cams)", value=round(world * args.steps / dt, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=n_warm,
@@ -492,7 +559,19 @@ def main():
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1]),
                                launch="eager" if args.eager else "hip graphs: lidar / heads / others (capacity 15, device-resident count) on the main stream, brake and ego[cmd] on side streams"),
                    roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, roofline_hbm_glue=glue,
-                   forced_others=forced, hip_kernel_us_per_frame=per_frame_us)
+                   forced_others=forced, hip_kernel_us_per_frame=per_frame_us,
+                   health=health, last_frame_outputs_finite=host_finite, chain_only_ms=chain_ms, graph_replay_ms=graphs_ms)
+        bad = [] if host_finite else ["the last timed frame holds non-finite outputs"]
+        if health is not None:
+            if health["nonfinite_outputs"]:
+                bad.append(f"{health['nonfinite_outputs']} non-finite output tensors inside the timed frames")
+            if health["plan_aborts"] or health["plans_recomputed"]:
+                bad.append(f"{health['plan_aborts']} persistent plan launches timed out")
+        res["valid"] = not bad
+        if bad:
+            res["invalid_reason"] = "; ".join(bad)
+        if world == 1 and not args.eager and not args.no_variants:
+            res["frame_fp32_kernels"] = f32_frame()
         if world == 1 and not args.no_train:
             res["training"] = training_lines(with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:

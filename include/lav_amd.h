@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 21
+#define LAV_ABI_VERSION 22
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -161,6 +161,9 @@ int lav_gru_plan(const float *embd, const float *nxp, const float *cast_locs, in
                  const float *mlp_w, const float *mlp_b, float *out,
                  void *workspace, size_t workspace_bytes, void *stream);
 size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T);
+/* A plan workspace must be ZERO before its first use and belongs to one stream.  Its first 512 bytes are a control block:
+ * [0, 256) sticky counters {aborted persistent launches, persistent launches} since it was zero-filled, [256, 512) the status
+ * and diagnosis words of the last persistent launch (cleared at every launch). */
 /*
  * lav_gru_plan runs all iters*T dependent steps in ONE persistent launch when B*(1 or num_cmds) <= 6: its H/8 workgroups
  * exchange the hidden state through HBM and must be co-resident.  Every wait is bounded; a launch that times out (the chip
@@ -171,6 +174,14 @@ size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T);
  */
 int lav_gru_plan_status(const void *workspace, size_t workspace_bytes, int B, int H, int num_cmds, int cmd,
                         int *h_status, void *stream);
+/* lav_gru_plan_diag: the 16 diagnosis words of the last persistent launch (SYNCHRONISES `stream`): [0] status, [1] workgroups
+ * that entered the kernel, [2] 1 + workgroup / [3] wave / [4] step epoch of the first wave that gave up, [5] its spin count,
+ * [6] the state granule it was waiting for, [7] the tag it last saw there, [8] microseconds from its kernel entry to the abort,
+ * [9] workgroups that ran to completion (H/8 after a good launch); sticky since the workspace was zero-filled: [10] aborted
+ * launches, [11] all persistent launches (a plan workspace must be ZERO before its first use).  No counterpart in the reference (cuDNN's GRU cannot
+ * time out); it exists so that an abort can be told apart from lost co-residency vs a lost hand-off. */
+int lav_gru_plan_diag(const void *workspace, size_t workspace_bytes, int B, int H, int num_cmds, int cmd,
+                      int *h_words16, void *stream);
 int lav_gru_plan_steps(const float *embd, const float *nxp, const float *cast_locs, int B, int H, int num_cmds, int T,
                        int iters, int cmd, float pixels_per_meter, float crop_size,
                        const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
@@ -233,7 +244,9 @@ typedef struct lav_conv {
     int precision;     /* how the fp32 contraction is evaluated: LAV_CONV_F32 = v_mfma_f32_32x32x2_f32 only (bit-for-bit an
                           fmaf chain); LAV_CONV_BF16X6 = layers whose plan favours it run on the bf16 matrix cores with every
                           fp32 operand split exactly into three bf16 pieces and the six leading partial products accumulated
-                          in fp32 (error of an fp32 dot product, 2.4x the matrix rate; fp32 subnormal inputs are flushed);
+                          in fp32 (error of an fp32 dot product, 2.4x the matrix rate; fp32 subnormal inputs are flushed; every
+                          finite input up to FLT_MAX is split exactly; an Inf or NaN activation / weight gives NaN in the
+                          outputs it reaches, where LAV_CONV_F32 and the reference's cuDNN path propagate Inf as Inf);
                           0 = the library default (environment LAV_CONV_PRECISION = f32 | bf16x6, default bf16x6).  The
                           packed weights of a layer depend on it: pack and run with the same descriptor */
 } lav_conv;
@@ -347,6 +360,14 @@ int lav_extract_peaks(const float *heat, int ncls, int h, int w, int ks, int max
  * ------------------------------------------------------------------------------------------ */
 int lav_attn_pool(const float *x, int batch, int C, int N, int heads, const float *u, const float *dots_bias,
                   const float *w_v, const float *b_v, float *out, void *stream);
+
+/*
+ * Health counter of a frame: counter2[0] += how many of the n (<= 8) float tensors hold a NaN or an Inf, counter2[1] += 1.
+ * Sticky and device resident: enqueued behind a frame's last kernels (it is part of the HIP graphs), read by the host when it
+ * likes.  The reference checks its waypoints on the host every tick (lav_agent_fast.py:325-328, np.isnan after .cpu()); this is
+ * the same question asked without a device->host copy per tensor, so that a benchmark loop can prove every timed frame finite.
+ */
+int lav_nonfinite_count(int n, const float *const *tensors, const long *numel, int *counter2, void *stream);
 
 /* Frame glue that replaces library launches inside the frame graphs:
  * lav_maxpool3x3s2: nn.MaxPool2d(3, 2, 1) of the ResNet stems (lav/models/resnet.py:161,236), x [batch][channels][h][w] ->

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 MAX_CAM = 4
 
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     "lav_gru_plan": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_plan_steps": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_plan_status": (_I, [_P, _Z, _I, _I, _I, _I, C.POINTER(_I), _P]),
+    "lav_gru_plan_diag": (_I, [_P, _Z, _I, _I, _I, _I, C.POINTER(_I), _P]),
     "lav_gru_plan_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "lav_conv_out_hw": (_I, [C.POINTER(Conv), C.POINTER(_I), C.POINTER(_I)]),
     "lav_conv_packed_weight_floats": (_Z, [C.POINTER(Conv)]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "lav_linear_act": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P]),
     "lav_maxpool3x3s2": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "lav_channel_affine": (_I, [_P, _I, _I, C.c_long, _P, _P, _P, _P]),
+    "lav_nonfinite_count": (_I, [_I, C.POINTER(_P), C.POINTER(C.c_long), _P, _P]),
     "lav_copy_many": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_Z), _P]),
     "lav_stage_many": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I), C.POINTER(C.c_long), C.POINTER(_I), _P]),
     "lav_det_decode": (_I, [_P, _I, _I, _I] + [C.c_double] * 10 + [_P, _P, _P]),

@@ -238,8 +238,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void pair_split3(float x, unsigned &p0, unsigned &p1, unsigned &p2) {
-    p0 = (__float_as_uint(x) + 0x8000u) & 0xffff0000u;
+__device__ __forceinline__ void pair_split3(float x, unsigned &p0, unsigned &p1, unsigned &p2) {   // = split3 of conv_split.hpp
+    const unsigned u = __float_as_uint(x), r = u + 0x8000u;
+    p0 = ((r & 0x7f800000u) == 0x7f800000u ? u : r) & 0xffff0000u;
     const float r1 = x - __uint_as_float(p0);
     p1 = (__float_as_uint(r1) + 0x8000u) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(p1);
@@ -514,7 +515,8 @@ extern "C" int lav_conv1d_pair_pack_weights(int channels, const float *h_weight,
     auto bf = [](float x, float &rest) {
         unsigned u;
         memcpy(&u, &x, 4);
-        u = (u + 0x8000u) & 0xffff0000u;
+        const unsigned r = u + 0x8000u;
+        u = ((r & 0x7f800000u) == 0x7f800000u ? u : r) & 0xffff0000u;
         float b;
         memcpy(&b, &u, 4);
         rest = x - b;
@@ -564,7 +566,7 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
         sa.B = batch; sa.C = channels; sa.H = h; sa.W = w; sa.dA = d_a; sa.dB = d_b; sa.relu_post = relu_post;
         sa.CP = (channels + 31) / 32 * 32;
         hipStream_t sst = static_cast<hipStream_t>(stream);
-        const int ks2 = channels >= 64 ? 2 : 1;
+        const int ks2 = channels >= 64 && (channels / 16) % 2 == 0 ? 2 : 1;   // K halves of equal whole chunk counts only (80 channels: one wave group)
         const int nch2 = channels / 16 / ks2;
         const int ring2 = nch2 % 4 == 0 ? 4 : nch2 % 2 == 0 ? 2 : 1;
         const int tok2 = timer_begin("conv1d_pair", sst);
@@ -596,7 +598,7 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
     // rows are few (one workgroup each, at most one per CU for ERFNet's shapes): put 8 waves on the channel loop when it
     // is long enough to halve (the partial sums need 16 KB of the staging area)
     static const bool no_split = getenv("LAV_PAIR_KSPLIT") && getenv("LAV_PAIR_KSPLIT")[0] == '0';
-    const int ks = (channels >= 64 && !no_split && (size_t)channels * 3 * w * sizeof(float) >= 16 * 1024) ? 2 : 1;
+    const int ks = (channels >= 64 && (channels / 16) % 2 == 0 && !no_split && (size_t)channels * 3 * w * sizeof(float) >= 16 * 1024) ? 2 : 1;
     const int nch = channels / 16 / ks;              // chunks per wave
     const int ring = nch % 4 == 0 ? 4 : nch % 2 == 0 ? 2 : 1;
 #define LAV_PAIR_CASE(KS_, R_) if (ks == KS_ && ring == R_) { \

@@ -57,9 +57,13 @@ __device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0)
 // barrier that adds the cycles spent in it to `acc` (trace builds of the loop only)
 #define SPLIT_TIMED(barrier_call, acc) do { if (a.trace) { const long long t_ = clock64(); barrier_call; acc += clock64() - t_; } else { barrier_call; } } while (0)
 
-// x -> three bf16 pieces (round half up on the dropped bits), returned in the HIGH halves of p0..p2
+// x -> three bf16 pieces (round half up on the dropped bits), returned in the HIGH halves of p0..p2.  Where the round-up would
+// carry into the Inf / NaN exponent (|x| within half a bf16 ulp of FLT_MAX) the first piece is truncated instead: the pieces still
+// sum to x exactly.  Non-finite x: the first piece keeps Inf / NaN and the rest become NaN (Inf - Inf), so the output is NaN where
+// the fp32 kernels (and the reference) propagate Inf - documented in lav_amd.h.  fp32 subnormals are flushed by the hardware.
 __device__ __forceinline__ void split3(float x, unsigned &p0, unsigned &p1, unsigned &p2) {
-    p0 = (__float_as_uint(x) + 0x8000u) & 0xffff0000u;
+    const unsigned u = __float_as_uint(x), r = u + 0x8000u;
+    p0 = ((r & 0x7f800000u) == 0x7f800000u ? u : r) & 0xffff0000u;
     const float r1 = x - __uint_as_float(p0);          // exact
     p1 = (__float_as_uint(r1) + 0x8000u) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(p1);         // exact
@@ -468,7 +472,8 @@ inline size_t split_weight_bytes(const Plan &p) {
 inline unsigned short bf16_round(float x, float &rest) {
     unsigned u;
     memcpy(&u, &x, 4);
-    u = (u + 0x8000u) & 0xffff0000u;
+    const unsigned r = u + 0x8000u;
+    u = ((r & 0x7f800000u) == 0x7f800000u ? u : r) & 0xffff0000u;   // as split3: no round-up into the Inf exponent
     float b;
     memcpy(&b, &u, 4);
     rest = x - b;

@@ -331,17 +331,31 @@ __global__ __launch_bounds__(64 * OUT_WAVES) void k_plan_out(PlanArgs a, int it)
 // waypoints (no steering, no throttle, lav_agent_fast.py:325-328) applies, and lav_gru_plan_steps recomputes it without any
 // co-residency requirement.
 constexpr long long PLAN_SPIN_LIMIT = 1ll << 22;
+constexpr size_t PLAN_CTRL_BYTES = 512;   // head of a plan workspace: sticky counters + status / diagnosis words
 
-__global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ status, float *__restrict__ out, long n_out) {
-    if (*status == 0) return;
+// sticky[0] / sticky[1]: aborted / all persistent launches on this workspace since the caller zero-filled it (outside
+// the range the per-launch memset clears) - a benchmark or a drive reads them once at its end (lav_gru_plan_diag words 10, 11).
+__global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ status, int *__restrict__ sticky, float *__restrict__ out, long n_out) {
+    const bool aborted = *status != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(sticky + 1, 1);
+        if (aborted) atomicAdd(sticky, 1);
+    }
+    if (!aborted) return;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (long)gridDim.x * 256) out[i] = __uint_as_float(0x7fc00000u);
 }
 
+// Diagnosis words behind the status word (ints; lav_gru_plan_diag copies all 16): [0] status, [1] workgroups that entered the
+// kernel, [2] 1 + workgroup / [3] wave / [4] epoch of the FIRST wave that gave up, [5] its spin count, [6] the granule index
+// it was waiting for, [7] the tag it last saw there, [8] microseconds between its kernel entry and the abort, [9] workgroups
+// that ran to completion.  The words are cleared with the granule tags at every launch.
 __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status,
                                                          long long spin_limit) {
     const int H = a.H, T = a.T, R = a.R;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = H / 64;
+    const unsigned long long t_entry = wall_clock64();
+    if (tid == 0) atomicAdd(status + 1, 1);
     __shared__ float gh_s[3 * PLAN_UNITS][PLAN_RC];
     __shared__ float loc_s[2][PLAN_RC][64][2];
     __shared__ float run_s[PLAN_RC][2];
@@ -423,11 +437,26 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                             }
                         }
                     }
-                    ok = __all(ok);
+                    const unsigned long long bad = __ballot(!ok);
+                    ok = bad == 0;
                     if (!ok) {
                         if (++spins > spin_limit || *(volatile int *)&abort_s) {
                             abort_s = 1;
-                            if (lane == 0) atomicExch(status, 1);
+                            if (lane == (int)__builtin_ctzll(bad)) {
+                                atomicExch(status, 1);
+                                if (atomicCAS(status + 2, 0, (int)blockIdx.x + 1) == 0) {   // the first wave of the grid to give up
+                                    int bi = 0;
+                                    unsigned bt = 0;
+                                    for (int rr = R - 1; rr >= 0; --rr)
+                                        for (int i = nk - 1; i >= 0; --i) {
+                                            const unsigned long long x = __hip_atomic_load(g + (long)rr * H + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            if ((unsigned)(x >> 32) != epoch) { bi = rr * H + lane + 64 * i; bt = (unsigned)(x >> 32); }
+                                        }
+                                    status[3] = wid; status[4] = (int)epoch; status[5] = (int)min(spins, 0x7fffffffll);
+                                    status[6] = bi; status[7] = (int)bt;
+                                    status[8] = (int)((wall_clock64() - t_entry) / 100);   // 100 MHz constant clock
+                                }
+                            }
                             break;
                         }
                         __builtin_amdgcn_s_sleep(2);
@@ -514,6 +543,7 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
         __syncthreads();
         cur ^= 1;
     }
+    if (tid == 0) atomicAdd(status + 9, 1);
 }
 }  // namespace
 
@@ -557,9 +587,11 @@ extern "C" int lav_embed_cast(const float *feat, int B, int embd_dim, int hw, fl
 extern "C" size_t lav_gru_plan_workspace_bytes(int B, int H, int num_cmds, int T) {
     // step-per-launch path: h sequence [T][R][H] floats; persistent path: 2 granule buffers [R][H] u64 + status word
     // (+ many-row path: initial state [R][H] and inputs [R][T][4])
+    // Layout: [0, 256) sticky counters (launches / aborted launches since the caller zero-filled the workspace), [256, 512) the
+    // status + diagnosis words of the last persistent launch, from PLAN_CTRL_BYTES on the granules resp. the step path's buffers.
     const size_t seq = ((size_t)T * B * num_cmds * H + (size_t)B * num_cmds * H + (size_t)B * num_cmds * T * 4) * sizeof(float) + 512;
-    const size_t gran = lav::align_up(2 * (size_t)PLAN_RC * H * sizeof(unsigned long long), 256) + 256;
-    return lav::align_up(seq > gran ? seq : gran, 256);
+    const size_t gran = lav::align_up(2 * (size_t)PLAN_RC * H * sizeof(unsigned long long), 256);
+    return lav::align_up(seq > gran ? seq : gran, 256) + PLAN_CTRL_BYTES;
 }
 
 namespace {
@@ -575,34 +607,36 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
     PlanArgs a;
     a.embd = embd; a.nxp = nxp; a.cast_locs = cast_locs;
     a.w_ih = w_ih; a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.mlp_w = mlp_w; a.mlp_b = mlp_b;
-    a.out = out; a.hseq = static_cast<float *>(workspace);
+    a.out = out; a.hseq = reinterpret_cast<float *>(static_cast<char *>(workspace) + PLAN_CTRL_BYTES);
     a.B = B; a.H = H; a.num_cmds = num_cmds; a.T = T; a.iters = iters; a.cmd = cmd;
     a.NC = cmd >= 0 ? 1 : num_cmds;
     a.R = B * a.NC;
     a.ppm = pixels_per_meter; a.crop = crop_size;
-    const size_t need = (size_t)T * a.R * H * sizeof(float);
+    const size_t need = (size_t)T * a.R * H * sizeof(float) + PLAN_CTRL_BYTES;
     if (!workspace || workspace_bytes < need) return lav::fail(LAV_EWORKSPACE, "lav_gru_plan: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("gru_plan", st);
     const char *impl = getenv("LAV_PLAN_IMPL");
     if (allow_persistent && a.R <= PLAN_RC && !(impl && impl[0] == 's')) {
-        // persistent kernel: needs its H/8 workgroups co-resident (64 of 256 CUs) - always true on an MI355X
+        // persistent kernel: its H/8 workgroups (64 of 256 CUs) must become co-resident while other streams' kernels hold the
+        // chip - not guaranteed by HIP, hence the bounded spins, the status / diagnosis words and the NaN poisoning
         const size_t gbytes = 2 * (size_t)a.R * H * sizeof(unsigned long long);
-        LAV_REQUIRE(workspace_bytes >= lav::align_up(gbytes, 256) + 256, "lav_gru_plan: workspace too small for the persistent kernel");
-        unsigned long long *gran = static_cast<unsigned long long *>(workspace);
-        int *status = reinterpret_cast<int *>(static_cast<char *>(workspace) + lav::align_up(gbytes, 256));
-        LAV_HIP(hipMemsetAsync(workspace, 0, lav::align_up(gbytes, 256) + 256, st));  // tags and status start at 0 (a whole number of 256-byte lines: one fill kernel)
+        LAV_REQUIRE(workspace_bytes >= lav::align_up(gbytes, 256) + PLAN_CTRL_BYTES, "lav_gru_plan: workspace too small for the persistent kernel");
+        unsigned long long *gran = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + PLAN_CTRL_BYTES);
+        int *sticky = static_cast<int *>(workspace);
+        int *status = sticky + 64;
+        LAV_HIP(hipMemsetAsync(status, 0, 256 + lav::align_up(gbytes, 256), st));  // status words and tags start at 0 (a whole number of 256-byte lines: one fill kernel)
         const char *lim = getenv("LAV_PLAN_SPIN_LIMIT");   // test knob: 1 forces the time-out path
         const long long spin_limit = lim && atoll(lim) > 0 ? atoll(lim) : PLAN_SPIN_LIMIT;
         hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit);
         const long n_out = (long)a.B * a.iters * a.NC * T * 2;
-        hipLaunchKernelGGL(k_plan_poison, dim3((unsigned)std::min<long>((n_out + 255) / 256, 64)), dim3(256), 0, st, status, a.out, n_out);
+        hipLaunchKernelGGL(k_plan_poison, dim3((unsigned)std::min<long>((n_out + 255) / 256, 64)), dim3(256), 0, st, status, sticky, a.out, n_out);
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
         return LAV_OK;
     }
     const size_t seq_floats = lav::align_up((size_t)T * a.R * H, 64);
-    const bool many_rows = a.R >= PLAN_MFMA_MIN_ROWS && workspace_bytes >= (seq_floats + (size_t)a.R * H + 64 + (size_t)a.R * T * 4) * sizeof(float) &&
+    const bool many_rows = a.R >= PLAN_MFMA_MIN_ROWS && workspace_bytes >= (seq_floats + (size_t)a.R * H + 64 + (size_t)a.R * T * 4) * sizeof(float) + PLAN_CTRL_BYTES &&
                            !(impl && impl[0] == 'v');   // LAV_PLAN_IMPL=v: the VALU step kernel at any size (A/B knob)
     float *h0 = a.hseq + seq_floats, *u = h0 + lav::align_up((size_t)a.R * H, 64);
     for (int it = 0; it < iters; ++it) {
@@ -651,10 +685,22 @@ extern "C" int lav_gru_plan_status(const void *workspace, size_t workspace_bytes
     const int R = B * (cmd >= 0 ? 1 : num_cmds);
     *h_status = 0;
     if (R > PLAN_RC) return LAV_OK;   // the step-per-launch path has no spin loops
-    const size_t off = lav::align_up(2 * (size_t)R * H * sizeof(unsigned long long), 256);
-    LAV_REQUIRE(workspace_bytes >= off + 4, "lav_gru_plan_status: workspace too small");
+    LAV_REQUIRE(workspace_bytes >= PLAN_CTRL_BYTES, "lav_gru_plan_status: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LAV_HIP(hipMemcpyAsync(h_status, static_cast<const char *>(workspace) + off, sizeof(int), hipMemcpyDeviceToHost, st));
+    LAV_HIP(hipMemcpyAsync(h_status, static_cast<const char *>(workspace) + 256, sizeof(int), hipMemcpyDeviceToHost, st));
+    LAV_HIP(hipStreamSynchronize(st));
+    return LAV_OK;
+}
+
+extern "C" int lav_gru_plan_diag(const void *workspace, size_t workspace_bytes, int B, int H, int num_cmds, int cmd,
+                                 int *h_words16, void *stream) {
+    LAV_REQUIRE(workspace && h_words16, "lav_gru_plan_diag: null argument");
+    LAV_REQUIRE(B >= 1 && H > 0 && num_cmds > 0 && cmd >= -1 && cmd < num_cmds, "lav_gru_plan_diag: bad sizes");
+    for (int i = 0; i < 16; ++i) h_words16[i] = 0;
+    LAV_REQUIRE(workspace_bytes >= PLAN_CTRL_BYTES, "lav_gru_plan_diag: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LAV_HIP(hipMemcpyAsync(h_words16, static_cast<const char *>(workspace) + 256, 10 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LAV_HIP(hipMemcpyAsync(h_words16 + 10, workspace, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     LAV_HIP(hipStreamSynchronize(st));
     return LAV_OK;
 }

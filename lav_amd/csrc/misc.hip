@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void k_maxpool3s2(const float *__restrict__ x,
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int iy = 2 * oy + dy, ix = 2 * ox + dx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) m = fmaxf(m, xp[iy * W + ix]);
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const float v = xp[iy * W + ix];
+                m = (v > m || v != v) ? v : m;   // NaN-propagating like F.max_pool2d (fmaxf would drop it)
+            }
         }
     y[i] = m;
 }
@@ -295,6 +298,54 @@ extern "C" int lav_copy_many(int n, const void *const *src, void *const *dst, co
     a.n = n;
     if (total == 0) return LAV_OK;
     hipLaunchKernelGGL(k_copy_many, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ health counter
+// counter[0] += the number of the given tensors that hold a NaN / Inf, counter[1] += 1 (launches): a sticky, device-resident
+// record that a frame's outputs were finite, enqueued at the end of the frame graphs - nothing waits for it, the host reads it
+// whenever it likes (bench.py: after the timed region; the reference agent's own NaN rule, lav_agent_fast.py:325-328, is applied
+// by the caller per frame as before).
+namespace {
+constexpr int FINITE_MAX = 8;
+struct FiniteArgs {
+    const float *p[FINITE_MAX];
+    long n[FINITE_MAX];
+    int count;
+};
+__global__ __launch_bounds__(256) void k_nonfinite_count(FiniteArgs a, int *__restrict__ counter) {
+    __shared__ int bad_s;
+    if (threadIdx.x == 0) bad_s = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int t = 0; t < a.count; ++t) {
+        bool b = false;
+        for (long i = threadIdx.x; i < a.n[t]; i += 256) {
+            const float v = a.p[t][i];
+            b = b || !(fabsf(v) <= 3.4028234664e38f);   // NaN or Inf
+        }
+        if (__any(b) && (threadIdx.x & 63) == 0) bad |= 1 << t;
+    }
+    if (bad) atomicOr(&bad_s, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (bad_s) atomicAdd(counter, __popc(bad_s));
+        atomicAdd(counter + 1, 1);
+    }
+}
+}  // namespace
+
+extern "C" int lav_nonfinite_count(int n, const float *const *tensors, const long *numel, int *counter2, void *stream) {
+    LAV_REQUIRE(n >= 0 && n <= FINITE_MAX && counter2 && (n == 0 || (tensors && numel)), "lav_nonfinite_count: at most %d tensors", FINITE_MAX);
+    FiniteArgs a;
+    a.count = n;
+    for (int i = 0; i < FINITE_MAX; ++i) {
+        a.p[i] = i < n ? tensors[i] : nullptr;
+        a.n[i] = i < n ? numel[i] : 0;
+        if (i < n) LAV_REQUIRE(tensors[i] != nullptr && numel[i] >= 0, "lav_nonfinite_count: tensor %d is null", i);
+    }
+    hipLaunchKernelGGL(k_nonfinite_count, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, counter2);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }

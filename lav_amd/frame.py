@@ -187,6 +187,9 @@ class GraphedFramePipeline(FramePipeline):
         self.forced_others = None     # set_forced_others: (actors, count, n) on the device
         self.decode_mismatches = 0    # frames on which the device and host detection decodes disagreed (host result used)
         self.plan_aborts = 0          # frames whose persistent plan launch timed out and was recomputed (recover_plan)
+        # [tensors found non-finite, checks run] by lav_nonfinite_count at the end of the ego / brake / heads graphs: sticky and
+        # device resident, read by health() - a benchmark loop proves every timed frame finite without a copy per frame
+        self.d_health = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.poses = deque()
 
     def _grow(self, new_p: int):
@@ -234,6 +237,7 @@ class GraphedFramePipeline(FramePipeline):
                            centre_xy=(float(W / 2 + ox * W / 2), float(H / 2 + oy * H / 2)), skip_px=4.0, ppm=up.pixels_per_meter)
             if self.forced_others is not None:   # measurement hook (set_forced_others): fixed poses instead of the detections
                 self.d_actors.copy_(self.forced_others[0]); self.d_n.copy_(self.forced_others[1])
+        ops.nonfinite_count([det_raw], self.d_health)
         return dict(det_raw=det_raw, pred_bev=pred_bev)
 
     def set_forced_others(self, locs=None, oris=None):
@@ -255,8 +259,9 @@ class GraphedFramePipeline(FramePipeline):
         self.graphs.pop("heads", None); self.outs.pop("heads", None)   # the hook is part of the heads graph: re-capture
 
     def _g_brake(self):
-        bra = self.bra_model
-        return dict(pred_bra=bra(self.b_rgbs, self.b_tel))
+        pred_bra = self.bra_model(self.b_rgbs, self.b_tel)
+        ops.nonfinite_count([pred_bra], self.d_health)
+        return dict(pred_bra=pred_bra)
 
     def _g_ego(self, cmd_value):
         up, features = self.infer_model.uniplanner, self.b_features
@@ -264,6 +269,7 @@ class GraphedFramePipeline(FramePipeline):
         ego_embd, ego_cast, _ = up.embed_cast(ego_crop)
         ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
                            crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
+        ops.nonfinite_count([ego_embd, ego_plan, ego_cast], self.d_health)
         return dict(ego_embd=ego_embd, ego_plan_locs=ego_plan, ego_cast_locs=ego_cast[0, int(cmd_value)])
 
     def _g_others(self, n):
@@ -449,6 +455,19 @@ class GraphedFramePipeline(FramePipeline):
                        crop_size=up.crop_size * 2, cmd=int(cmd_value), impl="steps")[0, -1, 0]
         self.plan_aborts += 1
         return plan
+
+    def health(self, cmd_value: int = 3) -> dict:
+        """Counters of the drive so far (synchronises): non-finite output tensors seen by the graphs' own checks (ego embedding /
+        plan / cast, brake prediction, peak rows), persistent plan launches and how many of them timed out (sticky words of the
+        plan workspace on the ego stream - they count what the GPU did, whether or not the caller looked at the waypoints),
+        plans recomputed by recover_plan, device / host detection-decode disagreements, ticks that outgrew the static buffers."""
+        torch.cuda.synchronize()
+        up = self.infer_model.uniplanner
+        diag = ops.gru_plan_diag(1, up.plan_gru.hidden_size, up.num_cmds, int(cmd_value), self.device, stream=self.s_ego)
+        nonfinite, checks = (int(v) for v in self.d_health.cpu())
+        return dict(nonfinite_outputs=nonfinite, finite_checks=checks, plan_launches=diag["launches"], plan_aborts=diag["aborted_launches"],
+                    plans_recomputed=self.plan_aborts, decode_mismatches=self.decode_mismatches, overflow_ticks=self.overflow_ticks,
+                    last_plan_launch=diag)
 
     @torch.no_grad()
     def precapture(self, cmds=range(6), max_others=15):

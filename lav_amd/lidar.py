@@ -44,12 +44,22 @@ class _Engine(nn.Module):
         if self.__dict__.get("_eng") is not None:
             object.__setattr__(self, "_stale", True)
 
+    def _tensor_ids(self):
+        return tuple(id(t) for t in self.parameters()) + tuple(id(t) for t in self.buffers())
+
     def _fresh(self, device):
-        """The cached engine for `device`, brought up to date; None when there is none."""
+        """The cached engine for `device`, brought up to date; None when there is none (or when a parameter OBJECT was replaced -
+        load_state_dict(assign=True), module.weight = nn.Parameter(...) - since the engine was packed: the layers re-pack from
+        the tensors they were built from, so such an engine is dropped and rebuilt from the module)."""
         eng = self.__dict__.get("_eng")
         if eng is None or eng.get("device") != device:
             return None
+        if "tensor_ids" not in eng:
+            eng["tensor_ids"] = self._tensor_ids()
         if self.__dict__.get("_stale"):
+            if eng["tensor_ids"] != self._tensor_ids():
+                self._drop()
+                return None
             for layer in _refreshable(eng):
                 layer.refresh()
             object.__setattr__(self, "_stale", False)

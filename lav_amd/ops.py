@@ -7,6 +7,7 @@ current stream.  No function here has a torch/CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -318,6 +319,23 @@ def gru_plan_status(B: int, H: int, num_cmds: int, cmd: int, device, stream=None
     return int(status.value)
 
 
+def gru_plan_diag(B: int, H: int, num_cmds: int, cmd: int, device, stream=None) -> dict:
+    """The diagnosis words of the last persistent gru_plan launch on `stream` (include/lav_amd.h: lav_gru_plan_diag)."""
+    lib = _lib.load()
+    st = stream if stream is not None else torch.cuda.current_stream()
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ws = _workspaces.get(("plan", device, st.cuda_stream))
+    names = ("status", "entered", "abort_wg_plus1", "abort_wave", "abort_epoch", "abort_spins", "missing_granule", "tag_seen",
+             "abort_us", "completed", "aborted_launches", "launches")
+    if ws is None:
+        return dict.fromkeys(names, 0)
+    words = (C.c_int * 16)()
+    check(lib.lav_gru_plan_diag(_ptr(ws), ws.numel(), B, H, num_cmds, cmd, words, st.cuda_stream), "lav_gru_plan_diag")
+    return dict(zip(names, list(words)))
+
+
 # ------------------------------------------------------------------------------------------ conv
 class ConvLayer:
     """One fused convolution of the C ABI: packed weights + epilogue vectors resident in HBM.
@@ -457,7 +475,7 @@ class ConvLayer:
             if residual.shape != out.shape:
                 raise RuntimeError("residual shape mismatch")
         lib = _lib.load()
-        key = (B, h, w)
+        key = (B, h, w, _os.environ.get("LAV_CONV_SPLIT"))   # lav_conv2d re-reads the plan knob per call: the cached size follows it
         nbytes = self._ws_bytes.get(key)
         if nbytes is None:
             nbytes = self._ws_bytes[key] = lib.lav_conv_workspace_bytes(C.byref(d))
@@ -664,6 +682,17 @@ def channel_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) ->
     check(_lib.load().lav_channel_affine(_ptr(x), B, Cc, H * W, _ptr(_f32c(scale, "scale")), _ptr(_f32c(shift, "shift")), _ptr(out), _stream()),
           "lav_channel_affine")
     return out
+
+
+def nonfinite_count(tensors, counter: torch.Tensor) -> None:
+    """counter (2,) int32 in HBM: [0] += number of `tensors` (float32, contiguous, <= 8) holding a NaN / Inf, [1] += 1.
+    One launch, no host sync (include/lav_amd.h: lav_nonfinite_count)."""
+    ts = [_f32c(t, "tensor") for t in tensors]
+    n = len(ts)
+    if counter.dtype != torch.int32 or counter.numel() < 2 or not counter.is_cuda:
+        raise RuntimeError("nonfinite_count: counter must be an int32 tensor of two elements in HBM")
+    check(_lib.load().lav_nonfinite_count(n, (C.c_void_p * n)(*[t.data_ptr() for t in ts]), (C.c_long * n)(*[t.numel() for t in ts]),
+                                          _ptr(counter), _stream()), "lav_nonfinite_count")
 
 
 def copy_many(pairs) -> None:

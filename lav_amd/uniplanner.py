@@ -45,6 +45,13 @@ class UniPlanner(DecoderMixin, _Engine):
         self._drop_dec()
         object.__setattr__(self, "_offsets", None)
 
+    def _mark_stale(self):
+        """Parameters may have changed in place (train()/eval() toggle, load_state_dict): the conv engines re-pack themselves at
+        their next use; the stacked decoder weights and the cached offsets are plain copies, so they are dropped and rebuilt."""
+        super()._mark_stale()
+        self._drop_dec()
+        object.__setattr__(self, "_offsets", None)
+
     def offsets(self):
         """(offset_x, offset_y) as host floats, read from the parameters once (no device->host sync per frame;
         keeps the forward HIP-graph capturable)."""
