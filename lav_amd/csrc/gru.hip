@@ -335,6 +335,11 @@ constexpr size_t PLAN_CTRL_BYTES = 512;   // head of a plan workspace: sticky co
 
 // sticky[0] / sticky[1]: aborted / all persistent launches on this workspace since the caller zero-filled it (outside
 // the range the per-launch memset clears) - a benchmark or a drive reads them once at its end (lav_gru_plan_diag words 10, 11).
+__global__ __launch_bounds__(256) void k_plan_reset(uint4 *__restrict__ p, unsigned n16) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ status, int *__restrict__ sticky, float *__restrict__ out, long n_out) {
     const bool aborted = *status != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -349,6 +354,10 @@ __global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ sta
 // kernel, [2] 1 + workgroup / [3] wave / [4] epoch of the FIRST wave that gave up, [5] its spin count, [6] the granule index
 // it was waiting for, [7] the tag it last saw there, [8] microseconds between its kernel entry and the abort, [9] workgroups
 // that ran to completion.  The words are cleared with the granule tags at every launch.
+// POLL = 0: every wave sweeps all R*H granules itself (rounds 1-3).  POLL = 1 (H a multiple of 256): a wave polls only its quarter
+// of the state and the four quarters meet in LDS - a quarter of the polling traffic per workgroup (the chip's other streams pay
+// for every poll: MI355X guide, "polling-cost"), two loads instead of eight per lane and poll round.
+template <int POLL, int RC>   // RC: state rows held per register pass (1 for the frame's single commanded branch, else RC)
 __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status,
                                                          long long spin_limit) {
     const int H = a.H, T = a.T, R = a.R;
@@ -356,10 +365,11 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
     const int nk = H / 64;
     const unsigned long long t_entry = wall_clock64();
     if (tid == 0) atomicAdd(status + 1, 1);
-    __shared__ float gh_s[3 * PLAN_UNITS][PLAN_RC];
-    __shared__ float loc_s[2][PLAN_RC][64][2];
-    __shared__ float run_s[PLAN_RC][2];
+    __shared__ float gh_s[3 * PLAN_UNITS][RC];
+    __shared__ float loc_s[2][RC][64][2];
+    __shared__ float run_s[RC][2];
     __shared__ int abort_s;
+    __shared__ float h_s[POLL ? RC : 1][POLL ? 64 * PLAN_MAXK : 1];
     const int j0 = blockIdx.x * PLAN_UNITS;
     float w[6][PLAN_MAXK], bh[6];
 #pragma unroll
@@ -409,10 +419,10 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
         if (tid < R * 2) run_s[tid >> 1][tid & 1] = 0.f;
         for (int t = 0; t <= T; ++t) {  // t == T only gathers h_{T-1} to finish the iteration's waypoints
             const unsigned epoch = (unsigned)(it * T + t);  // the state published by the previous step carries this tag
-            float hv[PLAN_RC][PLAN_MAXK];
+            float hv[RC][PLAN_MAXK];
             if (t == 0) {
 #pragma unroll
-                for (int rr = 0; rr < PLAN_RC; ++rr) {
+                for (int rr = 0; rr < RC; ++rr) {
                     int b, ci, c;
                     row_decode(a, min(rr, R - 1), b, ci, c);
 #pragma unroll
@@ -422,17 +432,21 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                 const unsigned long long *g = gran + (long)((epoch - 1) & 1) * R * H;
                 long long spins = 0;
                 bool ok;
+                constexpr int NP = POLL ? PLAN_MAXK / 4 : PLAN_MAXK;   // granules per lane and row in one poll round
+                const int np = POLL ? nk / 4 : nk;
+                const int base = POLL ? wid * (H / 4) : 0;              // first unit of this wave's share
+                float pv[RC][NP];
                 do {
                     ok = true;
 #pragma unroll
-                    for (int rr = 0; rr < PLAN_RC; ++rr) {
+                    for (int rr = 0; rr < RC; ++rr) {
                         if (rr < R) {
 #pragma unroll
-                            for (int i = 0; i < PLAN_MAXK; ++i) {
-                                if (i < nk) {
-                                    const unsigned long long x = __hip_atomic_load(g + (long)rr * H + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (int i = 0; i < NP; ++i) {
+                                if (i < np) {
+                                    const unsigned long long x = __hip_atomic_load(g + (long)rr * H + base + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     ok = ok && (unsigned)(x >> 32) == epoch;
-                                    hv[rr][i] = __uint_as_float((unsigned)x);
+                                    pv[rr][i] = __uint_as_float((unsigned)x);
                                 }
                             }
                         }
@@ -448,9 +462,9 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                                     int bi = 0;
                                     unsigned bt = 0;
                                     for (int rr = R - 1; rr >= 0; --rr)
-                                        for (int i = nk - 1; i >= 0; --i) {
-                                            const unsigned long long x = __hip_atomic_load(g + (long)rr * H + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                            if ((unsigned)(x >> 32) != epoch) { bi = rr * H + lane + 64 * i; bt = (unsigned)(x >> 32); }
+                                        for (int i = np - 1; i >= 0; --i) {
+                                            const unsigned long long x = __hip_atomic_load(g + (long)rr * H + base + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                            if ((unsigned)(x >> 32) != epoch) { bi = rr * H + base + lane + 64 * i; bt = (unsigned)(x >> 32); }
                                         }
                                     status[3] = wid; status[4] = (int)epoch; status[5] = (int)min(spins, 0x7fffffffll);
                                     status[6] = bi; status[7] = (int)bt;
@@ -462,11 +476,33 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                         __builtin_amdgcn_s_sleep(2);
                     }
                 } while (!ok);
+                if constexpr (POLL) {   // the four quarters meet in LDS (also the rendezvous of an abort: every wave leaves together)
+#pragma unroll
+                    for (int rr = 0; rr < RC; ++rr)
+                        if (rr < R) {
+#pragma unroll
+                            for (int i = 0; i < NP; ++i)
+                                if (i < np) h_s[rr][base + lane + 64 * i] = pv[rr][i];
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (*(volatile int *)&abort_s) return;
+#pragma unroll
+                    for (int rr = 0; rr < RC; ++rr)
+                        if (rr < R) {
+#pragma unroll
+                            for (int i = 0; i < PLAN_MAXK; ++i) hv[rr][i] = i < nk ? h_s[rr][lane + 64 * i] : 0.f;
+                        }
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < RC; ++rr)
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) hv[rr][i] = pv[rr][i];
+                }
                 if (*(volatile int *)&abort_s) return;   // give up: never hang the device (k_plan_poison, next on the stream, voids the output)
                 // waypoint t-1 of this iteration from h_{t-1} (every workgroup needs it as next iteration's input)
                 if (wid == 0) {
 #pragma unroll
-                    for (int rr = 0; rr < PLAN_RC; ++rr) {
+                    for (int rr = 0; rr < RC; ++rr) {
                         if (rr < R) {
                             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -500,7 +536,7 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
             }
             if (t == T) break;
 #pragma unroll
-            for (int rr = 0; rr < PLAN_RC; ++rr) {
+            for (int rr = 0; rr < RC; ++rr) {
                 if (rr < R) {
                     float acc[6];
 #pragma unroll
@@ -625,10 +661,19 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
         unsigned long long *gran = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + PLAN_CTRL_BYTES);
         int *sticky = static_cast<int *>(workspace);
         int *status = sticky + 64;
-        LAV_HIP(hipMemsetAsync(status, 0, 256 + lav::align_up(gbytes, 256), st));  // status words and tags start at 0 (a whole number of 256-byte lines: one fill kernel)
+        // status words and tags start at 0.  A kernel, not hipMemsetAsync: a memset node captured into a HIP graph replays with a
+        // garbage fill value on ROCm 7.2 (first replay fine, later ones wrote a pointer-like pattern: every graph-mode frame of
+        // round 3 read a non-zero status word and poisoned a plan that had in fact completed - tools/plan_timeout_probe.py)
+        const unsigned reset_words = (unsigned)((256 + lav::align_up(gbytes, 256)) / 4);
+        hipLaunchKernelGGL(k_plan_reset, dim3((reset_words / 4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4 *>(status), reset_words / 4);
         const char *lim = getenv("LAV_PLAN_SPIN_LIMIT");   // test knob: 1 forces the time-out path
         const long long spin_limit = lim && atoll(lim) > 0 ? atoll(lim) : PLAN_SPIN_LIMIT;
-        hipLaunchKernelGGL(k_plan_persistent, dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit);
+        static const char *poll_env = getenv("LAV_PLAN_POLL");   // all | quarter (default where H allows it)
+        const bool quarter = H % 256 == 0 && !(poll_env && poll_env[0] == 'a');
+#define LAV_PLAN_CASE(P_, RC_) hipLaunchKernelGGL((k_plan_persistent<P_, RC_>), dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit)
+        if (a.R == 1) { if (quarter) LAV_PLAN_CASE(1, 1); else LAV_PLAN_CASE(0, 1); }
+        else { if (quarter) LAV_PLAN_CASE(1, PLAN_RC); else LAV_PLAN_CASE(0, PLAN_RC); }
+#undef LAV_PLAN_CASE
         const long n_out = (long)a.B * a.iters * a.NC * T * 2;
         hipLaunchKernelGGL(k_plan_poison, dim3((unsigned)std::min<long>((n_out + 255) / 256, 64)), dim3(256), 0, st, status, sticky, a.out, n_out);
         timer_end(tok, st);

@@ -116,9 +116,15 @@ def test_plan_timeout_is_loud_and_recoverable(golden, monkeypatch):
     monkeypatch.delenv("LAV_PLAN_SPIN_LIMIT")
     assert ops.gru_plan_status(1, 512, 6, 3, DEV) == 1, "a launch that gave up must raise the status word"
     assert torch.isnan(bad).all(), "and must not return anything that could pass for waypoints"
+    d = ops.gru_plan_diag(1, 512, 6, 3, DEV)   # who gave up, where: all 64 workgroups entered, the first to abort left its trace
+    assert d["status"] == 1 and d["entered"] == 64 and 1 <= d["abort_wg_plus1"] <= 64 and d["abort_epoch"] >= 1 and d["abort_spins"] >= 1, d
+    assert d["tag_seen"] != d["abort_epoch"] and d["aborted_launches"] >= 1
     again = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=3, impl="steps")
     torch.cuda.synchronize()
     assert_close(again.cpu().numpy(), good.cpu().numpy(), atol=2e-5, what="step path after an abort")
     back = up.plan(embd, nxp, cast_locs=cast, pixels_per_meter=4, crop_size=192, cmd=3)
     torch.cuda.synchronize()
     assert ops.gru_plan_status(1, 512, 6, 3, DEV) == 0 and torch.equal(back, good)
+    d2 = ops.gru_plan_diag(1, 512, 6, 3, DEV)
+    assert d2["status"] == 0 and d2["entered"] == 64 and d2["completed"] == 64 and d2["abort_wg_plus1"] == 0, d2
+    assert d2["launches"] >= d["launches"] + 1 and d2["aborted_launches"] == d["aborted_launches"]
