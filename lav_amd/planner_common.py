@@ -7,6 +7,14 @@ import torch.nn.functional as F
 from . import ops
 
 
+def _hip_train(what: str) -> bool:
+    """Diagnosis knob (tools/curve_bisect.py): LAV_TRAIN_<what>=torch runs that piece of the TRAINING graph on torch's own ops
+    (nn.GRU = MIOpen's RNN, affine_grid + grid_sample) instead of liblav_amd's autograd functions - to tell a kernel's effect on a
+    training run apart from everything else.  Inference never consults it."""
+    import os
+    return os.environ.get("LAV_TRAIN_" + what, "hip") != "torch"
+
+
 def stack_cast_weights(grus, mlps, device):
     """6 x nn.GRU(512,64) + 6 x nn.Linear(64,2) -> the stacked arrays lav_gru_cast takes."""
     g = lambda n: torch.stack([getattr(m, n).detach() for m in grus]).float().contiguous().to(device)
@@ -143,7 +151,7 @@ class DecoderMixin:
         B = embd.size(0)
         u = embd[:, None].expand(-1, self.num_plan, -1).contiguous()
         h0 = embd.new_zeros((1, B, nc * H))
-        if embd.is_cuda:   # liblav_amd's sequence GRU: the input is the same at every step, so it is projected once
+        if embd.is_cuda and _hip_train("GRU"):   # liblav_amd's sequence GRU: the input is the same at every step, so it is projected once
             out = ops.gru_seq(F.linear(embd, w_ih, b_ih), h0[0], w_hh, b_hh, self.num_plan)                       # (B, T, nc*H)
         else:
             out, _ = torch._VF.gru(u, h0, [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, self.training, False, True)
@@ -166,7 +174,7 @@ class DecoderMixin:
         outs = []
         for _ in range(self.num_plan_iter):
             u = torch.cat([u0, plan_loc.transpose(0, 1).reshape(nb * B, T, 2)], dim=2)
-            if u.is_cuda:
+            if u.is_cuda and _hip_train("GRU"):
                 g = self.plan_gru
                 hseq = ops.gru_seq(F.linear(u, g.weight_ih_l0, g.bias_ih_l0), h0[0], g.weight_hh_l0, g.bias_hh_l0, T)
             else:

@@ -103,7 +103,15 @@ GAINS = (
     ("backbone.conv1.0.weight", 0.6),
     ("backbone", 0.72),
     ("head.net.0.weight", 0.5),
-    ("bra.classifier.0.weight", 0.003),   # keeps the brake logit O(1): a saturated sigmoid would pin nothing
+    # The brake logit of random weights barely depends on the images (w.x = 0.486 .. 0.537 over the 24 ticks of agent_scenario()
+    # at gain 0.003).  Gain and bias (BIASES below) are chosen so that the reference agent's pred_bra falls on BOTH sides of its 0.1
+    # threshold along that drive (10 ticks below, 13 above, none within 0.07 of the threshold in logit): the fixture then pins the
+    # throttle / brake rules of run_step (lav_agent_fast.py:325-352), not only the steering.
+    ("bra.classifier.0.weight", 0.12),
+)
+# (state_dict key suffix -> value) for the few biases that are set, not drawn
+BIASES = (
+    ("bra.classifier.0.bias", -22.133),
 )
 
 
@@ -155,6 +163,9 @@ def seeded_state_dict(module: torch.nn.Module, seed: int = SEED, prefix: str = "
             a = r.uniform(-b, b, shape)
         elif v.dim() == 1:
             a = r.normal(0.0, 0.05, shape)
+            for sub, val in BIASES:
+                if (prefix + k).endswith(sub):
+                    a = np.full(shape, val)
             if "box_head.net.3.bias" in k:
                 a = a + 1.5  # boxes of ~1.5 px so that random-weight vehicle peaks survive
                              # det_inference's size filter (model_inference.py:110-111)

@@ -10,7 +10,7 @@ from torch import nn
 
 from . import ops
 from .lidar import _Engine
-from .planner_common import DecoderMixin, crop_feature, crop_feature_torch, sample_others, transform_points
+from .planner_common import _hip_train, DecoderMixin, crop_feature, crop_feature_torch, sample_others, transform_points
 from .resnet import resnet18
 
 
@@ -79,7 +79,7 @@ class UniPlanner(DecoderMixin, _Engine):
         """map_index (int32, per crop): take crop i from features[map_index[i]] instead of features[i] - the training
         forwards crop several vehicles out of each sample's map without materialising one copy of the map per vehicle."""
         ox, oy = self.offsets()
-        if map_index is not None and features.is_cuda:          # HIP forward + backward (autograd.Function)
+        if map_index is not None and features.is_cuda and (_hip_train("CROP") or not self.training):   # HIP forward + backward (autograd.Function)
             return ops.crop_rotate_indexed(features, map_index, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
         if map_index is not None:
             features = features[map_index.long()]

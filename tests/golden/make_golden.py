@@ -457,11 +457,13 @@ def gold_train():
         torch.set_grad_enabled(False)
 
 
-def gold_train_curve(steps=None):
+def gold_train_curve(steps=None, name="train_curve", batch=2, points=20000, nbatches=4, seed0=40):
     """BASELINE.json config #5 asks for a loss-curve match over 500 steps: the REFERENCE trainer (lav/lav_final_v2.py
     `train_lidar`, the loop of lav/train_full_v2.py:24-46) on CPU over `steps` optimisation steps, cycling through four
     seeded synthetic batches of 2 samples (20 000-point clouds), global torch seed re-set per step like gold_train.
-    Stores every loss term of every step (tests/golden/train_curve.npz)."""
+    Stores every loss term of every step (tests/golden/train_curve.npz).
+    `train_curve_b8` (round 4): the same at batch 8 with config #5's own cloud size (120 000 points), two alternating batches,
+    100 steps - the largest batch the reference's CPU run finishes in the build container's time budget."""
     import types
     sys.path.insert(0, REF)
     import lav.lav_final_v2 as ref_final  # noqa: E402  (reference)
@@ -491,19 +493,20 @@ def gold_train_curve(steps=None):
     try:
         trainer = ref_final.LAV(args)
         trainer.distill = True
-        batches = [synthetic_lidar_batch(2, seed=40 + i, max_points=20000, num_objs=3) for i in range(4)]
+        batches = [synthetic_lidar_batch(batch, seed=seed0 + i, max_points=points, num_objs=3) for i in range(nbatches)]
         keys = ("hm_loss", "box_loss", "ori_loss", "seg_loss", "plan_loss", "ego_cast_loss", "other_cast_loss", "cmd_loss")
         rows = []
         import time
         t0 = time.time()
+        meta = dict(keys=np.array(keys), batch=np.array([batch]), points=np.array([points]), nbatches=np.array([nbatches]), seed0=np.array([seed0]))
         for step in range(steps):
             torch.manual_seed(1000 + step)
-            info = trainer.train_lidar(*batches[step % 4])
+            info = trainer.train_lidar(*batches[step % nbatches])
             rows.append([info[k] for k in keys])
             if step % 10 == 0:
                 print(f"curve step {step}: {[round(v, 4) for v in rows[-1]]}  ({time.time() - t0:.0f} s)", flush=True)
-                save("train_curve", terms=np.array(rows), keys=np.array(keys))
-        save("train_curve", terms=np.array(rows), keys=np.array(keys))
+                save(name, terms=np.array(rows), **meta)
+        save(name, terms=np.array(rows), **meta)
     finally:
         torch.load = real_load
         torch.set_grad_enabled(False)
@@ -579,6 +582,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:] == ["train_curve"]:     # only the loss-curve fixture (hours of CPU time)
         gold_train_curve()
+        sys.exit(0)
+    if sys.argv[1:] == ["train_curve_b8"]:     # config #5's cloud size at batch 8, 100 steps (about an hour of CPU time)
+        gold_train_curve(steps=int(os.environ.get("LAV_CURVE_STEPS", "100")), name="train_curve_b8", batch=8, points=120000, nbatches=2, seed0=60)
         sys.exit(0)
     if sys.argv[1:] == ["datasets"]:     # only the data-loader fixture
         gold_datasets()

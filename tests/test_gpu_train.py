@@ -247,6 +247,14 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     assert early.max() < 0.05, f"the first 60 smoothed steps leave the band: {early.max():.3f}"
     assert whole.max() < 0.45, f"the 100-step moving average leaves the band: {whole.max():.3f}"
     assert 0.55 * final_r < final_o < 1.25 * final_r, f"final level {final_o:.2f} vs the reference's {final_r:.2f}"
+    # Per term (round 4, profiles/r04_loss_curve_bisect.md): the heat-map, segmentation and command terms are reproducible observables -
+    # every run measured, on the MI355X and on the CPU, holds the reference's 100-step average within 2 % over all 500 steps; the
+    # trajectory-forecast terms within 10-26 %.  (box / ori / plan are the chaotic ones: the CPU port of this very trainer, run with
+    # 3 instead of 4 threads, leaves the reference's average by up to 168 % - their bars are the total's, above.)
+    for k, bar in (("hm_loss", 0.05), ("seg_loss", 0.05), ("cmd_loss", 0.05), ("ego_cast_loss", 0.35), ("other_cast_loss", 0.35)):
+        j = keys.index(k)
+        dev = (np.abs(smooth(ours[:, j], 100) - smooth(ref[:, j], 100)) / smooth(ref[:, j], 100)).max()
+        assert dev < bar, f"{k}: 100-step moving average leaves the reference's by {dev:.3f} (bar {bar})"
     # the loss terms that training drives down go down here too (detection heat-map, box, orientation, motion terms)
     for j, k in enumerate(keys):
         if ref[-100:, j].mean() < 0.5 * ref[:20, j].mean():
