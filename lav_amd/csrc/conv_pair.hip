@@ -247,6 +247,18 @@ __device__ __forceinline__ void pair_split3(float x, unsigned &p0, unsigned &p1,
     p2 = __float_as_uint(r2) + 0x8000u;
 }
 __device__ __forceinline__ unsigned pair_pack(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
+// two values at once on v_cvt_pk_bf16_f32 (= split3_pair of conv_split.hpp: 13 instructions per pair instead of ~25)
+typedef __bf16 pair_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pair_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pair_split3x2(float x0, float x1, unsigned &q0, unsigned &q1, unsigned &q2) {
+    constexpr float M = 3.3895313892515355e38f;   // the largest finite bf16
+    const float c0 = __builtin_amdgcn_fmed3f(x0, -M, M), c1 = __builtin_amdgcn_fmed3f(x1, -M, M);
+    q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(pair_f32x2{c0, c1}, pair_bf16x2));
+    const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+    q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(pair_f32x2{r0, r1}, pair_bf16x2));
+    const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+    q2 = __builtin_bit_cast(unsigned, __builtin_convertvector(pair_f32x2{s0, s1}, pair_bf16x2));
+}
 
 struct PairSplitArgs {
     const float *x, *bA, *bB, *scale, *shift, *res;
@@ -318,10 +330,9 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_split(PairSplitArgs a)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x0 = ok[u] ? v[u][8 * h + 2 * e] : 0.f, x1 = ok[u] ? v[u][8 * h + 2 * e + 1] : 0.f;
-                        unsigned e0, e1, e2, o0, o1, o2;
-                        pair_split3(x0, e0, e1, e2);
-                        pair_split3(x1, o0, o1, o2);
-                        q3[0][e] = pair_pack(e0, o0); q3[1][e] = pair_pack(e1, o1); q3[2][e] = pair_pack(e2, o2);
+                        unsigned p0, p1, p2;
+                        pair_split3x2(x0, x1, p0, p1, p2);
+                        q3[0][e] = p0; q3[1][e] = p1; q3[2][e] = p2;
                     }
                     const int entry = ((c * 2 + h) * 3 + t) * W + pxs;
 #pragma unroll
@@ -391,18 +402,18 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_split(PairSplitArgs a)
         // this lane: pixel px, channels cg*32 + 8*g8 + 4*half + e (g8 = 0..3, e = 0..3) = acc[4*g8 + e]
 #pragma unroll
         for (int g8 = 0; g8 < 4; ++g8) {
-            unsigned p[3][4];
+            unsigned pk[3][2];   // pieces of channels (0, 1) and (2, 3) of the lane's four
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float vv = acc[4 * g8 + e] + bAv[4 * g8 + e];
-                pair_split3(vv > 0.f ? vv : 0.f, p[0][e], p[1][e], p[2][e]);
+            for (int e = 0; e < 2; ++e) {
+                const float v0 = acc[4 * g8 + 2 * e] + bAv[4 * g8 + 2 * e], v1 = acc[4 * g8 + 2 * e + 1] + bAv[4 * g8 + 2 * e + 1];
+                pair_split3x2(v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f, pk[0][e], pk[1][e], pk[2][e]);
             }
             const int grp = cg * 4 + g8;   // 8-channel group = chunk * 2 + k half
             if (grp * 8 < C) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     *reinterpret_cast<u32x2 *>(s_mid + pl * mid_piece + (grp * WM + a.dB + px) * 16 + half * 8) =
-                        u32x2{pair_pack(p[pl][0], p[pl][1]), pair_pack(p[pl][2], p[pl][3])};
+                        u32x2{pk[pl][0], pk[pl][1]};
             }
         }
     }

@@ -69,6 +69,23 @@ __device__ __forceinline__ void split3(float x, unsigned &p0, unsigned &p1, unsi
     const float r2 = r1 - __uint_as_float(p1);         // exact
     p2 = __float_as_uint(r2) + 0x8000u;                // low half is dropped by the pack
 }
+// Two values at once on the conversion unit (round 4): v_cvt_pk_bf16_f32 rounds both to bf16 (nearest even) and packs them, so a
+// pair costs 13 instructions instead of ~25 - the activation loaders' conversion of a chunk sat in the critical path of its
+// barrier interval (in-kernel trace of the BEV layers: 2.4 k cycles per chunk).  q0..q2 = the three pieces of (x0, x1), x0 in the
+// low half.  Exactness as split3: x - bf16(x) and the second remainder are exact, the third piece has at most 8 significant bits
+// left.  The first piece of |x| > the largest finite bf16 is that bound (the remainder carries the rest): no finite input
+// overflows; Inf / NaN end in NaN outputs as documented in lav_amd.h.
+typedef __bf16 split_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &q0, unsigned &q1, unsigned &q2) {
+    constexpr float M = 3.3895313892515355e38f;   // 0x7f7f0000
+    const float c0 = __builtin_amdgcn_fmed3f(x0, -M, M), c1 = __builtin_amdgcn_fmed3f(x1, -M, M);
+    q0 = __builtin_bit_cast(unsigned, __builtin_convertvector(split_f32x2{c0, c1}, split_bf16x2));
+    const float r0 = x0 - __uint_as_float(q0 << 16), r1 = x1 - __uint_as_float(q0 & 0xffff0000u);
+    q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(split_f32x2{r0, r1}, split_bf16x2));
+    const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+    q2 = __builtin_bit_cast(unsigned, __builtin_convertvector(split_f32x2{s0, s1}, split_bf16x2));
+}
 // {hi half of odd, hi half of even} -> one dword of two bf16 (even in the low half)
 __device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
 
@@ -240,10 +257,9 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
                         const int c0 = 8 * h + 2 * e;
                         const float x0 = c0 < nc ? (ok ? v[i][c0] : a.pad_value) : 0.f;
                         const float x1 = c0 + 1 < nc ? (ok ? v[i][c0 + 1] : a.pad_value) : 0.f;
-                        unsigned e0, e1, e2, o0, o1, o2;
-                        split3(x0, e0, e1, e2);
-                        split3(x1, o0, o1, o2);
-                        q[0][h][e] = pack_hi(e0, o0); q[1][h][e] = pack_hi(e1, o1); q[2][h][e] = pack_hi(e2, o2);
+                        unsigned p0, p1, p2;
+                        split3_pair(x0, x1, p0, p1, p2);
+                        q[0][h][e] = p0; q[1][h][e] = p1; q[2][h][e] = p2;
                     }
                 if (pos < plane) {
 #pragma unroll
@@ -563,8 +579,10 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
             if (plane > SPLIT_LOADERS * SPLIT_NT) continue;
             {
                 // LDS: two activation chunk buffers + a ring of three groups of G taps of weights
-                for (int G : {2, 1}) {
-                    if (f_tg && G != f_tg) continue;
+                static const int g_max = [] { const char *e = getenv("LAV_SPLIT_GMAX"); return e ? atoi(e) : 4; }();
+                for (int G : {4, 2, 1}) {
+                    if (G > g_max || (f_tg && G != f_tg)) continue;
+                    if (G == 4 && MP * MC > 2 && !f_tg) continue;   // 2x2 tiles have 24 matrix instructions per tap: a barrier every 2 taps is amortised
                     if (2 * G > min_taps + 1 && G > 1) continue;   // 2G consecutive taps must touch at most two chunks (in every class)
                     const size_t lds_in = (size_t)2 * 6 * plane * 16, wslot = (size_t)NBLK * 3 * 1024;
                     const size_t lds = lds_in + 3 * G * wslot;
@@ -602,6 +620,7 @@ int launch_split_g(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
 template <int MP, int MC, int WPX>
 int launch_split_t(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
     const bool small = sa.plane <= SPLIT_LOADERS * 2;
+    if (sa.tap_group == 4) return small ? launch_split_g<MP, MC, WPX, 2, 4>(sa, grid, lds, st) : launch_split_g<MP, MC, WPX, SPLIT_NT, 4>(sa, grid, lds, st);
     if (sa.tap_group == 2) return small ? launch_split_g<MP, MC, WPX, 2, 2>(sa, grid, lds, st) : launch_split_g<MP, MC, WPX, SPLIT_NT, 2>(sa, grid, lds, st);
     return small ? launch_split_g<MP, MC, WPX, 2, 1>(sa, grid, lds, st) : launch_split_g<MP, MC, WPX, SPLIT_NT, 1>(sa, grid, lds, st);
 }
