@@ -472,6 +472,24 @@ int lav_bn_train_backward(const float *x, const float *y, const float *dy, int b
  * ------------------------------------------------------------------------------------------ */
 size_t lav_conv1d_pair_packed_weight_floats(int channels);
 int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_packed);
+/*
+ * lav_conv1d_pair_chain: a RUN of such pairs over one map - the non_bottleneck_1d blocks of an ERFNet stage
+ * (lav/models/erfnet.py:25-62: 5 blocks at 64 channels, 8 dilated ones at 128, 2 + 2 in the decoder) - as ONE persistent launch:
+ * a workgroup per image row walks all pairs; between two pairs only its two neighbour rows (y -+ d_a) travel through memory
+ * (write-through stores + a per-row progress counter), its own row, the block residual and the next pair's first weights never
+ * leave the CU.  residual[i] != 0: pair i adds the INPUT of pair i-1 (the block's input) before its ReLU; the run starts at a
+ * block boundary.  out[i]: output buffer of pair i ([batch][channels][h][w] each, all distinct; out[npairs-1] is the result).
+ * batch * h must not exceed the CU count (every row's workgroup waits for its neighbours'); bf16x6 precision only.  Waits are
+ * bounded: lav_conv1d_pair_chain_status returns how many workgroups of the last launch gave up (0 = the result is valid).
+ * workspace: lav_conv1d_pair_chain_workspace_bytes, private to the stream.
+ */
+size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h);
+size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max);
+int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
+                          const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
+                          const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
+                          const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream);
+int lav_conv1d_pair_chain_status(const void *workspace, int batch, int h, int *h_timeouts, void *stream);
 size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b);
 int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,
                     const float *bias_a, const float *wb_packed, const float *bias_b, const float *scale, const float *shift,

@@ -26,6 +26,8 @@
 #include <cstring>
 #include <vector>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -484,6 +486,308 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_split(PairSplitArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent chain
+// A RUN of pairs (the non_bottleneck_1d blocks of one ERFNet stage: same channels and map, dilations per pair) as ONE launch
+// (round 4).  One workgroup per image row, as above, walks the whole run.  What that removes per pair: the kernel boundary,
+// the argument fetch, the staging of the workgroup's OWN row (it is converted into the next pair's LDS slot in the epilogue,
+// never re-read), the residual's round trip (a block's input row stays in registers until its second pair adds it), and the
+// exposed latency of the first weight fragments (requested while the previous pair's last chunks are multiplied).  What is left
+// between two pairs is the hand-off of the two NEIGHBOUR rows y -+ dA: every row is published with write-through (sc1) stores,
+// `s_waitcnt vmcnt(0)`, barrier, then a relaxed agent-scope counter flags[row] = pairs done (MI355X guide, Guideline 16 write-
+// through form); a consumer polls its two neighbours' counters with one lane and reads their rows with sc1 loads.  Every pair
+// writes its own buffer, so there is no write-after-read hazard whatever the dilations.  Progress: the row with the fewest pairs
+// done never waits (its neighbours are at least as far), so the run completes as soon as every workgroup is resident
+// (B*H <= the CU count: checked by the host); spins are bounded and raise a status word instead of hanging.
+constexpr int CHAIN_MAX = 16;
+struct PairChainArgs {
+    const float *x0;                  // input of the run [B][C][H][W]
+    float *out[CHAIN_MAX];            // output of pair i (the last one is the run's result)
+    const unsigned char *wA[CHAIN_MAX], *wB[CHAIN_MAX];
+    const float *bA[CHAIN_MAX], *bB[CHAIN_MAX], *scale[CHAIN_MAX], *shift[CHAIN_MAX];
+    unsigned char dA[CHAIN_MAX], dB[CHAIN_MAX], res[CHAIN_MAX], relu[CHAIN_MAX];   // res: add the input of the pair before (block residual)
+    int *flags;                       // [B*H] pairs completed by the row, zero at launch; [B*H] = status word (time-outs)
+    int B, C, H, W, CP, npairs;
+    long long spin_limit;
+};
+
+template <int KS, int R>
+__global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int wid = wid8 & 3, kpart = wid8 >> 2;
+    const int C = a.C, W = a.W, H = a.H, CP = a.CP;
+    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    const int NPG = W >> 5, npg_sh = NPG >> 1;
+    const int pg = wid & (NPG - 1), cg = wid >> npg_sh;
+    const int px = pg * 32 + l31;
+    const bool co_ok = cg * 32 < CP;
+    const int nchunk = C >> 4, nblk = CP >> 5;
+    // LDS: s_red [4 waves][16][64] floats (its own region here: the next pair's rows are staged while nothing else is read),
+    //      s_in [3 pieces][nchunk][2][3 rows][W] x 16 B, s_mid [3 pieces][nchunk][2][W + 2 dB] x 16 B (sized for the run's largest dB)
+    const int in_piece = nchunk * 2 * 3 * W * 16;
+    float *s_red = reinterpret_cast<float *>(smem_raw);
+    unsigned char *s_in = smem_raw + 16384, *s_mid = s_in + 3 * in_piece;
+    __shared__ int s_abort;
+    __shared__ float s_epi[4][128];   // per pair: bias of the 3x1 convolution, bias of the 1x3 one, BatchNorm scale and shift
+    const int ch_lo = kpart * (nchunk / KS), ch_hi = kpart == KS - 1 ? nchunk : ch_lo + nchunk / KS;
+    const int nch = ch_hi - ch_lo;   // multiple of R
+    const long plane = (long)H * W;
+    const long base = (long)n * C * plane + (long)y * W + px;
+    if (tid == 0) s_abort = 0;
+
+    u32x4 wr[R][3][3];
+    auto load_w = [&](const unsigned char *wp, int t, int chunk, u32x4 (&dst)[3]) {
+        const unsigned char *p = wp + ((((long)t * nchunk + chunk) * nblk + cg) * 3) * 1024 + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const u32x4 *>(p + pl * 1024);
+    };
+    // rows of `src` into s_in: all three (first pair) or only the neighbours' (t = 0, 2); task = (chunk, row, pixel), 16 channel loads
+    auto stage_rows = [&](const float *src, int dA, auto ALL_ROWS_, bool coherent) __attribute__((always_inline)) {
+        constexpr bool all_rows = decltype(ALL_ROWS_)::value;
+        constexpr int nrow = all_rows ? 3 : 2;
+        const int ntask = nchunk * nrow * W;
+        const float *xn = src + (long)n * C * plane;
+        // tasks per thread: C W <= 4096, so three rows are at most 768 tasks and two rows 512, over 256 KS threads
+        constexpr int NTK = all_rows ? (KS == 2 ? 2 : 3) : (KS == 2 ? 1 : 2);
+        float v[NTK][16];
+        int task[NTK];
+        bool ok[NTK];
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            task[u] = tid + u * 256 * KS;
+            const int tk = min(task[u], ntask - 1);
+            const int pxs = tk & (W - 1), q = tk >> (5 + npg_sh), c = q / nrow, tt = q - nrow * c;
+            const int t = all_rows ? tt : 2 * tt;
+            const int yy = y + (t - 1) * dA;
+            ok[u] = task[u] < ntask && yy >= 0 && yy < H;
+            const float *sp = xn + ((long)c * 16 * H + (ok[u] ? yy : 0)) * W + pxs;
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch)
+                v[u][ch] = coherent ? __hip_atomic_load(sp + ch * plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sp[ch * plane];
+        }
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            if (task[u] < ntask) {
+                const int pxs = task[u] & (W - 1), q = task[u] >> (5 + npg_sh), c = q / nrow, tt = q - nrow * c;
+                const int t = all_rows ? tt : 2 * tt;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 q3[3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = ok[u] ? v[u][8 * h + 2 * e] : 0.f, x1 = ok[u] ? v[u][8 * h + 2 * e + 1] : 0.f;
+                        unsigned p0, p1, p2;
+                        pair_split3x2(x0, x1, p0, p1, p2);
+                        q3[0][e] = p0; q3[1][e] = p1; q3[2][e] = p2;
+                    }
+                    const int entry = ((c * 2 + h) * 3 + t) * W + pxs;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(s_in + pl * in_piece + entry * 16) = q3[pl];
+                }
+            }
+        }
+    };
+    stage_rows(a.x0, a.dA[0], std::true_type{}, false);
+    if (co_ok) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) load_w(a.wA[0], t, ch_lo + i, wr[i][t]);
+    }
+    // the block's input row in registers (what the block's second pair adds back): this lane's 16 channels of pixel px
+    float blk_in[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk_in[r] = a.x0[base + (long)min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1) * plane];
+
+    auto mma6 = [&](f32x16 &acc, const u32x4 (&w)[3], const u32x4 (&b)[3]) {
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[PA[k]]), __builtin_bit_cast(bf16x8, b[PB[k]]), acc, 0, 0, 0);
+    };
+
+    for (int p = 0; p < a.npairs; ++p) {
+        const int dA = a.dA[p], dB = a.dB[p];
+        const int WM = W + 2 * dB, mid_piece = nchunk * 2 * WM * 16;
+        const unsigned char *wA = a.wA[p], *wB = a.wB[p];
+        const bool last = p + 1 == a.npairs;
+        if (p > 0) {
+            // ---- the two neighbour rows of the previous pair's output: wait for their counters, then stage them
+            if (wid8 == 0) {
+                const int yu = y - dA, yd = y + dA;
+                long long spins = 0;
+                bool ok = false;
+                while (!ok) {
+                    const int fu = yu >= 0 ? __hip_atomic_load(a.flags + n * H + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
+                    const int fd = yd < H ? __hip_atomic_load(a.flags + n * H + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
+                    ok = fu >= p && fd >= p;
+                    if (!ok) {
+                        if (++spins > a.spin_limit) {   // never hang the device: the result is void, the status word says so
+                            if (lane == 0) { s_abort = 1; atomicAdd(a.flags + a.B * H, 1); }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            __syncthreads();
+            stage_rows(a.out[p - 1], dA, std::false_type{}, true);
+        }
+        if (tid < C) {   // the pair's epilogue vectors: through LDS, so that they hold no registers while the phases run
+            s_epi[0][tid] = a.bA[p][tid];
+            s_epi[1][tid] = a.bB[p][tid];
+            s_epi[2][tid] = a.scale[p][tid];
+            s_epi[3][tid] = a.shift[p][tid];
+        }
+        {   // zero halo of the intermediate row (all pieces, all 8-channel groups)
+            const int ngrp = nchunk * 2, nh = 2 * dB;
+            for (int i = tid; i < 3 * ngrp * nh; i += 256 * KS) {
+                const int j = i % nh, g = (i / nh) % ngrp, pl = i / (nh * ngrp);
+                *reinterpret_cast<u32x4 *>(s_mid + pl * mid_piece + (g * WM + (j < dB ? j : W + j)) * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        __syncthreads();
+
+        // ---- phase A: vertical taps
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (co_ok) {
+            for (int j0 = 0; j0 < nch; j0 += R) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ch = ch_lo + j0 + i;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        u32x4 b[3];
+                        const int entry = ((ch * 2 + half) * 3 + t) * W + px;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(s_in + pl * in_piece + entry * 16);
+                        mma6(acc, wr[i][t], b);
+                    }
+                    const int nxt = j0 + i + R;
+                    const unsigned char *wsrc = nxt < nch ? wA : wB;
+                    const int nch_src = nxt < nch ? ch_lo + nxt : ch_lo + nxt - nch;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) load_w(wsrc, t, nch_src, wr[i][t]);
+                }
+            }
+        }
+        if constexpr (KS == 2) {
+            if (kpart == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+            }
+            __syncthreads();
+            if (kpart == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+            }
+        }
+        if (co_ok && kpart == 0) {
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {
+                unsigned pk[3][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int cch = min(cg * 32 + 8 * g8 + 4 * half + 2 * e, C - 2);
+                    const float v0 = acc[4 * g8 + 2 * e] + s_epi[0][cch], v1 = acc[4 * g8 + 2 * e + 1] + s_epi[0][cch + 1];
+                    pair_split3x2(v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f, pk[0][e], pk[1][e], pk[2][e]);
+                }
+                const int grp = cg * 4 + g8;
+                if (grp * 8 < C) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        *reinterpret_cast<u32x2 *>(s_mid + pl * mid_piece + (grp * WM + dB + px) * 16 + half * 8) = u32x2{pk[pl][0], pk[pl][1]};
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: horizontal taps over the intermediate; the ring is refilled with the NEXT pair's first vertical fragments
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char *wNext = a.wA[last ? p : p + 1];
+        if (co_ok) {
+            for (int j0 = 0; j0 < nch; j0 += R) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ch = ch_lo + j0 + i;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        u32x4 b[3];
+                        const int entry = (ch * 2 + half) * WM + px + t * dB;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4 *>(s_mid + pl * mid_piece + entry * 16);
+                        mma6(acc, wr[i][t], b);
+                    }
+                    const int nxt = j0 + i + R;
+                    const unsigned char *wsrc = nxt < nch ? wB : wNext;
+                    const int nch_src = nxt < nch ? ch_lo + nxt : ch_lo + nxt - nch;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) load_w(wsrc, t, nch_src, wr[i][t]);
+                }
+            }
+        }
+        if constexpr (KS == 2) {   // (phase A's partials were read before the barrier that followed the intermediate row's stores)
+            if (kpart == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+            }
+            __syncthreads();
+            if (kpart == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+            }
+        }
+        // ---- epilogue: bias, BatchNorm, block residual, ReLU; the row goes out write-through and into the next pair's LDS slot
+        if (co_ok && kpart == 0) {
+            float vout[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co_ = min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1);
+                float v = fmaf(acc[r] + s_epi[1][co_], s_epi[2][co_], s_epi[3][co_]);   // the single-pair kernel's arithmetic, bit for bit
+                if (a.res[p]) v += blk_in[r];
+                if (a.relu[p]) v = v > 0.f ? v : 0.f;
+                vout[r] = v;
+            }
+            float *yo = a.out[p];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < C) {
+                    if (last) yo[base + co * plane] = vout[r];
+                    else __hip_atomic_store(yo + base + co * plane, vout[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (!last) {
+#pragma unroll
+                for (int g8 = 0; g8 < 4; ++g8) {
+                    unsigned pk[3][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) pair_split3x2(vout[4 * g8 + 2 * e], vout[4 * g8 + 2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                    const int grp = cg * 4 + g8;
+                    if (grp * 8 < C) {
+                        const int entry = (grp * 3 + 1) * W + px;   // (chunk * 2 + k half) = grp, row slot t = 1
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            *reinterpret_cast<u32x2 *>(s_in + pl * in_piece + entry * 16 + half * 8) = u32x2{pk[pl][0], pk[pl][1]};
+                    }
+                }
+                if (a.res[p]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) blk_in[r] = vout[r];
+                }
+            }
+        }
+        if (last) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row stores have left (write-through): the counter may follow
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flags + n * H + y, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (*(volatile int *)&s_abort) return;
+    }
+}
+
 // fp32 floats of the exact packing of one convolution of a pair
 inline size_t pair_f32_floats(int channels) {
     const int CP = (channels + 31) / 32 * 32;
@@ -637,5 +941,86 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+}  // namespace
+
+extern "C" size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h) {
+    return batch > 0 && h > 0 ? lav::align_up((size_t)(batch * h + 1) * sizeof(int), 256) : 0;
+}
+
+extern "C" size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max) {
+    return 16384 + (size_t)channels * w * 18 + (size_t)channels * (w + 2 * d_b_max) * 6;
+}
+
+extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
+                                     const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
+                                     const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
+                                     const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream) {
+    LAV_REQUIRE(pair_use_split(), "lav_conv1d_pair_chain: the persistent run exists for the bf16x6 kernels only (LAV_CONV_PRECISION=f32 runs the pairs one launch each)");
+    LAV_REQUIRE(batch >= 1 && h >= 1 && npairs >= 1 && npairs <= CHAIN_MAX, "lav_conv1d_pair_chain: 1..%d pairs", CHAIN_MAX);
+    LAV_REQUIRE(w == 32 || w == 64 || w == 128, "lav_conv1d_pair_chain: row width %d not in {32, 64, 128}", w);
+    LAV_REQUIRE(channels >= 16 && channels % 16 == 0 && (channels + 31) / 32 <= 128 / w,
+                "lav_conv1d_pair_chain: %d channels do not fit a %d-pixel row tile (at most %d)", channels, w, 32 * (128 / w));
+    LAV_REQUIRE(d_a && d_b && residual && relu_post && x && wa_packed && bias_a && wb_packed && bias_b && scale && shift && out, "lav_conv1d_pair_chain: null argument");
+    LAV_REQUIRE(workspace && workspace_bytes >= lav_conv1d_pair_chain_workspace_bytes(batch, h), "lav_conv1d_pair_chain: workspace too small");
+    // every row's workgroup must be resident at once (they wait for each other): one workgroup per CU at these LDS sizes
+    static const int cus = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    LAV_REQUIRE(batch * h <= cus, "lav_conv1d_pair_chain: %d rows exceed the %d compute units (run the pairs one launch each)", batch * h, cus);
+    PairChainArgs a;
+    int dbmax = 1;
+    for (int i = 0; i < CHAIN_MAX; ++i) {
+        const int j = i < npairs ? i : npairs - 1;
+        LAV_REQUIRE(d_a[j] >= 1 && d_b[j] >= 1 && d_b[j] <= 16 && d_a[j] < 256, "lav_conv1d_pair_chain: bad dilation");
+        LAV_REQUIRE(wa_packed[j] && bias_a[j] && wb_packed[j] && bias_b[j] && scale[j] && shift[j] && out[j], "lav_conv1d_pair_chain: null argument of pair %d", j);
+        a.out[i] = out[j];
+        a.wA[i] = reinterpret_cast<const unsigned char *>(wa_packed[j] + pair_f32_floats(channels));
+        a.wB[i] = reinterpret_cast<const unsigned char *>(wb_packed[j] + pair_f32_floats(channels));
+        a.bA[i] = bias_a[j]; a.bB[i] = bias_b[j]; a.scale[i] = scale[j]; a.shift[i] = shift[j];
+        a.dA[i] = (unsigned char)d_a[j]; a.dB[i] = (unsigned char)d_b[j]; a.res[i] = residual[j] ? 1 : 0; a.relu[i] = relu_post[j] ? 1 : 0;
+        dbmax = std::max(dbmax, d_b[j]);
+    }
+    LAV_REQUIRE(!residual[0], "lav_conv1d_pair_chain: the run starts at a block boundary (its first pair has no residual)");
+    a.x0 = x; a.flags = static_cast<int *>(workspace);
+    a.B = batch; a.C = channels; a.H = h; a.W = w; a.CP = (channels + 31) / 32 * 32; a.npairs = npairs;
+    static const long long spin_limit = [] { const char *e = getenv("LAV_CHAIN_SPIN_LIMIT"); return e && atoll(e) > 0 ? atoll(e) : (1ll << 21); }();
+    a.spin_limit = spin_limit;
+    const size_t lds = lav_conv1d_pair_chain_lds_bytes(channels, w, dbmax);
+    LAV_REQUIRE(lds <= 156 * 1024, "lav_conv1d_pair_chain: %zu bytes of LDS needed", lds);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nflag = batch * h + 1;
+    hipLaunchKernelGGL(k_zero_ints, dim3((nflag + 255) / 256), dim3(256), 0, st, a.flags, nflag);
+    const int ks2 = channels >= 64 && (channels / 16) % 2 == 0 ? 2 : 1;
+    const int nch2 = channels / 16 / ks2;
+    // weight ring of at most two chunks: the four-chunk ring of the single-pair kernel does not fit the registers next to the
+    // block's input row and the next pair's prefetch (364 bytes of scratch per lane)
+    const int ring2 = nch2 % 2 == 0 ? 2 : 1;
+    const int tok = timer_begin("conv1d_pair", st);
+#define LAV_CHAIN_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
+        static bool attr = false;   /* (the kernel also holds ~2 KB of static LDS: the dynamic part may not claim all 160 KB) */ \
+        if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_conv1d_pair_chain<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, st, a); }
+    LAV_CHAIN_CASE(1, 1) LAV_CHAIN_CASE(1, 2) LAV_CHAIN_CASE(2, 1) LAV_CHAIN_CASE(2, 2)
+#undef LAV_CHAIN_CASE
+    timer_end(tok, st);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
+
+extern "C" int lav_conv1d_pair_chain_status(const void *workspace, int batch, int h, int *h_timeouts, void *stream) {
+    LAV_REQUIRE(workspace && h_timeouts && batch >= 1 && h >= 1, "lav_conv1d_pair_chain_status: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LAV_HIP(hipMemcpyAsync(h_timeouts, static_cast<const int *>(workspace) + batch * h, sizeof(int), hipMemcpyDeviceToHost, st));
+    LAV_HIP(hipStreamSynchronize(st));
     return LAV_OK;
 }

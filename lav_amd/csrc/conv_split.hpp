@@ -595,7 +595,10 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
                         const int nch = (nchunks + ks - 1) / ks;
                         // per chunk: matrix work + one barrier per G taps, and the loaders' floor (a chunk's loads + conversion)
                         const double chunk_us = std::max(p.taps_per_class * (MP * MC * c_mma + c_stage / G), c_chunk * plane / 384.0);
-                        const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
+                        // a K loop of very few steps (1x1 and stride-4 up-convolutions, parity classes of one tap) never fills the
+                        // loader / compute pipeline: measured 21-35 us where the direct fp32 kernel takes 17-29 (round-4 sweep)
+                        const double short_loop_us = nchunks * min_taps <= 8 ? 6.0 : 0.0;
+                        const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + short_loop_us + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
                         if (t < best.cost * (ks > 1 ? 0.97 : 1.0) - 1e-9) {
                             best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, G, ks, 3 * G, lds, t};
                         }

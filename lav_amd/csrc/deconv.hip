@@ -13,6 +13,8 @@
 //                 a group are wave-uniform and come through the scalar cache
 //   epilogue    : + bias -> sigmoid on channels >= sigmoid_from -> NCHW store
 // Groups never share output channels, so there is no reduction and the result is deterministic.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -28,7 +30,9 @@ struct DeconvArgs {
     int w_off[8];       // float offset of group g's weights [cin_g][nc_g][K][K] (PyTorch ConvTranspose2d layout)
 };
 
-template <int K, int S, int NC>
+// U = channels per batch of loads: all NJ*NJ*U gathers of a batch are requested before its first FMA (the loop is a chain of
+// L2 round trips: 64 channels at U = 2 were 32 of them)
+template <int K, int S, int NC, int U>
 __global__ __launch_bounds__(256) void k_deconv_grouped(DeconvArgs a) {
     constexpr int NJ = (K + S - 1) / S;   // input rows / columns one output parity class can reach
     const int g = blockIdx.y;
@@ -62,25 +66,33 @@ __global__ __launch_bounds__(256) void k_deconv_grouped(DeconvArgs a) {
     const long cplane = (long)a.H * a.W;
     const float *xg = a.x + ((long)n * a.cin + (long)g * a.cin_g) * cplane;
     const float *wg = a.w + a.w_off[g];   // wave-uniform
-#pragma unroll 2
-    for (int c = 0; c < a.cin_g; ++c) {
-        float v[NJ][NJ];
+    for (int c0 = 0; c0 < a.cin_g; c0 += U) {
+        float v[U][NJ][NJ];
 #pragma unroll
-        for (int jy = 0; jy < NJ; ++jy)
+        for (int u = 0; u < U; ++u) {
+            const int c = min(c0 + u, a.cin_g - 1);   // (a ragged last batch re-reads the last channel and skips its FMAs)
 #pragma unroll
-            for (int jx = 0; jx < NJ; ++jx) {
-                const float t = xg[c * cplane + off[jy][jx]];
-                v[jy][jx] = ok[jy][jx] ? t : 0.f;
-            }
-        const float *wc = wg + (long)c * nc * (K * K);
+            for (int jy = 0; jy < NJ; ++jy)
 #pragma unroll
-        for (int co = 0; co < NC; ++co) {
-            if (co < nc) {   // wave-uniform
+                for (int jx = 0; jx < NJ; ++jx) {
+                    const float t = xg[c * cplane + off[jy][jx]];
+                    v[u][jy][jx] = ok[jy][jx] ? t : 0.f;
+                }
+        }
 #pragma unroll
-                for (int ky = 0; ky < K; ++ky)
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u < a.cin_g) {   // wave-uniform
+                const float *wc = wg + (long)(c0 + u) * nc * (K * K);
 #pragma unroll
-                    for (int kx = 0; kx < K; ++kx)   // output parity (ky % S, kx % S), input row qy - ky / S
-                        acc[ky % S][kx % S][co] = fmaf(v[ky / S][kx / S], wc[co * (K * K) + ky * K + kx], acc[ky % S][kx % S][co]);
+                for (int co = 0; co < NC; ++co) {
+                    if (co < nc) {   // wave-uniform
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < K; ++kx)   // output parity (ky % S, kx % S), input row qy - ky / S
+                                acc[ky % S][kx % S][co] = fmaf(v[u][ky / S][kx / S], wc[co * (K * K) + ky * K + kx], acc[ky % S][kx % S][co]);
+                    }
+                }
             }
         }
     }
@@ -128,7 +140,11 @@ __global__ __launch_bounds__(256) void k_deconv_grouped(DeconvArgs a) {
 template <int K, int S, int NC>
 void launch(const DeconvArgs &a, int groups, hipStream_t st) {
     const long nq = (long)a.B * a.QH * a.QW;
-    hipLaunchKernelGGL((k_deconv_grouped<K, S, NC>), dim3((unsigned)((nq + 255) / 256), groups), dim3(256), 0, st, a);
+    static const int unroll = [] { const char *e = getenv("LAV_DECONV_UNROLL"); return e ? atoi(e) : 8; }();
+    const dim3 grid((unsigned)((nq + 255) / 256), groups);
+    if (unroll >= 8) hipLaunchKernelGGL((k_deconv_grouped<K, S, NC, 8>), grid, dim3(256), 0, st, a);
+    else if (unroll >= 4) hipLaunchKernelGGL((k_deconv_grouped<K, S, NC, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_deconv_grouped<K, S, NC, 2>), grid, dim3(256), 0, st, a);
 }
 }  // namespace
 

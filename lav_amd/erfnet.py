@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import Conv1dPair, ConvLayer, GroupedDeconv
+from .ops import Conv1dPair, Conv1dPairChain, ConvLayer, GroupedDeconv
 
 _USE_PAIRS = os.environ.get("LAV_ERFNET_PAIRS", "1") != "0"   # A/B switch: 0 = four lav_conv2d launches per block
 
@@ -97,7 +97,47 @@ class non_bottleneck_1d(nn.Module):  # name kept: it is part of pickled/traced c
             if _USE_PAIRS and p1.supported(x) and p2.supported(x):
                 return p2(p1(x), residual=x)
             return d(c(b(a(x))), residual=x)
+        run.pairs = (p1, p2)     # (ERFNet._engine chains the pairs of consecutive blocks into one persistent launch)
         return run
+
+
+def _chain_blocks(stages):
+    """Consecutive non_bottleneck_1d engines -> one Conv1dPairChain each (lav_conv1d_pair_chain: a persistent launch per run of
+    blocks - 10 pairs at 64 channels, 16 at 128, 4 + 4 in the decoder), falling back to the blocks' own launches for shapes the
+    run does not take (too many rows for the chip, exact-fp32 precision)."""
+    out, run = [], []
+
+    def flush():
+        if not run:
+            return
+        blocks = list(run)
+        run.clear()
+        if len(blocks) == 1 or not _USE_PAIRS:
+            out.extend(blocks)
+            return
+        pairs = [p for b in blocks for p in b.pairs]
+        chain = Conv1dPairChain(pairs, [i % 2 == 1 for i in range(len(pairs))])
+
+        def go(x):
+            if chain.supported(x):
+                return chain(x)
+            for b in blocks:
+                x = b(x)
+            return x
+        go.chain = chain
+        out.append(go)
+
+    for st in stages:
+        if getattr(st, "pairs", None) is not None and (not run or run[-1].pairs[0].ch == st.pairs[0].ch):
+            run.append(st)
+        else:
+            flush()
+            if getattr(st, "pairs", None) is not None:
+                run.append(st)
+            else:
+                out.append(st)
+    flush()
+    return out
 
 
 class UpsamplerBlock(nn.Module):
@@ -169,6 +209,7 @@ class ERFNet(nn.Module):
             stages = [self.encoder.initial_block.engine(device, input_affine)]
             stages += [m.engine(device) for m in self.encoder.layers]
             stages += [m.engine(device) for m in self.decoder.layers]
+            stages = _chain_blocks(stages)
             stages.append(GroupedDeconv([self.decoder.output_conv], softmax=softmax, device=device))   # 16 -> classes, k2 s2: memory bound
             object.__setattr__(self, "_eng", ((device, input_affine, softmax), stages))
         return self._eng[1]

@@ -591,6 +591,69 @@ class Conv1dPair:
         return y
 
 
+class Conv1dPairChain:
+    """A run of Conv1dPair layers over one map as ONE persistent launch (lav_conv1d_pair_chain): `pairs` in execution order,
+    `residual[i]` True where pair i adds the input of pair i-1 (the non_bottleneck_1d block's input).  Output buffers are kept per
+    (batch, h, w) - every pair writes its own, the last one is returned (a fresh tensor per call unless `reuse_out`)."""
+
+    def __init__(self, pairs, residual):
+        if len(pairs) != len(residual) or not pairs or residual[0]:
+            raise RuntimeError("Conv1dPairChain: one residual flag per pair, the first pair without")
+        if any(p.ch != pairs[0].ch or p.scale is None for p in pairs):
+            raise RuntimeError("Conv1dPairChain: pairs of one channel count, each with its BatchNorm affine")
+        self.pairs, self.residual = list(pairs), [int(bool(r)) for r in residual]
+        self._bufs = {}
+
+    def supported(self, x: torch.Tensor) -> bool:
+        lib = _lib.load()
+        B, ch, h, w = x.shape
+        p0 = self.pairs[0]
+        return (_os.environ.get("LAV_CONV_PRECISION", "bf16x6") not in ("f32", "fp32") and _os.environ.get("LAV_ERFNET_CHAIN", "1") != "0"
+                and len(self.pairs) <= 16 and all(p.supported(x) for p in self.pairs) and B * h <= _cu_count(x.device)
+                and lib.lav_conv1d_pair_chain_lds_bytes(p0.ch, w, max(p.db for p in self.pairs)) <= 156 * 1024)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, ch, h, w = x.shape
+        n = len(self.pairs)
+        key = (B, h, w, x.device, _stream())
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            bufs = self._bufs[key] = [torch.empty_like(x) for _ in range(n - 1)]
+        out = bufs + [torch.empty_like(x)]
+        ws = _workspace("pair_chain", lib.lav_conv1d_pair_chain_workspace_bytes(B, h), x.device)
+        ia = lambda vals: (C.c_int * n)(*vals)
+        pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ps = self.pairs
+        check(lib.lav_conv1d_pair_chain(B, ch, h, w, n, ia([p.da for p in ps]), ia([p.db for p in ps]), ia(self.residual),
+                                        ia([int(p.relu_post) for p in ps]), _ptr(x), pa([p.wa for p in ps]), pa([p.ba for p in ps]),
+                                        pa([p.wb for p in ps]), pa([p.bb for p in ps]), pa([p.scale for p in ps]), pa([p.shift for p in ps]),
+                                        pa(out), _ptr(ws), ws.numel(), _stream()), "lav_conv1d_pair_chain")
+        return out[-1]
+
+    def timeouts(self, x_like: torch.Tensor) -> int:
+        """Workgroups of the last launch on the current stream that gave up waiting for a neighbour row (0 = valid result)."""
+        B, _, h, _ = x_like.shape
+        ws = _workspaces.get(("pair_chain", x_like.device, _stream()))
+        if ws is None:
+            return 0
+        v = C.c_int(0)
+        check(_lib.load().lav_conv1d_pair_chain_status(_ptr(ws), B, h, C.byref(v), _stream()), "lav_conv1d_pair_chain_status")
+        return int(v.value)
+
+
+_CU_COUNT = {}
+
+
+def _cu_count(device) -> int:
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _CU_COUNT:
+        _CU_COUNT[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return _CU_COUNT[idx]
+
+
 # algorithmic work of the training-side kernels since the last reset (bench.py's training roofline reads it next to the
 # library's HIP-event timers): bytes the crop gradient must move, flops of the recurrent GEMMs
 train_work = {"crop_rotate_backward_bytes": 0, "crop_rotate_backward_calls": 0, "gru_seq_forward_flops": 0, "gru_seq_backward_flops": 0,

@@ -277,3 +277,39 @@ def test_grouped_deconv_matches_torch(outs, cin_g, k, pad, opad, B, H, W, sig):
     y = GroupedDeconv(cts, sigmoid_from=sf, device=DEV)(x.to(DEV)).cpu()
     assert y.shape == ref.shape
     assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=f"grouped deconv {outs}")
+
+
+@pytest.mark.parametrize("ch,h,w,dils", [(128, 36, 32, (2, 4, 8, 16)), (64, 72, 64, (1, 1, 1)), (64, 20, 64, (1, 3))])
+def test_pair_chain_is_bit_identical_to_the_pairs_launched_one_by_one(ch, h, w, dils):
+    """lav_conv1d_pair_chain (one persistent launch for a run of non_bottleneck_1d blocks, rows handed between workgroups through
+    write-through stores and per-row counters) against the same pairs as separate lav_conv1d_pair launches: same arithmetic in
+    the same order, so the results must agree bit for bit - on every row, whatever the dilations; no workgroup may have timed
+    out.  Repeated launches (stale counters, stale buffers of the previous launch) must give the same bits again."""
+    import torch.nn as nn
+    from lav_amd.ops import Conv1dPair, Conv1dPairChain
+    torch.manual_seed(ch + h)
+    B = 3
+    pairs, res = [], []
+    for d in dils:
+        for dd in (1, d):   # a non_bottleneck_1d block: an undilated pair, then the dilated one with the residual
+            ca = nn.Conv2d(ch, ch, (3, 1), padding=(dd, 0), dilation=(dd, 1))
+            cb = nn.Conv2d(ch, ch, (1, 3), padding=(0, dd), dilation=(1, dd))
+            bn = nn.BatchNorm2d(ch, eps=1e-3)
+            with torch.no_grad():
+                bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+            pairs.append(Conv1dPair(ca, cb, bn, device=DEV))
+            res.append(len(pairs) % 2 == 0)
+    chain = Conv1dPairChain(pairs, res)
+    x = torch.randn((B, ch, h, w), device=DEV)
+    assert chain.supported(x)
+    want = x
+    for i in range(0, len(pairs), 2):
+        want = pairs[i + 1](pairs[i](want), residual=want)
+    got = chain(x)
+    torch.cuda.synchronize()
+    assert chain.timeouts(x) == 0
+    assert torch.equal(got, want), f"max |diff| {(got - want).abs().max().item():.3e}"
+    for _ in range(3):
+        again = chain(x)
+    torch.cuda.synchronize()
+    assert chain.timeouts(x) == 0 and torch.equal(again, want)
