@@ -314,7 +314,7 @@ def main():
     if health0 is not None:
         h1 = pipe.health()
         health = {k: h1[k] - health0[k] for k in ("nonfinite_outputs", "finite_checks", "plan_launches", "plan_aborts", "plans_recomputed",
-                                                  "decode_mismatches", "overflow_ticks")}
+                                                  "decode_mismatches", "overflow_ticks", "pair_chain_launches", "pair_chain_timeouts")}
         health["last_plan_launch"] = h1["last_plan_launch"]
     host_finite = all(bool(torch.isfinite(out[k]).all()) for k in ("ego_plan_locs", "ego_cast_locs", "ego_embd", "pred_bra", "pred_bev")) \
         and bool(torch.isfinite(out["other_cast_locs"]).all())
@@ -567,6 +567,8 @@ def main():
                 bad.append(f"{health['nonfinite_outputs']} non-finite output tensors inside the timed frames")
             if health["plan_aborts"] or health["plans_recomputed"]:
                 bad.append(f"{health['plan_aborts']} persistent plan launches timed out")
+            if health["pair_chain_timeouts"]:
+                bad.append(f"{health['pair_chain_timeouts']} workgroups of the persistent ERFNet runs gave up waiting")
         res["valid"] = not bad
         if bad:
             res["invalid_reason"] = "; ".join(bad)

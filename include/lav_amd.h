@@ -480,8 +480,9 @@ int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_p
  * leave the CU.  residual[i] != 0: pair i adds the INPUT of pair i-1 (the block's input) before its ReLU; the run starts at a
  * block boundary.  out[i]: output buffer of pair i ([batch][channels][h][w] each, all distinct; out[npairs-1] is the result).
  * batch * h must not exceed the CU count (every row's workgroup waits for its neighbours'); bf16x6 precision only.  Waits are
- * bounded: lav_conv1d_pair_chain_status returns how many workgroups of the last launch gave up (0 = the result is valid).
- * workspace: lav_conv1d_pair_chain_workspace_bytes, private to the stream.
+ * bounded: a workgroup that gives up voids the launch's result and raises a sticky counter - lav_conv1d_pair_chain_status copies
+ * {workgroups that gave up, launches} since the workspace was zero-filled (it SYNCHRONISES `stream`; 0 = every result was valid).
+ * workspace: lav_conv1d_pair_chain_workspace_bytes, ZERO before its first use, private to the stream.
  */
 size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h);
 size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max);
@@ -489,7 +490,7 @@ int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, con
                           const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
                           const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
                           const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream);
-int lav_conv1d_pair_chain_status(const void *workspace, int batch, int h, int *h_timeouts, void *stream);
+int lav_conv1d_pair_chain_status(const void *workspace, int *h_timeouts_launches2, void *stream);
 size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b);
 int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,
                     const float *bias_a, const float *wb_packed, const float *bias_b, const float *scale, const float *shift,

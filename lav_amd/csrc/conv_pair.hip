@@ -505,13 +505,21 @@ struct PairChainArgs {
     const unsigned char *wA[CHAIN_MAX], *wB[CHAIN_MAX];
     const float *bA[CHAIN_MAX], *bB[CHAIN_MAX], *scale[CHAIN_MAX], *shift[CHAIN_MAX];
     unsigned char dA[CHAIN_MAX], dB[CHAIN_MAX], res[CHAIN_MAX], relu[CHAIN_MAX];   // res: add the input of the pair before (block residual)
-    int *flags;                       // [B*H] pairs completed by the row, zero at launch; [B*H] = status word (time-outs)
+    int *flags;                       // [B*H] pairs completed by the row, zeroed at every launch
+    int *sticky;                      // [0] workgroups that gave up waiting, [1] launches - since the caller zero-filled the workspace
     int B, C, H, W, CP, npairs;
     long long spin_limit;
+    long long *trace;                 // debug (LAV_PAIR_CHAIN_TRACE), else null
 };
 
-template <int KS, int R>
+// TRACE (LAV_PAIR_CHAIN_TRACE): thread 0 of every workgroup accumulates the shader-clock cycles of each phase over the run into
+// a.trace[workgroup][8]: 0 whole run, 1 counter waits, 2 neighbour rows (loads, conversion, LDS), 3 halo + barrier, 4 phase A,
+// 5 combine + intermediate row, 6 phase B, 7 epilogue + publication
+template <int KS, int R, bool TRACE = false>
 __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a) {
+    long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0, tr_t0 = 0;
+    if constexpr (TRACE) { tr_t0 = tr_t = clock64(); }
+#define CH_MARK(i) do { if constexpr (TRACE) { const long long now_ = clock64(); tr_acc[i] += now_ - tr_t; tr_t = now_; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int wid = wid8 & 3, kpart = wid8 >> 2;
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                     ok = fu >= p && fd >= p;
                     if (!ok) {
                         if (++spins > a.spin_limit) {   // never hang the device: the result is void, the status word says so
-                            if (lane == 0) { s_abort = 1; atomicAdd(a.flags + a.B * H, 1); }
+                            if (lane == 0) { s_abort = 1; atomicAdd(a.sticky, 1); }
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -631,7 +639,9 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                 }
             }
             __syncthreads();
+            CH_MARK(1);
             stage_rows(a.out[p - 1], dA, std::false_type{}, true);
+            CH_MARK(2);
         }
         if (tid < C) {   // the pair's epilogue vectors: through LDS, so that they hold no registers while the phases run
             s_epi[0][tid] = a.bA[p][tid];
@@ -647,6 +657,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
             }
         }
         __syncthreads();
+        CH_MARK(3);
 
         // ---- phase A: vertical taps
         f32x16 acc;
@@ -673,6 +684,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                 }
             }
         }
+        CH_MARK(4);
         if constexpr (KS == 2) {
             if (kpart == 1) {
 #pragma unroll
@@ -703,6 +715,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
             }
         }
         __syncthreads();
+        CH_MARK(5);
 
         // ---- phase B: horizontal taps over the intermediate; the ring is refilled with the NEXT pair's first vertical fragments
 #pragma unroll
@@ -729,6 +742,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                 }
             }
         }
+        CH_MARK(6);
         if constexpr (KS == 2) {   // (phase A's partials were read before the barrier that followed the intermediate row's stores)
             if (kpart == 1) {
 #pragma unroll
@@ -784,8 +798,16 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row stores have left (write-through): the counter may follow
         __syncthreads();
         if (tid == 0) __hip_atomic_store(a.flags + n * H + y, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_MARK(7);
         if (*(volatile int *)&s_abort) return;
     }
+    if constexpr (TRACE) {
+        CH_MARK(7);
+        tr_acc[0] = clock64() - tr_t0;
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) a.trace[(long)blockIdx.x * 8 + i] = tr_acc[i];
+    }
+#undef CH_MARK
 }
 
 // fp32 floats of the exact packing of one convolution of a pair
@@ -945,14 +967,15 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
 }
 
 namespace {
-__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n) {
+__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *launches) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0;
+    if (i == 0) atomicAdd(launches, 1);
 }
 }  // namespace
 
 extern "C" size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h) {
-    return batch > 0 && h > 0 ? lav::align_up((size_t)(batch * h + 1) * sizeof(int), 256) : 0;
+    return batch > 0 && h > 0 ? 256 + lav::align_up((size_t)(batch * h) * sizeof(int), 256) : 0;   // sticky counters + per-row progress
 }
 
 extern "C" size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max) {
@@ -991,15 +1014,15 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
         dbmax = std::max(dbmax, d_b[j]);
     }
     LAV_REQUIRE(!residual[0], "lav_conv1d_pair_chain: the run starts at a block boundary (its first pair has no residual)");
-    a.x0 = x; a.flags = static_cast<int *>(workspace);
+    a.x0 = x; a.sticky = static_cast<int *>(workspace); a.flags = a.sticky + 64;
     a.B = batch; a.C = channels; a.H = h; a.W = w; a.CP = (channels + 31) / 32 * 32; a.npairs = npairs;
-    static const long long spin_limit = [] { const char *e = getenv("LAV_CHAIN_SPIN_LIMIT"); return e && atoll(e) > 0 ? atoll(e) : (1ll << 21); }();
-    a.spin_limit = spin_limit;
+    const char *lim = getenv("LAV_CHAIN_SPIN_LIMIT");   // test knob: 0 makes every wait that is not satisfied at once a time-out
+    a.spin_limit = lim ? std::max(0ll, atoll(lim)) : (1ll << 21);
     const size_t lds = lav_conv1d_pair_chain_lds_bytes(channels, w, dbmax);
-    LAV_REQUIRE(lds <= 156 * 1024, "lav_conv1d_pair_chain: %zu bytes of LDS needed", lds);
+    LAV_REQUIRE(lds <= 152 * 1024, "lav_conv1d_pair_chain: %zu bytes of LDS needed", lds);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nflag = batch * h + 1;
-    hipLaunchKernelGGL(k_zero_ints, dim3((nflag + 255) / 256), dim3(256), 0, st, a.flags, nflag);
+    const int nflag = batch * h;
+    hipLaunchKernelGGL(k_zero_ints, dim3((nflag + 255) / 256), dim3(256), 0, st, a.flags, nflag, a.sticky + 1);
     const int ks2 = channels >= 64 && (channels / 16) % 2 == 0 ? 2 : 1;
     const int nch2 = channels / 16 / ks2;
     // weight ring of at most two chunks: the four-chunk ring of the single-pair kernel does not fit the registers next to the
@@ -1008,19 +1031,41 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
     const int tok = timer_begin("conv1d_pair", st);
 #define LAV_CHAIN_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
         static bool attr = false;   /* (the kernel also holds ~2 KB of static LDS: the dynamic part may not claim all 160 KB) */ \
-        if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)); attr = true; } \
+        if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
         hipLaunchKernelGGL((k_conv1d_pair_chain<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, st, a); }
+    static const bool want_trace = getenv("LAV_PAIR_CHAIN_TRACE") != nullptr;
+    static long long *d_trace = nullptr;
+    a.trace = nullptr;
+    if (want_trace && ks2 == 2 && ring2 == 2) {
+        if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)512 * 8 * sizeof(long long)));
+        a.trace = d_trace;
+        static bool attr_t = false;
+        if (!attr_t) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_t = true; }
+        hipLaunchKernelGGL((k_conv1d_pair_chain<2, 2, true>), dim3(batch * h), dim3(512), lds, st, a);
+        static int runs = 0;
+        if (++runs % 10 == 0 && batch * h <= 512) {
+            std::vector<long long> hst((size_t)batch * h * 8);
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hst.data(), d_trace, hst.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < batch * h; ++i) for (int k = 0; k < 8; ++k) m[k] += (double)hst[(size_t)i * 8 + k];
+                const double f = 1.0 / (batch * h) / npairs;
+                fprintf(stderr, "[pair chain trace] C %d W %d, %d rows, %d pairs: cycles per pair and workgroup: all %.0f | counter wait %.0f | neighbour rows %.0f | halo+barrier %.0f | phase A %.0f | combine+mid %.0f | phase B %.0f | epilogue+publish %.0f\n",
+                        channels, w, batch * h, npairs, m[0] * f, m[1] * f, m[2] * f, m[3] * f, m[4] * f, m[5] * f, m[6] * f, m[7] * f);
+            }
+        }
+    } else {
     LAV_CHAIN_CASE(1, 1) LAV_CHAIN_CASE(1, 2) LAV_CHAIN_CASE(2, 1) LAV_CHAIN_CASE(2, 2)
+    }
 #undef LAV_CHAIN_CASE
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }
 
-extern "C" int lav_conv1d_pair_chain_status(const void *workspace, int batch, int h, int *h_timeouts, void *stream) {
-    LAV_REQUIRE(workspace && h_timeouts && batch >= 1 && h >= 1, "lav_conv1d_pair_chain_status: bad argument");
+extern "C" int lav_conv1d_pair_chain_status(const void *workspace, int *h_timeouts_launches2, void *stream) {
+    LAV_REQUIRE(workspace && h_timeouts_launches2, "lav_conv1d_pair_chain_status: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LAV_HIP(hipMemcpyAsync(h_timeouts, static_cast<const int *>(workspace) + batch * h, sizeof(int), hipMemcpyDeviceToHost, st));
+    LAV_HIP(hipMemcpyAsync(h_timeouts_launches2, workspace, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     LAV_HIP(hipStreamSynchronize(st));
     return LAV_OK;
 }

@@ -465,7 +465,9 @@ class GraphedFramePipeline(FramePipeline):
         up = self.infer_model.uniplanner
         diag = ops.gru_plan_diag(1, up.plan_gru.hidden_size, up.num_cmds, int(cmd_value), self.device, stream=self.s_ego)
         nonfinite, checks = (int(v) for v in self.d_health.cpu())
+        chain_timeouts, chain_launches = ops.pair_chain_status(self.device, stream=self.s_cap)   # ERFNet's persistent pair runs (lidar graph)
         return dict(nonfinite_outputs=nonfinite, finite_checks=checks, plan_launches=diag["launches"], plan_aborts=diag["aborted_launches"],
+                    pair_chain_launches=chain_launches, pair_chain_timeouts=chain_timeouts,
                     plans_recomputed=self.plan_aborts, decode_mismatches=self.decode_mismatches, overflow_ticks=self.overflow_ticks,
                     last_plan_launch=diag)
 

@@ -610,7 +610,7 @@ class Conv1dPairChain:
         p0 = self.pairs[0]
         return (_os.environ.get("LAV_CONV_PRECISION", "bf16x6") not in ("f32", "fp32") and _os.environ.get("LAV_ERFNET_CHAIN", "1") != "0"
                 and len(self.pairs) <= 16 and all(p.supported(x) for p in self.pairs) and B * h <= _cu_count(x.device)
-                and lib.lav_conv1d_pair_chain_lds_bytes(p0.ch, w, max(p.db for p in self.pairs)) <= 156 * 1024)
+                and lib.lav_conv1d_pair_chain_lds_bytes(p0.ch, w, max(p.db for p in self.pairs)) <= 152 * 1024)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         lib = _lib.load()
@@ -633,14 +633,23 @@ class Conv1dPairChain:
         return out[-1]
 
     def timeouts(self, x_like: torch.Tensor) -> int:
-        """Workgroups of the last launch on the current stream that gave up waiting for a neighbour row (0 = valid result)."""
-        B, _, h, _ = x_like.shape
-        ws = _workspaces.get(("pair_chain", x_like.device, _stream()))
-        if ws is None:
-            return 0
-        v = C.c_int(0)
-        check(_lib.load().lav_conv1d_pair_chain_status(_ptr(ws), B, h, C.byref(v), _stream()), "lav_conv1d_pair_chain_status")
-        return int(v.value)
+        """Workgroups of pair-chain launches on the current stream that gave up waiting for a neighbour row (0 = all results valid)."""
+        return pair_chain_status(x_like.device)[0]
+
+
+def pair_chain_status(device, stream=None):
+    """(workgroups that gave up, launches) of lav_conv1d_pair_chain on `stream` (default: the current one) since its workspace
+    was created.  Synchronises that stream."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    ws = _workspaces.get(("pair_chain", device, st.cuda_stream))
+    if ws is None:
+        return (0, 0)
+    v = (C.c_int * 2)()
+    check(_lib.load().lav_conv1d_pair_chain_status(_ptr(ws), v, st.cuda_stream), "lav_conv1d_pair_chain_status")
+    return (int(v[0]), int(v[1]))
 
 
 _CU_COUNT = {}

@@ -313,3 +313,32 @@ def test_pair_chain_is_bit_identical_to_the_pairs_launched_one_by_one(ch, h, w, 
         again = chain(x)
     torch.cuda.synchronize()
     assert chain.timeouts(x) == 0 and torch.equal(again, want)
+
+
+def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):
+    """A workgroup of the persistent run that waits too long for a neighbour row (forced: a spin limit of 0) gives up instead of
+    hanging the device, and the sticky counter of the workspace says that the result is void; the next launch is valid again."""
+    import torch.nn as nn
+    from lav_amd import ops
+    from lav_amd.ops import Conv1dPair, Conv1dPairChain
+    torch.manual_seed(5)
+    ch, h, w = 128, 36, 32
+    pairs = []
+    for d in (1, 2, 1, 4, 1, 8):
+        pairs.append(Conv1dPair(nn.Conv2d(ch, ch, (3, 1), padding=(d, 0), dilation=(d, 1)), nn.Conv2d(ch, ch, (1, 3), padding=(0, d), dilation=(1, d)),
+                                nn.BatchNorm2d(ch, eps=1e-3).eval(), device=DEV))
+    chain = Conv1dPairChain(pairs, [i % 2 == 1 for i in range(len(pairs))])
+    x = torch.randn((3, ch, h, w), device=DEV)
+    good = chain(x)
+    torch.cuda.synchronize()
+    t0, n0 = ops.pair_chain_status(DEV)
+    monkeypatch.setenv("LAV_CHAIN_SPIN_LIMIT", "0")
+    chain(x)
+    torch.cuda.synchronize()          # (returns: nobody waits forever)
+    monkeypatch.delenv("LAV_CHAIN_SPIN_LIMIT")
+    t1, n1 = ops.pair_chain_status(DEV)
+    assert n1 == n0 + 1 and t1 > t0, "108 rows never finish a pair at the same instant: some workgroup must have given up"
+    back = chain(x)
+    torch.cuda.synchronize()
+    t2, n2 = ops.pair_chain_status(DEV)
+    assert (t2, n2) == (t1, n1 + 1) and torch.equal(back, good)
