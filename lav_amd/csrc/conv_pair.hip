@@ -999,7 +999,13 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         return v > 0 ? v : 256;
     }();
-    LAV_REQUIRE(batch * h <= cus, "lav_conv1d_pair_chain: %d rows exceed the %d compute units (run the pairs one launch each)", batch * h, cus);
+    {   // a CU takes two of the run's workgroups when they are 256 threads with at most 76 KB of LDS each (16-channel stages)
+        int dbm = 1;
+        for (int i = 0; i < npairs; ++i) dbm = std::max(dbm, d_b[i]);
+        const bool two = lav_conv1d_pair_chain_lds_bytes(channels, w, dbm) <= 76 * 1024 && !(channels >= 64 && (channels / 16) % 2 == 0);
+        LAV_REQUIRE(batch * h <= cus * (two ? 2 : 1), "lav_conv1d_pair_chain: %d rows exceed the %d workgroups the chip holds at once (run the pairs one launch each)",
+                    batch * h, cus * (two ? 2 : 1));
+    }
     PairChainArgs a;
     int dbmax = 1;
     for (int i = 0; i < CHAIN_MAX; ++i) {

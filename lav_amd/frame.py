@@ -187,7 +187,8 @@ class GraphedFramePipeline(FramePipeline):
         self.forced_others = None     # set_forced_others: (actors, count, n) on the device
         self.decode_mismatches = 0    # frames on which the device and host detection decodes disagreed (host result used)
         self.plan_aborts = 0          # frames whose persistent plan launch timed out and was recomputed (recover_plan)
-        # [tensors found non-finite, checks run] by lav_nonfinite_count at the end of the ego / brake / heads graphs: sticky and
+        self.nonfinite_det_frames = 0 # frames whose peak rows (scores, positions, sizes, orientations) held a NaN / Inf (host check)
+        # [tensors found non-finite, checks run] by lav_nonfinite_count at the end of the ego / brake graphs: sticky and
         # device resident, read by health() - a benchmark loop proves every timed frame finite without a copy per frame
         self.d_health = torch.zeros((2,), dtype=torch.int32, device=dev)
         self.poses = deque()
@@ -237,7 +238,6 @@ class GraphedFramePipeline(FramePipeline):
                            centre_xy=(float(W / 2 + ox * W / 2), float(H / 2 + oy * H / 2)), skip_px=4.0, ppm=up.pixels_per_meter)
             if self.forced_others is not None:   # measurement hook (set_forced_others): fixed poses instead of the detections
                 self.d_actors.copy_(self.forced_others[0]); self.d_n.copy_(self.forced_others[1])
-        ops.nonfinite_count([det_raw], self.d_health)
         return dict(det_raw=det_raw, pred_bev=pred_bev)
 
     def set_forced_others(self, locs=None, oris=None):
@@ -392,6 +392,8 @@ class GraphedFramePipeline(FramePipeline):
             main.wait_stream(self.s_ego)      # also keeps the next frame's input copies behind this frame's readers
             main.wait_stream(self.s_bra)
             self.ev_det.synchronize()
+            if not np.isfinite(self.hn_det).all():   # the peak rows are on the host every frame: their check costs no launch
+                self.nonfinite_det_frames += 1
             det, locs, oris = self.infer_model.det_decode_fast(self.hn_det)
             N = int(self.h_n[0])
             if self.forced_others is not None:
@@ -458,7 +460,7 @@ class GraphedFramePipeline(FramePipeline):
 
     def health(self, cmd_value: int = 3) -> dict:
         """Counters of the drive so far (synchronises): non-finite output tensors seen by the graphs' own checks (ego embedding /
-        plan / cast, brake prediction, peak rows), persistent plan launches and how many of them timed out (sticky words of the
+        plan / cast, brake prediction; the peak rows are checked on the host), persistent plan launches and how many of them timed out (sticky words of the
         plan workspace on the ego stream - they count what the GPU did, whether or not the caller looked at the waypoints),
         plans recomputed by recover_plan, device / host detection-decode disagreements, ticks that outgrew the static buffers."""
         torch.cuda.synchronize()
@@ -466,6 +468,7 @@ class GraphedFramePipeline(FramePipeline):
         diag = ops.gru_plan_diag(1, up.plan_gru.hidden_size, up.num_cmds, int(cmd_value), self.device, stream=self.s_ego)
         nonfinite, checks = (int(v) for v in self.d_health.cpu())
         chain_timeouts, chain_launches = ops.pair_chain_status(self.device, stream=self.s_cap)   # ERFNet's persistent pair runs (lidar graph)
+        nonfinite += self.nonfinite_det_frames
         return dict(nonfinite_outputs=nonfinite, finite_checks=checks, plan_launches=diag["launches"], plan_aborts=diag["aborted_launches"],
                     pair_chain_launches=chain_launches, pair_chain_timeouts=chain_timeouts,
                     plans_recomputed=self.plan_aborts, decode_mismatches=self.decode_mismatches, overflow_ticks=self.overflow_ticks,

@@ -608,9 +608,11 @@ class Conv1dPairChain:
         lib = _lib.load()
         B, ch, h, w = x.shape
         p0 = self.pairs[0]
+        lds = lib.lav_conv1d_pair_chain_lds_bytes(p0.ch, w, max(p.db for p in self.pairs))
         return (_os.environ.get("LAV_CONV_PRECISION", "bf16x6") not in ("f32", "fp32") and _os.environ.get("LAV_ERFNET_CHAIN", "1") != "0"
-                and len(self.pairs) <= 16 and all(p.supported(x) for p in self.pairs) and B * h <= _cu_count(x.device)
-                and lib.lav_conv1d_pair_chain_lds_bytes(p0.ch, w, max(p.db for p in self.pairs)) <= 152 * 1024)
+                and len(self.pairs) <= 16 and all(p.supported(x) for p in self.pairs)
+                and B * h <= _cu_count(x.device) * (2 if (lds <= 76 * 1024 and not (ch >= 64 and (ch // 16) % 2 == 0)) else 1)
+                and lds <= 152 * 1024)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         lib = _lib.load()

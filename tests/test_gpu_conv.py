@@ -279,7 +279,7 @@ def test_grouped_deconv_matches_torch(outs, cin_g, k, pad, opad, B, H, W, sig):
     assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=f"grouped deconv {outs}")
 
 
-@pytest.mark.parametrize("ch,h,w,dils", [(128, 36, 32, (2, 4, 8, 16)), (64, 72, 64, (1, 1, 1)), (64, 20, 64, (1, 3))])
+@pytest.mark.parametrize("ch,h,w,dils", [(128, 36, 32, (2, 4, 8, 16)), (64, 72, 64, (1, 1, 1)), (64, 20, 64, (1, 3)), (16, 144, 128, (1, 1))])
 def test_pair_chain_is_bit_identical_to_the_pairs_launched_one_by_one(ch, h, w, dils):
     """lav_conv1d_pair_chain (one persistent launch for a run of non_bottleneck_1d blocks, rows handed between workgroups through
     write-through stores and per-row counters) against the same pairs as separate lav_conv1d_pair launches: same arithmetic in

@@ -36,6 +36,11 @@ def short(n):
     return n[:70]
 
 
+c_st = "Stream_Id" if "Stream_Id" in k else c_q
+import collections
+main = collections.Counter(r[c_st] for r in rows if "k_merge_ticks" in r[c_name]).most_common(1)[0][0]   # (eager warm-ups run elsewhere)
+side = [r for r in rows if r[c_st] != main]
+rows = [r for r in rows if r[c_st] == main]        # the critical chain: the stream that runs the lidar / heads / others graphs
 starts = [i for i, r in enumerate(rows) if "k_merge_ticks" in r[c_name]]
 if len(starts) < back + 1:
     sys.exit(f"only {len(starts)} frames in the trace")
@@ -53,6 +58,14 @@ for r in rows[lo:hi]:
     print(f"{(r['_s'] - t0) / 1e3:9.1f} {(r['_e'] - r['_s']) / 1e3:7.1f} {gap:7.1f}  {q:>5s}  {nm}")
     a = per.setdefault(nm, [0, 0.0])
     a[0] += 1; a[1] += (r["_e"] - r["_s"]) / 1e3
+t1 = rows[hi]["_s"]
+print("# side streams inside this frame window: per stream, kernels / busy us")
+agg = {}
+for r in side:
+    if t0 <= r["_s"] < t1:
+        a = agg.setdefault(r[c_st], [0, 0.0]); a[0] += 1; a[1] += (r["_e"] - r["_s"]) / 1e3
+for st, (n, t) in agg.items():
+    print(f"#   stream {st}: {n} kernels, {t:.1f} us")
 print("# per kernel in this frame: calls, total us")
 for nm, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
     print(f"# {n:4d} {t:8.1f}  {nm}")
