@@ -454,7 +454,7 @@ def main():
         # PointNet (max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) is the binding roof) are carried beside it.
         m, mf = micro["config2_32768pts"], micro["agent_196608pts"]
         traffic, traffic_src = None, None
-        for prof_name in ("r03_pmc_pillar.json", "r02_b_pmc_pillar.json"):
+        for prof_name in ("r04_pmc_pillar.json", "r03_pmc_pillar.json", "r02_b_pmc_pillar.json"):
             try:  # HBM bytes per launch from the committed PMC pass of this kernel (counters cannot be read from inside a run)
                 with open(os.path.join(REPO, "profiles", prof_name)) as f:
                     pm = json.load(f)
