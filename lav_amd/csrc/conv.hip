@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256) void k_conv_reduce(ConvArgs a, int batch) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int n = (int)(e / (a.cout * plane_o));
+    if (a.n_valid && n >= *a.n_valid) return;   // lav_batch_limit: rows the first pass skipped hold no partial sums
     const int co = (int)((e / plane_o) % a.cout);
     const long pix = e % plane_o;
     float v = 0.f;
@@ -816,7 +817,7 @@ Choice decide(const lav_conv &c, const Plan &p, double tile_cost, double tile_ra
             double other = ch.kind == 1 ? ch.dp.cost * (1.0 + 0.3 * std::min(1.0, (double)ch.dp.tiles / 800.0)) : tile_raw;
             // deep 7x7 stems: the split kernel's tiles are LDS-bound there (64 pixels x 64 couts) and only match the tiled
             // fp32 kernel (measured 451 vs 431 us at 7 crops)
-            const bool deep_stem = p.taps_per_class > 16 && c.cin >= 64;
+            const bool deep_stem = p.taps_per_class > 16 && c.cin >= 64 && !ch.sp.tp;   // (round 4: tap-pair plans hold 128-pixel tiles)
             if (ch.sp.ok && (mode == 2 || (ch.sp.cost < other && !deep_stem))) ch.kind = 2;
         }
     }
@@ -844,7 +845,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     const DirectPlan &d = ch.dp;
     if (ch.kind == 2) {   // split kernel: info[0] = -1, then MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows
         info[0] = -1; info[1] = ch.sp.MP; info[2] = ch.sp.MC; info[3] = ch.sp.WPX; info[4] = ch.sp.tw; info[5] = (int)ch.sp.lds;
-        info[6] = ch.sp.ksplit; info[7] = ch.sp.tap_group; info[8] = ch.sp.th;
+        info[6] = ch.sp.ksplit; info[7] = ch.sp.tap_group + 100 * ch.sp.tp; info[8] = ch.sp.th;   // (tap group + 100 in tap-pair mode)
         return LAV_OK;
     }
     if (ch.kind == 1) {   // direct path: info[0] = 0, info[1] = waves per workgroup

@@ -27,6 +27,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SPLIT_NT = 8;          // most staged positions per activation-loader thread (128 threads): plane <= 1024
+constexpr int SPLIT_NT_TP = 12;      // tap-pair mode (8-channel chunks: half the registers per position): plane <= 1536
 constexpr int SPLIT_LOADERS = 128;
 
 struct SplitArgs {
@@ -113,16 +114,25 @@ struct SplitOps {
 // drain the queue at each join, one memory round trip per position
 // G: taps per barrier.  A barrier costs ~300 cycles of skew between the eight waves whatever the work between two of
 // them; a 2x2 wave tile has 24 matrix instructions (~1000 cycles) per tap, a 1x1 tile only 6.
-template <int MP, int MC, int WPX, int NT, int G>
+// TP ("tap pairs", round 4): the 16 k-steps of a matrix instruction are 8 channels of TWO taps (k half h = tap 2p + h) instead
+// of 16 channels of one.  A staged position then costs 48 bytes per buffer instead of 96, which is what lets a 7x7 stride-2 stem
+// (every output pixel drags ~4 input positions along) hold a 128-pixel tile double buffered: its tiles were 64 pixels x 64
+// couts before - LDS-read bound, no faster than the fp32 kernel.  Same packed weights: lane (h, cout) of a fragment fetches
+// its 16 bytes from tap 2p + h, channel half (chunk & 1) of the ordinary layout; the odd tap out (49 = 24 pairs + 1) is
+// zeroed on its way into LDS.  A chunk is 8 channels, a step one tap pair.
+template <int MP, int MC, int WPX, int NT, int G, bool TP = false>
 __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     constexpr int WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
+    constexpr int CH = TP ? 8 : 16;                            // channels per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ks = blockIdx.z % a.ksplit;
     const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
     if (a.n_valid && n >= *a.n_valid) return;   // workgroup-uniform
-    const int ntaps = a.cls_ntaps[cls];
+    const int ntaps_real = a.cls_ntaps[cls];
+    const int ntaps = TP ? (ntaps_real + 1) >> 1 : ntaps_real;   // steps per chunk (TP: tap pairs)
+    const int nchunks_k = TP ? 2 * a.nchunks : a.nchunks;       // chunks of the K loop
     int qy0, qx0, q0 = 0;
     if (a.tw) {
         const int tx = blockIdx.y % a.tiles_x, ty = blockIdx.y / a.tiles_x;
@@ -132,10 +142,10 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     }
     const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls], in_ox = qx0 * a.in_s + a.cls_in_ox[cls];
     const int plane = a.plane;
-    const int ibuf_bytes = 6 * plane * 16;                    // [3 pieces][2 k halves][plane] x 16 B
+    const int ibuf_bytes = (TP ? 3 : 6) * plane * 16;         // [3 pieces][2 k halves][plane] x 16 B (TP: no k-half dimension)
     constexpr int WSLOT = NBLK * 3 * 1024;                    // one tap's weights of the tile: [cout block][piece][lane] x 16 B
     unsigned char *s_in = smem_raw, *s_w = smem_raw + 2 * ibuf_bytes;
-    const int chunk_lo = ks * a.nchunks / a.ksplit, chunk_hi = (ks + 1) * a.nchunks / a.ksplit;
+    const int chunk_lo = ks * nchunks_k / a.ksplit, chunk_hi = (ks + 1) * nchunks_k / a.ksplit;
     const int nchunk = chunk_hi - chunk_lo, nsteps = nchunk * ntaps;   // a step = one tap of one 16-channel chunk
     constexpr int WFM = 4 / G;                                 // groups of G taps the weight waves keep in flight in registers
     const int ngroups = (nsteps + G - 1) / G;                 // a group = the G taps between two barriers
@@ -165,28 +175,41 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             if (pc >= NBLK * 3) pc = lw;
             const int b = pc / 3, pl = pc - b * 3;
             const int blk = min((int)blockIdx.x * NBLK + b, a.nblk_total - 1);
-            rel[k] = (unsigned)((blk * ntaps * a.nchunks * 3 + pl) * 1024) + lane * 16;
+            rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * 3 + pl) * 1024) + lane * 16;
+            if constexpr (TP) rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * 3 + pl) * 1024) + l31 * 16 + half * (unsigned)(a.nchunks * 3072);
             doff[k] = pc * 1024 + lane * 16;
         }
+        const unsigned tap_hop = TP ? half * (unsigned)(a.nchunks * 3072) : 0u;   // TP: the second tap of a pair sits one tap further
         u32x4 wreg[WFM][G][NPW];
         int r_t = 0, r_chunk = chunk_lo;   // next tap to request
         auto request = [&](u32x4 (&dst)[NPW]) {
-            const unsigned char *base = wcls + ((long)r_t * a.nchunks + min(r_chunk, chunk_hi - 1)) * 3072;
+            const int cch = min(r_chunk, chunk_hi - 1);
+            const unsigned char *base = TP ? wcls + ((long)(2 * r_t) * a.nchunks + (cch >> 1)) * 3072 + (cch & 1) * 512
+                                           : wcls + ((long)r_t * a.nchunks + cch) * 3072;
+            // TP, odd tap count: the last pair's second tap does not exist - its lanes re-read the first (zeroed at the deposit)
+            const unsigned back = TP && (ntaps_real & 1) && r_t == ntaps - 1 ? tap_hop : 0u;
 #pragma unroll
-            for (int k = 0; k < NPW; ++k) dst[k] = *reinterpret_cast<const u32x4 *>(base + rel[k]);
+            for (int k = 0; k < NPW; ++k) dst[k] = *reinterpret_cast<const u32x4 *>(base + (rel[k] - back));
             const bool wrap = r_t + 1 == ntaps;
             r_t = wrap ? 0 : r_t + 1;
             r_chunk += wrap ? 1 : 0;
         };
         // LDS ring of 3 groups: while group k is multiplied (its taps, and the first tap of group k+1, are fetched during
         // it), group k+2 is written
-        int w_grp = 0;
+        int w_grp = 0, d_t = 0;   // d_t: step (tap / tap pair) within its chunk of the next deposit
         auto deposit = [&](const u32x4 (&src)[G][NPW]) {
             unsigned char *dst = s_w + w_grp * (G * WSLOT);
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g) {
+                const bool dead = TP && (ntaps_real & 1) && d_t == ntaps - 1 && half;   // the tap that does not exist
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) *reinterpret_cast<u32x4 *>(dst + g * WSLOT + doff[k]) = src[g][k];
+                for (int k = 0; k < NPW; ++k) {
+                    u32x4 v = src[g][k];
+                    if constexpr (TP) v = dead ? u32x4{0u, 0u, 0u, 0u} : v;
+                    *reinterpret_cast<u32x4 *>(dst + g * WSLOT + doff[k]) = v;
+                }
+                d_t = d_t + 1 == ntaps ? 0 : d_t + 1;
+            }
             w_grp = w_grp == 2 ? 0 : w_grp + 1;
         };
         long long waited = 0;
@@ -230,28 +253,29 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         }
         const long cplane = (long)a.H * a.W;
         const char *xin = reinterpret_cast<const char *>(a.x + ((long)n * a.in_c_total + a.in_c_offset) * cplane);
-        float v[NT][16];
-        auto issue_loads_to = [&](float (&v)[NT][16], int sc) __attribute__((always_inline)) {
-            const int ci0 = (chunk_lo + sc) * 16;
-            const int nc = min(16, a.cin - ci0);   // wave-uniform
+        float v[NT][CH];
+        auto issue_loads_to = [&](float (&v)[NT][CH], int sc) __attribute__((always_inline)) {
+            const int ci0 = (chunk_lo + sc) * CH;
+            const int nc = min(CH, a.cin - ci0);   // wave-uniform (TP: the host requires cin % 16 == 0, so nc = 8)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < CH; ++c) {
                 const char *pc = xin + ((long)ci0 + min(c, nc - 1)) * cplane * 4;   // scalar base, 32-bit lane offset
 #pragma unroll
                 for (int i = 0; i < NT; ++i) v[i][c] = *reinterpret_cast<const float *>(pc + (unsigned)max(goff[i], 0));
             }
         };
-        auto convert_store_from = [&](const float (&v)[NT][16], int sc) __attribute__((always_inline)) {
-            const int ci0 = (chunk_lo + sc) * 16;
-            const int nc = min(16, a.cin - ci0);
+        auto convert_store_from = [&](const float (&v)[NT][CH], int sc) __attribute__((always_inline)) {
+            const int ci0 = (chunk_lo + sc) * CH;
+            const int nc = min(CH, a.cin - ci0);
             unsigned char *dst = s_in + (sc & 1) * ibuf_bytes;
+            constexpr int KH = CH / 8;   // k halves of a chunk
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int pos = lt + SPLIT_LOADERS * i;
                 const bool ok = goff[i] >= 0;
-                u32x4 q[3][2];
+                u32x4 q[3][KH];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < KH; ++h)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int c0 = 8 * h + 2 * e;
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) *reinterpret_cast<u32x4 *>(dst + ((pl * 2 + h) * plane + pos) * 16) = q[pl][h];
+                        for (int h = 0; h < KH; ++h) *reinterpret_cast<u32x4 *>(dst + ((pl * KH + h) * plane + pos) * 16) = q[pl][h];
                 }
             }
         };
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         auto convert_store = [&](int sc) __attribute__((always_inline)) { convert_store_from(v, sc); };
         long long waited = 0, conv = 0;
         if constexpr (NT <= 2) {   // small patches: the first two chunks travel together (one memory latency before the first tap)
-            float v2[NT][16];
+            float v2[NT][CH];
             if (nchunk > 0) issue_loads_to(v, 0);
             if (nchunk > 1) issue_loads_to(v2, 1);
             if (nchunk > 0) convert_store_from(v, 0);
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             const int qc = min(q, Q - 1);
             pqy[mp] = qc / a.QW; pqx[mp] = qc - pqy[mp] * a.QW;
         }
-        base[mp] = ((pqy[mp] - qy0) * a.in_s * a.Wst + (pqx[mp] - qx0) + half * plane) * 16;
+        base[mp] = ((pqy[mp] - qy0) * a.in_s * a.Wst + (pqx[mp] - qx0) + (TP ? 0 : half * plane)) * 16;
     }
     f32x16 acc[MC][MP];
 #pragma unroll
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mc][mp][r] = 0.f;
 
-    const int pstride = 2 * plane * 16;   // bytes between the pieces of the input buffer
+    const int pstride = (TP ? 1 : 2) * plane * 16;   // bytes between the pieces of the input buffer
     auto load_ops = [&](SplitOps<MP, MC> &o, const unsigned char *bin, const unsigned char *bw, int to) {
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
@@ -364,7 +388,14 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     // tap offsets: lane t of one VGPR holds tap t's offset, fetched with v_readlane (a scalar load per tap would share
     // lgkmcnt with the LDS reads and drain the operand pipeline at every tap)
     const int toff_lane = toff[min(lane, a.taps_per_class - 1)];
-    auto tap_off = [&](int t) { return __builtin_amdgcn_readlane(toff_lane, t); };
+    auto tap_off = [&](int t) {
+        if constexpr (TP) {   // k half h multiplies tap 2t + h (the tap that does not exist has zero weights: any staged entry will do)
+            const int t0 = __builtin_amdgcn_readlane(toff_lane, 2 * t), t1 = __builtin_amdgcn_readlane(toff_lane, min(2 * t + 1, ntaps_real - 1));
+            return half ? t1 : t0;
+        } else {
+            return __builtin_amdgcn_readlane(toff_lane, t);
+        }
+    };
     long long waited = 0;
     if (a.trace && tid == 0) a.trace[wg * 8 + 0] = clock64();
     lds_barrier();
@@ -530,6 +561,7 @@ struct SplitPlan {
     int MP, MC, WPX, tw, th, tiles_x, tiles, Wst, Wsub, ROWS, plane, tap_group, ksplit, wring;
     size_t lds;
     double cost;
+    int tp;   // tap-pair mode (k_conv_split<..., TP = true>)
 };
 
 // Tile shape, tile geometry, tap group and split-K factor of the split kernel, by estimated time (us).
@@ -537,8 +569,11 @@ struct SplitPlan {
 inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
     SplitPlan best{};
     best.ok = false; best.cost = 1e30;
-    int f_mp = 0, f_mc = 0, f_wpx = 0, f_tw = -1, f_tg = 0, f_ks = 0, f_wring = 0;
-    if (const char *e = getenv("LAV_SPLIT_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &f_mp, &f_mc, &f_wpx, &f_tw, &f_tg, &f_ks, &f_wring);
+    int f_mp = 0, f_mc = 0, f_wpx = 0, f_tw = -1, f_tg = 0, f_ks = 0, f_wring = 0, f_tp = -1;
+    if (const char *e = getenv("LAV_SPLIT_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &f_mp, &f_mc, &f_wpx, &f_tw, &f_tg, &f_ks, &f_wring, &f_tp);
+    // tap pairs (see the kernel): deep many-tap stems only - LAV_SPLIT_TP=0 switches the mode off
+    static const bool tp_on = [] { const char *e = getenv("LAV_SPLIT_TP"); return !e || atoi(e) != 0; }();
+    const bool tp_can = tp_on && !c.transposed && p.nclasses == 1 && p.taps_per_class >= 25 && p.taps_per_class <= 63 && c.cin % 16 == 0;
     static const double c_fixed = [] { const char *e = getenv("LAV_SPLIT_C_FIXED"); return e ? atof(e) : 11.0; }();
     static const double c_mma = [] { const char *e = getenv("LAV_SPLIT_C_MMA"); return e ? atof(e) : 0.105; }();
     static const double c_stage = [] { const char *e = getenv("LAV_SPLIT_C_STAGE"); return e ? atof(e) : 0.18; }();
@@ -556,7 +591,12 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
         const int MP = sh[0], MC = sh[1], WPX = sh[2], WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
         if ((f_mp && MP != f_mp) || (f_mc && MC != f_mc) || (f_wpx && WPX != f_wpx)) continue;
         if (NBLK * 32 > p.cout_pad && NBLK > 1 && !(f_mc && f_wpx)) continue;   // more cout blocks than the layer has
-        for (int tw : {0, 32, 64, 128, 256}) {
+        for (int tp = 0; tp <= (tp_can ? 1 : 0); ++tp)
+        for (int tw : {0, 16, 32, 64, 128, 256}) {
+            if (f_tp >= 0 && tp != f_tp) continue;
+            // tap-pair kernels are built for two tile shapes; 16-wide tiles (a wave's 32 pixels = two tile rows) exist for them only
+            if (tp && !((MP == 1 && MC == 2 && WPX == 4) || (MP == 2 && MC == 2 && WPX == 4))) continue;
+            if (tw == 16 && !tp) continue;
             if (tw > PIXW || (f_tw >= 0 && tw != f_tw)) continue;
             if (tw && tw / 2 >= p.QW && tw > 32) continue;        // half of the tile would hang over the image
             if (tw == 0 && p.QW >= 64 && f_tw < 0) continue;      // wide maps: full-width rows of a linearised tile are too much staging
@@ -576,15 +616,17 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
             const int Wsub = (Wreal + p.in_s - 1) / p.in_s, Wst = Wsub * p.in_s;
             const int ROWS = (rows - 1) * p.in_s + p.max_dy + 1;
             const int plane = (ROWS * Wst + 63) / 64 * 64;
-            if (plane > SPLIT_LOADERS * SPLIT_NT) continue;
+            if (plane > SPLIT_LOADERS * (tp ? SPLIT_NT_TP : SPLIT_NT)) continue;
             {
                 // LDS: two activation chunk buffers + a ring of three groups of G taps of weights
                 static const int g_max = [] { const char *e = getenv("LAV_SPLIT_GMAX"); return e ? atoi(e) : 4; }();
                 for (int G : {4, 2, 1}) {
                     if (G > g_max || (f_tg && G != f_tg)) continue;
                     if (G == 4 && MP * MC > 2 && !f_tg) continue;   // 2x2 tiles have 24 matrix instructions per tap: a barrier every 2 taps is amortised
-                    if (2 * G > min_taps + 1 && G > 1) continue;   // 2G consecutive taps must touch at most two chunks (in every class)
-                    const size_t lds_in = (size_t)2 * 6 * plane * 16, wslot = (size_t)NBLK * 3 * 1024;
+                    if (tp && G != (MP * MC == 2 ? 4 : 1)) continue;   // built: 1x2 tiles with G = 4, 2x2 tiles with G = 1 (their 256-pixel patch leaves LDS for a 3-slot ring)
+                    const int steps_per_chunk = tp ? (min_taps + 1) / 2 : min_taps;
+                    if (2 * G > steps_per_chunk + 1 && G > 1) continue;   // 2G consecutive steps must touch at most two chunks (in every class)
+                    const size_t lds_in = (size_t)2 * (tp ? 3 : 6) * plane * 16, wslot = (size_t)NBLK * 3 * 1024;
                     const size_t lds = lds_in + 3 * G * wslot;
                     if (lds > LDS_MAX) continue;
                     const long wgs1 = tiles * ((c.cout + NBLK * 32 - 1) / (NBLK * 32)) * c.batch * p.nclasses;
@@ -600,7 +642,7 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
                         const double short_loop_us = nchunks * min_taps <= 8 ? 6.0 : 0.0;
                         const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + short_loop_us + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
                         if (t < best.cost * (ks > 1 ? 0.97 : 1.0) - 1e-9) {
-                            best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, G, ks, 3 * G, lds, t};
+                            best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, G, ks, 3 * G, lds, t, tp};
                         }
                     }
                 }
@@ -610,14 +652,14 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
     return best;
 }
 
-template <int MP, int MC, int WPX, int NT, int G>
+template <int MP, int MC, int WPX, int NT, int G, bool TP = false>
 int launch_split_g(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split<MP, MC, WPX, NT, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split<MP, MC, WPX, NT, G, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT, G>), grid, dim3(512), lds, st, sa);
+    hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT, G, TP>), grid, dim3(512), lds, st, sa);
     return LAV_OK;
 }
 template <int MP, int MC, int WPX>
@@ -669,6 +711,11 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
     dim3 grid((c.cout + NBLK * 32 - 1) / (NBLK * 32), sp.tiles, c.batch * p.nclasses * sp.ksplit);
     const int tok = timer_begin("conv2d", st);
     int rc = LAV_EINVAL;
+    if (sp.tp) {
+        if (sp.MP == 1 && sp.MC == 2 && sp.WPX == 4 && sp.tap_group == 4) rc = launch_split_g<1, 2, 4, SPLIT_NT_TP, 4, true>(s, grid, sp.lds, st);
+        else if (sp.MP == 2 && sp.MC == 2 && sp.WPX == 4 && sp.tap_group == 1) rc = launch_split_g<2, 2, 4, SPLIT_NT_TP, 1, true>(s, grid, sp.lds, st);
+        else return fail(LAV_EINVAL, "lav_conv2d: tap-pair split tile %dx%d/%d G%d not built", sp.MP, sp.MC, sp.WPX, sp.tap_group);
+    } else
     switch (sp.MP * 100 + sp.MC * 10 + sp.WPX) {
         case 224: rc = launch_split_t<2, 2, 4>(s, grid, sp.lds, st); break;
         case 124: rc = launch_split_t<1, 2, 4>(s, grid, sp.lds, st); break;

@@ -342,3 +342,67 @@ def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):
     torch.cuda.synchronize()
     t2, n2 = ops.pair_chain_status(DEV)
     assert (t2, n2) == (t1, n1 + 1) and torch.equal(back, good)
+
+
+TAP_PAIR_CASES = [
+    # name, B, cin, cout, k, stride, pad, H, W, LAV_SPLIT_FORCE (MP,MC,WPX,tw,tg,ks,ring,tp)
+    ("7x7 s2 stem 1x2 tile, ragged tiles", 3, 32, 64, 7, 2, 3, 50, 46, "1,2,4,16,4,0,0,1"),
+    ("7x7 s2 stem 2x2 tile", 2, 64, 64, 7, 2, 3, 96, 96, "2,2,4,16,1,0,0,1"),
+    ("7x7 s2 stem, split-K 3", 1, 96, 64, 7, 2, 3, 96, 96, "1,2,4,16,4,3,0,1"),
+    ("5x5 s1 (13 pairs, odd tap out), ragged couts", 2, 48, 40, 5, 1, 2, 20, 36, "1,2,4,16,4,0,0,1"),
+    ("6x6 s2 (even tap count), split-K 2", 2, 32, 64, 6, 2, 2, 40, 40, "1,2,4,16,4,2,0,1"),
+]
+
+
+@pytest.mark.parametrize("case", TAP_PAIR_CASES, ids=[c[0] for c in TAP_PAIR_CASES])
+def test_split_kernel_tap_pair_mode(case, monkeypatch):
+    """k_conv_split<..., TP>: 8-channel chunks, two taps per matrix instruction (the 7x7 stride-2 crop stems).  The plan is
+    pinned and checked (tap-pair mode reports tap group + 100), the result held to the fp32 reference with bias, eval-mode
+    BatchNorm, residual and ReLU in the epilogue, and to the exact-fp32 kernel of this library."""
+    import ctypes
+    from lav_amd import _lib
+    name, B, cin, cout, k, s, p, H, W, force = case
+    monkeypatch.setenv("LAV_CONV_SPLIT", "2")
+    monkeypatch.setenv("LAV_SPLIT_FORCE", force)
+    x = rnd((B, cin, H, W), 31)
+    w = rnd((cout, cin, k, k), 32, scale=1.0 / np.sqrt(cin * k * k))
+    bias = rnd((cout,), 33)
+    bn = (rnd((cout,), 34, 0.1), rnd((cout,), 35).abs() + 0.5, rnd((cout,), 36).abs() + 0.5, rnd((cout,), 37, 0.1))
+    conv = F.conv2d(x, w, bias, s, p)
+    res = rnd(tuple(conv.shape), 38)
+    ref = F.relu(F.batch_norm(conv, bn[0], bn[1], bn[2], bn[3], False, 0., 1e-5) + res)
+    kw = dict(stride=s, padding=(p, p), bias=bias, bn=bn, relu_post=True, device=DEV)
+    layer = ConvLayer(w, precision=_lib.CONV_BF16X6, **kw)
+    d = _lib.Conv.from_buffer_copy(layer.desc); d.batch, d.h, d.w = B, H, W
+    info = (ctypes.c_int * 9)()
+    assert _lib.load().lav_conv_tile_info(ctypes.byref(d), info) == 0
+    assert info[0] == -1 and info[7] >= 100, f"expected a tap-pair split plan, got {list(info)}"
+    y = layer(x.to(DEV), residual=res.to(DEV)).cpu()
+    assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=name)
+    monkeypatch.delenv("LAV_SPLIT_FORCE")
+    exact = ConvLayer(w, precision=_lib.CONV_F32, **kw)(x.to(DEV), residual=res.to(DEV)).cpu()
+    assert_close(y.numpy(), exact.numpy(), atol=1e-5, rtol=1e-5, what=name + " vs fp32 kernel")
+
+
+def test_tap_pair_stem_respects_the_batch_limit(monkeypatch):
+    """The others branch runs its stem at capacity 15 with a device-resident row limit: rows >= N keep their old contents,
+    rows < N are bit-identical to a batch-N launch."""
+    import ctypes
+    from lav_amd import _lib, ops
+    monkeypatch.setenv("LAV_CONV_SPLIT", "2")
+    monkeypatch.setenv("LAV_SPLIT_FORCE", "1,2,4,16,4,2,0,1")   # split-K 2: the reduce launch honours the limit as well
+    B, N, cin = 5, 2, 32
+    x = rnd((B, cin, 48, 48), 41)
+    w = rnd((64, cin, 7, 7), 42, scale=1.0 / np.sqrt(cin * 49))
+    layer = ConvLayer(w, stride=2, padding=(3, 3), relu_post=True, precision=_lib.CONV_BF16X6, device=DEV)
+    d = _lib.Conv.from_buffer_copy(layer.desc); d.batch, d.h, d.w = B, 48, 48
+    info = (ctypes.c_int * 9)()
+    assert _lib.load().lav_conv_tile_info(ctypes.byref(d), info) == 0
+    assert info[0] == -1 and info[7] >= 100, f"expected a tap-pair split plan, got {list(info)}"
+    full = layer(x.to(DEV)).clone()
+    out = torch.full_like(full, 7.0)
+    n_dev = torch.tensor([N], dtype=torch.int32, device=DEV)
+    with ops.batch_limit(n_dev):
+        layer(x.to(DEV), out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:N], full[:N]) and (out[N:] == 7).all()

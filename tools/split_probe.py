@@ -29,7 +29,9 @@ SHAPES = [
     ("up2 convT 4x4 s2", 1, 128, 128, (4, 4), 2, (1, 1), (1, 1), True, 0, 80, 80),
     ("up3 convT 4x4 s4", 1, 128, 128, (4, 4), 4, (1, 1), (1, 1), True, 2, 40, 40),
     ("stem 7x7 B1", 1, 384, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 96),
+    ("stem 7x7 B4", 4, 384, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 96),
     ("stem 7x7 B7", 7, 384, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 96),
+    ("stem 7x7 B15", 15, 384, 64, (7, 7), 2, (3, 3), (1, 1), False, 0, 96, 96),
     ("res l1 64 24x24 B1", 1, 64, 64, (3, 3), 1, (1, 1), (1, 1), False, 0, 24, 24),
     ("res l1 64 24x24 B7", 7, 64, 64, (3, 3), 1, (1, 1), (1, 1), False, 0, 24, 24),
     ("res l2 128 12x12 B7", 7, 128, 128, (3, 3), 1, (1, 1), (1, 1), False, 0, 12, 12),
@@ -64,7 +66,7 @@ def plan_str(lib, layer, B, H, W):
     if lib.lav_conv_tile_info(ctypes.byref(desc), info):
         return "?"
     if info[0] == -1:
-        return f"split {info[1]}x{info[2]}/w{info[3]} tw{info[4]}xth{info[8]} tg{info[7]} ks{info[6]} lds{info[5] // 1024}K"
+        return f"split {info[1]}x{info[2]}/w{info[3]} tw{info[4]}xth{info[8]} tg{info[7] % 100}{'p' if info[7] >= 100 else ''} ks{info[6]} lds{info[5] // 1024}K"
     if info[0] == 0:
         return f"direct w{info[1]} mc{info[2]} ks{info[6]}"
     return f"tiled {info[0]}x{info[1]} ks{info[6]} lds{info[5] // 1024}K"
