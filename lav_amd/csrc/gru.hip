@@ -668,8 +668,14 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
         hipLaunchKernelGGL(k_plan_reset, dim3((reset_words / 4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4 *>(status), reset_words / 4);
         const char *lim = getenv("LAV_PLAN_SPIN_LIMIT");   // test knob: 1 forces the time-out path
         const long long spin_limit = lim && atoll(lim) > 0 ? atoll(lim) : PLAN_SPIN_LIMIT;
-        static const char *poll_env = getenv("LAV_PLAN_POLL");   // all | quarter (default where H allows it)
-        const bool quarter = H % 256 == 0 && !(poll_env && poll_env[0] == 'a');
+        // all (default) | quarter.  The quarter-poll variant is 0.16 ms faster per plan, bit-identical on a quiet chip and beside
+        // most kernels - and returns finite but WRONG plans (errors from 1e-5 growing to 0.5 m over the 100 steps, every launch)
+        // while the tap-pair 7x7 stem kernel of conv_split.hpp (150 KB of LDS, its waves share SIMDs with this kernel's) runs on
+        // another stream: tools/plan_stress.py, profiles/r04_plan_stress.txt.  The rendezvous values equal the granules and no
+        // foreign write reaches this workgroup's LDS (both instrumented); the cause is not found, so the variant is opt-in
+        // for experiments only and tests/test_gpu_paint_gru.py holds the default to the step path under that load.
+        static const char *poll_env = getenv("LAV_PLAN_POLL");
+        const bool quarter = H % 256 == 0 && poll_env && poll_env[0] == 'q';
 #define LAV_PLAN_CASE(P_, RC_) hipLaunchKernelGGL((k_plan_persistent<P_, RC_>), dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit)
         if (a.R == 1) { if (quarter) LAV_PLAN_CASE(1, 1); else LAV_PLAN_CASE(0, 1); }
         else { if (quarter) LAV_PLAN_CASE(1, PLAN_RC); else LAV_PLAN_CASE(0, PLAN_RC); }

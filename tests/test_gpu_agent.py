@@ -118,7 +118,10 @@ def test_agent_vs_reference_agent_golden(golden, tmp_path, hip_graphs):
         out = a.last_outputs
         # pose handed to the stacking = the reference's EKF state before the tick
         pose = a.pipeline.poses[-1] if hip_graphs else (a.pipeline.locs[-1], a.pipeline.oris[-1])
-        np.testing.assert_allclose(np.r_[pose[0], pose[1]], g["poses"][i], rtol=0, atol=1e-6)
+        # (the EKF integrates the PREVIOUS ticks' steer - held to 1e-3 above - through the bicycle model: a steer difference d
+        # moves the pose by about speed * 0.05 s * d / 2 per tick, so 1e-4 m here is the steer bar's own consequence; measured
+        # 1.6e-5 m with the crop stems on the split-operand kernel, < 1e-6 while they ran on the fp32 kernel)
+        np.testing.assert_allclose(np.r_[pose[0], pose[1]], g["poses"][i], rtol=0, atol=1e-4)
         if hip_graphs:
             np.testing.assert_allclose(a.pipeline.b_nxp.cpu().numpy(), g["nxps"][i], rtol=1e-5, atol=1e-4)
         assert abs(float(out["pred_bra"]) - g["pred_bra"][i]) < 1e-5

@@ -97,7 +97,8 @@ def test_embed_cast_is_pool_cast_cmd_pred_and_transform(B, hw, with_pose):
 
 
 @pytest.mark.parametrize("case", [("head", 1, 384, 256, 3, 1, 1, 40, False), ("s2", 2, 64, 128, 3, 2, 1, 40, False),
-                                  ("up", 2, 128, 64, 3, 2, 1, 20, True), ("res", 7, 128, 128, 3, 1, 1, 12, False)])
+                                  ("up", 2, 128, 64, 3, 2, 1, 20, True), ("res", 7, 128, 128, 3, 1, 1, 12, False),
+                                  ("stem", 2, 384, 64, 7, 2, 3, 96, False)])   # (tap-pair mode of the split kernel, K = 18 816)
 def test_split_operand_convolution_is_as_accurate_as_fp32(case):
     """precision bf16x6 (three bf16 pieces per operand, the six leading products on the bf16 matrix cores, fp32 accumulation)
     against a float64 convolution: its error stays at the fp32 kernel's level (both ~1e-6 of sum |a||b|), so the 1e-4 / 3e-5

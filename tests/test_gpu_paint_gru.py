@@ -128,3 +128,59 @@ def test_plan_timeout_is_loud_and_recoverable(golden, monkeypatch):
     d2 = ops.gru_plan_diag(1, 512, 6, 3, DEV)
     assert d2["status"] == 0 and d2["entered"] == 64 and d2["completed"] == 64 and d2["abort_wg_plus1"] == 0, d2
     assert d2["launches"] >= d["launches"] + 1 and d2["aborted_launches"] == d["aborted_launches"]
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_persistent_plan_is_exact_beside_the_crop_stem(graph):
+    """The one-launch plan kernel against the step-per-launch path while another stream keeps every CU busy with the others
+    branch's 7x7 stem (tap-pair split kernel: 150 KB of LDS per workgroup, its waves share SIMDs with the plan kernel's) -
+    the load under which round 4's quarter-poll variant returned finite but wrong plans on every launch (it passed every
+    quiet-chip test; tools/plan_stress.py).  Two alternating inputs, so that state left over from the previous launch would
+    show; every launch must equal the step path bit for bit and none may abort."""
+    from lav_amd import _lib
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    H, T, NC, N = 512, 20, 6, 80
+    g = lambda *s, sc=1.0: (torch.randn(*s) * sc).to(dev)
+    w_ih, w_hh, b_ih, b_hh = g(3 * H, 4, sc=0.3), g(3 * H, H, sc=H ** -0.5), g(3 * H, sc=0.1), g(3 * H, sc=0.1)
+    mlp_w, mlp_b = g(2, H, sc=0.05), g(2, sc=0.1)
+    inputs = [(g(1, H, sc=0.5), g(1, 2, sc=3.0), g(1, NC, T, 2, sc=2.0)) for _ in range(2)]
+
+    def plan(i, impl="auto"):
+        e, n, c = inputs[i & 1]
+        return ops.gru_plan(e, n, c, w_ih, w_hh, b_ih, b_hh, mlp_w, mlp_b, 5, 3, 4.0, 192.0, impl=impl)
+
+    want = [plan(0, "steps").clone(), plan(1, "steps").clone()]
+    hog = ops.ConvLayer(torch.randn(64, 384, 7, 7) / (384 * 49) ** 0.5, stride=2, padding=(3, 3), relu_post=True,
+                        precision=_lib.CONV_BF16X6, device=dev)
+    hog_x = torch.randn(15, 384, 96, 96, device=dev)
+    s_hog, s_plan = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s_hog):
+        hog(hog_x)
+    torch.cuda.synchronize()
+    graphs = []
+    if graph:
+        for i in range(2):
+            with torch.cuda.stream(s_plan):
+                plan(i)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s_plan):
+                o = plan(i)
+            graphs.append((gr, o))
+        torch.cuda.synchronize()
+    outs = []
+    for i in range(N):
+        with torch.cuda.stream(s_hog):
+            hog(hog_x)
+        with torch.cuda.stream(s_plan):
+            if graph:
+                graphs[i & 1][0].replay()
+                outs.append(graphs[i & 1][1].clone())
+            else:
+                outs.append(plan(i))
+    torch.cuda.synchronize()
+    wrong = [(i, float((o - want[i & 1]).abs().max())) for i, o in enumerate(outs) if not torch.equal(o, want[i & 1])]
+    assert not wrong, f"{len(wrong)} of {N} persistent plan launches differ from the step path: {wrong[:5]}"
+    diag = ops.gru_plan_diag(1, H, NC, 3, dev, stream=s_plan)
+    assert diag["aborted_launches"] == 0 and diag["launches"] >= N, diag
