@@ -318,6 +318,13 @@ def main():
         health["last_plan_launch"] = h1["last_plan_launch"]
     host_finite = all(bool(torch.isfinite(out[k]).all()) for k in ("ego_plan_locs", "ego_cast_locs", "ego_embd", "pred_bra", "pred_bev")) \
         and bool(torch.isfinite(out["other_cast_locs"]).all())
+    # finite is not yet right: forty more frames (untimed), each plan recomputed on the step-per-launch path and compared
+    plan_dev = None
+    if hasattr(pipe, "plan_deviation"):
+        plan_dev = 0.0
+        for _ in range(40):
+            o = step(i); i += 1
+            plan_dev = max(plan_dev, pipe.plan_deviation(o, 3))
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -560,7 +567,8 @@ def main():
                                launch="eager" if args.eager else "hip graphs: lidar / heads / others (capacity 15, device-resident count) on the main stream, brake and ego[cmd] on side streams"),
                    roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, roofline_hbm_glue=glue,
                    forced_others=forced, hip_kernel_us_per_frame=per_frame_us,
-                   health=health, last_frame_outputs_finite=host_finite, chain_only_ms=chain_ms, graph_replay_ms=graphs_ms)
+                   health=health, last_frame_outputs_finite=host_finite, plan_vs_step_path_max_abs=plan_dev, chain_only_ms=chain_ms,
+                   graph_replay_ms=graphs_ms)
         bad = [] if host_finite else ["the last timed frame holds non-finite outputs"]
         if health is not None:
             if health["nonfinite_outputs"]:
@@ -569,6 +577,8 @@ def main():
                 bad.append(f"{health['plan_aborts']} persistent plan launches timed out")
             if health["pair_chain_timeouts"]:
                 bad.append(f"{health['pair_chain_timeouts']} workgroups of the persistent ERFNet runs gave up waiting")
+        if plan_dev is not None and not plan_dev <= 1e-5:
+            bad.append(f"the graphs' plan differs from the step path by {plan_dev:.3g} m (finite but wrong)")
         res["valid"] = not bad
         if bad:
             res["invalid_reason"] = "; ".join(bad)

@@ -41,7 +41,7 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *lds) {
     a = wave_sum(a);
     b = wave_sum(b);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) { lds[2 * wid] = a; lds[2 * wid + 1] = b; }
+    if (lane == 0) { lds[2 * wid] = a; lav::lds_store_fence(); lds[2 * wid + 1] = b; }   // (no ds_write2_b64: common.hpp)
     __syncthreads();
     if (threadIdx.x == 0) {
         a = lds[0] + lds[2] + lds[4] + lds[6];

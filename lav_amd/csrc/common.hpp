@@ -25,6 +25,26 @@ inline int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// gfx950 hazard found in round 4 (tools/plan_stress.py, profiles/r04_plan_stress.txt): hipcc merges two adjacent 64-bit LDS stores
+// into one ds_write2_b64 (128 bits of data read from the VGPR file over more than one cycle) and then schedules VALU instructions
+// that OVERWRITE those data registers right behind it - its hazard recognizer only pads stores whose first data operand is wider than
+// 64 bits (ds_write_b96 / b128).  Alone on its SIMD the wave gets away with it; with another kernel's waves issuing matrix
+// instructions on the same SIMD the LDS instruction reads its operands late and stores the NEW register contents: the persistent plan
+// kernel's gate pre-activations of every fourth row, whenever a 7x7 crop stem (tap-pair split kernel) shared its CUs.  Call this
+// between LDS stores that the compiler could pair into 2 x 64 bits; tests/test_capi_host.py fails if a ds_write2_b64 is left in the
+// library.
+__device__ __forceinline__ void lds_store_fence() { asm volatile("" ::: "memory"); }
+// The same stress test then showed the 64-bit form as well (ds_write_b64 of {r0, r1} with a v_pk_add_f32 into the same registers as
+// the very next instruction) once the neighbour waves issue matrix instructions AND LDS traffic (the real stem kernel; the
+// synthetic one of tools/probes/lds_hog.hip in mode 1): an LDS store waiting in a congested LDS queue reads its data registers
+// when it gets there, not when it was issued.  A long-running kernel that shares CUs with such neighbours therefore COMMITS its LDS
+// stores: wait until they have left (lgkmcnt 0), and keep every stored value pinned in its register until then -
+//     s[i] = v; ...; lds_commit(); lds_keep(v); ...
+// (lds_keep is an empty asm that "modifies" v, so the register allocator cannot hand v's register to anything else before it).
+__device__ __forceinline__ void lds_commit() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <class T>
+__device__ __forceinline__ void lds_keep(T &v) { asm volatile("" : "+v"(v)); }
+
 #define LAV_HIP(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t lav_e_ = (expr);                                                                        \

@@ -458,6 +458,21 @@ class GraphedFramePipeline(FramePipeline):
         self.plan_aborts += 1
         return plan
 
+    @torch.no_grad()
+    def plan_deviation(self, out, cmd_value) -> float:
+        """max |graph's persistent plan - the same plan recomputed on the step-per-launch path| of a frame `step` returned (the two
+        paths are bit-identical: tests/test_gpu_paint_gru.py).  A finite but wrong plan is invisible to the health counters - round
+        4's quarter-poll kernel produced exactly that beside the crop stems - so bench.py runs this on frames after its timed ones."""
+        up = self.infer_model.uniplanner
+        with torch.cuda.stream(self.s_ego):
+            self.s_ego.wait_stream(torch.cuda.current_stream())
+            ego_cast = up.cast(out["ego_embd"], mode="ego")
+            plan = up.plan(out["ego_embd"], self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
+                           crop_size=up.crop_size * 2, cmd=int(cmd_value), impl="steps")[0, -1, 0]
+            dev = (plan - out["ego_plan_locs"]).abs().max()
+        torch.cuda.current_stream().wait_stream(self.s_ego)
+        return float(dev)
+
     def health(self, cmd_value: int = 3) -> dict:
         """Counters of the drive so far (synchronises): non-finite output tensors seen by the graphs' own checks (ego embedding /
         plan / cast, brake prediction; the peak rows are checked on the host), persistent plan launches and how many of them timed out (sticky words of the

@@ -355,3 +355,27 @@ def test_split_kernel_is_never_planned_for_classes_without_taps():
             info = (C.c_int * 9)()
             assert lib.lav_conv_tile_info(C.byref(d), info) == 0
             assert info[0] != -1, (cin, cout, B, H, list(info))
+
+
+def test_library_holds_no_ds_write2_b64(tmp_path):
+    """hipcc pairs adjacent 64-bit LDS stores into ds_write2_b64 and may overwrite the store's data registers with the very next
+    instructions (its hazard recognizer only pads stores whose FIRST data operand is wider than 64 bits); on gfx950 that store
+    then writes the new register contents whenever another kernel's waves keep the SIMD's matrix pipe busy - round 4's
+    wrong-but-finite plans (profiles/r04_plan_stress.txt, lav_amd/csrc/common.hpp: lds_store_fence).  No such instruction may be
+    left in the built library."""
+    import glob
+    import shutil
+    import subprocess
+    from lav_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or the built library is missing")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert objs, "no gfx950 code object found in the library"
+    bad = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", o], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+        bad += asm.count("ds_write2_b64") + asm.count("ds_write2st64_b64")
+    assert bad == 0, f"{bad} ds_write2_b64 instructions in liblav_amd.so: separate the stores with lav::lds_store_fence()"

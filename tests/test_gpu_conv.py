@@ -313,6 +313,25 @@ def test_pair_chain_is_bit_identical_to_the_pairs_launched_one_by_one(ch, h, w, 
         again = chain(x)
     torch.cuda.synchronize()
     assert chain.timeouts(x) == 0 and torch.equal(again, want)
+    # ... and beside a stream that keeps every CU busy with the tap-pair 7x7 stem kernel (150 KB of LDS per workgroup, waves that
+    # share SIMDs with other kernels' - the load that broke round 4's quarter-poll plan kernel, tools/plan_stress.py)
+    from lav_amd import _lib
+    hog = ConvLayer(torch.randn(64, 384, 7, 7) / (384 * 49) ** 0.5, stride=2, padding=(3, 3), relu_post=True, precision=_lib.CONV_BF16X6, device=DEV)
+    hog_x = torch.randn(15, 384, 96, 96, device=DEV)
+    s_hog, s_chain = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s_hog):
+        hog(hog_x)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(30):
+        with torch.cuda.stream(s_hog):
+            hog(hog_x)
+        with torch.cuda.stream(s_chain):
+            outs.append(chain(x).clone())
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s_chain):
+        assert chain.timeouts(x) == 0
+    assert all(torch.equal(o, want) for o in outs), "the persistent run differs from the single launches beside the stem kernel"
 
 
 def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):

@@ -35,7 +35,23 @@ torch.cuda.synchronize()
 print("persistent vs steps, quiet chip:", [float((plan(i) - want[i]).abs().max()) for i in range(2)])
 
 HOG = os.environ.get("PLAN_STRESS_HOG", "stem")   # stem: the 7x7 crop stem at capacity 15 | head: 384->256 3x3 @160x160 | fill: 400 MB fills
-if HOG == "head":
+#                                                    synth0/1/2: tools/probes/lds_hog.hip (stem-shaped workgroups: no LDS access / LDS traffic / sleeping)
+if HOG.startswith("synth"):
+    import ctypes
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes")
+    so = os.path.join(here, "liblds_hog.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", os.path.join(here, "lds_hog.hip"), "-o", so])
+    hoglib = ctypes.CDLL(so)
+    hoglib.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    hog_x = torch.zeros(16, device=dev)
+    mode = int(HOG[5:])
+
+    def hog(x):
+        rc = hoglib.hog_launch(810, 153600, mode, 2000 if mode == 2 else 4000, x.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+elif HOG == "head":
     hog_w = torch.randn(256, 384, 3, 3) / (384 * 9) ** 0.5
     hog = ConvLayer(hog_w, stride=1, padding=(1, 1), relu_post=True, precision=_lib.CONV_BF16X6, device=dev)
     hog_x = torch.randn(1, 384, 160, 160, device=dev)
@@ -89,6 +105,6 @@ def run(label, with_hog, graph):
     print(f"{label:28s} launches {N}  max |diff| {max(dev_):.3e}  wrong {len(bad)}  first {bad[:6]}  aborted {diag['aborted_launches']}/{diag['launches']}", flush=True)
 
 
-for graph in ((False,) if os.environ.get("LAV_PLAN_CHECK") else (False, True)):
+for graph in (False, True):
     for with_hog in (False, True):
         run(f"{'graph' if graph else 'eager'} {'+ hog stream' if with_hog else 'alone'}", with_hog, graph)
