@@ -248,7 +248,11 @@ typedef struct lav_conv {
                           finite input up to FLT_MAX is split exactly; an Inf or NaN activation / weight gives NaN in the
                           outputs it reaches, where LAV_CONV_F32 and the reference's cuDNN path propagate Inf as Inf);
                           0 = the library default (environment LAV_CONV_PRECISION = f32 | bf16x6, default bf16x6).  The
-                          packed weights of a layer depend on it: pack and run with the same descriptor */
+                          packed weights of a layer depend on it: pack and run with the same descriptor.  Launch note: a
+                          workgroup of the split-operand kernel claims its CU's whole 160 KB of LDS whatever its tiles need
+                          (one workgroup per CU either way), so that no kernel that uses LDS runs beside it on a CU - such
+                          neighbours were measured to compute wrong results on gfx950 (DESIGN 4.4c;
+                          LAV_SPLIT_LDS_EXCLUSIVE=0 restores the exact size for experiments) */
 } lav_conv;
 #define LAV_CONV_F32 1
 #define LAV_CONV_BF16X6 2
