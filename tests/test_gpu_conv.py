@@ -370,6 +370,7 @@ TAP_PAIR_CASES = [
     ("7x7 s2 stem, split-K 3", 1, 96, 64, 7, 2, 3, 96, 96, "1,2,4,16,4,3,0,1"),
     ("5x5 s1 (13 pairs, odd tap out), ragged couts", 2, 48, 40, 5, 1, 2, 20, 36, "1,2,4,16,4,0,0,1"),
     ("6x6 s2 (even tap count), split-K 2", 2, 32, 64, 6, 2, 2, 40, 40, "1,2,4,16,4,2,0,1"),
+    ("7x7 s2 stem at a training-size batch of 20 crops", 20, 32, 64, 7, 2, 3, 48, 48, "1,2,4,16,4,0,0,1"),
 ]
 
 
@@ -400,7 +401,7 @@ def test_split_kernel_tap_pair_mode(case, monkeypatch):
     assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=name)
     monkeypatch.delenv("LAV_SPLIT_FORCE")
     exact = ConvLayer(w, precision=_lib.CONV_F32, **kw)(x.to(DEV), residual=res.to(DEV)).cpu()
-    assert_close(y.numpy(), exact.numpy(), atol=1e-5, rtol=1e-5, what=name + " vs fp32 kernel")
+    assert_close(y.numpy(), exact.numpy(), atol=3e-5, rtol=1e-5, what=name + " vs fp32 kernel")   # (two fp32 summation orders: 2.1e-5 in 2 of 737 280 outputs of the 20-crop case)
 
 
 def test_tap_pair_stem_respects_the_batch_limit(monkeypatch):

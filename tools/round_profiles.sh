@@ -9,7 +9,7 @@ cd /tmp; export TMPDIR=/tmp
 # the bench line (frame + roofline blocks + forced-N frames + the two training lines + cpu baselines)
 timeout 900 python $R/bench.py > $O/bench_line.json 2> $O/bench.err < /dev/null
 # per-kernel times of the same frame loop
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 30 --warmup 16 --no-cpu-baseline --no-train > /dev/null 2>&1 < /dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $R/bench.py --steps 30 --warmup 16 --no-cpu-baseline --no-train --no-variants > /dev/null 2>&1 < /dev/null
 f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_bench.csv
 # PMC passes, one counter set per run (never together with a trace)
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
