@@ -251,6 +251,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the short train_full / train_bev runs appended to the inference line")
     ap.add_argument("--no-variants", action="store_true", help="skip the exact-fp32 child run of the frame")
+    ap.add_argument("--plan-check-frames", type=int, default=40, help="frames after the timed ones whose plan is recomputed on the step-per-launch path")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     ap.add_argument("--mode", default="infer", choices=["infer", "train_full", "train_bev"],
                     help="infer: BASELINE metric (i) frames/s; train_full / train_bev: metric (ii) samples/s, data parallel")
@@ -318,11 +319,11 @@ def main():
         health["last_plan_launch"] = h1["last_plan_launch"]
     host_finite = all(bool(torch.isfinite(out[k]).all()) for k in ("ego_plan_locs", "ego_cast_locs", "ego_embd", "pred_bra", "pred_bev")) \
         and bool(torch.isfinite(out["other_cast_locs"]).all())
-    # finite is not yet right: forty more frames (untimed), each plan recomputed on the step-per-launch path and compared
+    # finite is not yet right: more frames (untimed, --plan-check-frames), each plan recomputed on the step-per-launch path and compared
     plan_dev = None
     if hasattr(pipe, "plan_deviation"):
         plan_dev = 0.0
-        for _ in range(40):
+        for _ in range(args.plan_check_frames):
             o = step(i); i += 1
             plan_dev = max(plan_dev, pipe.plan_deviation(o, 3))
     if world > 1:
