@@ -45,6 +45,20 @@ __device__ __forceinline__ void lds_commit() { asm volatile("s_waitcnt lgkmcnt(0
 template <class T>
 __device__ __forceinline__ void lds_keep(T &v) { asm volatile("" : "+v"(v)); }
 
+// Host side of the same finding: the kernels that combine bf16 matrix instructions with heavy LDS traffic (split-operand
+// convolutions, the ERFNet pair kernels) corrupt LDS-dependent results of kernels whose waves share their CUs (measured with the
+// persistent plan kernel as the victim: wrong in 171 of 300 launches beside the brake net's split convolutions, 3-10 of 300 beside
+// ERFNet, 0 of 300 once these kernels leave no LDS on their CUs; the fp32 tiled / direct kernels are harmless).  They therefore
+// CLAIM the LDS of their CU: all of it when one workgroup runs per CU, half each when two do.  LAV_LDS_EXCLUSIVE=0: exact sizes.
+inline size_t lds_claim(size_t need, size_t static_bytes = 0) {
+    static const bool on = [] { const char *e = getenv("LAV_LDS_EXCLUSIVE"); return !e || atoi(e) != 0; }();
+    const size_t total = 160 * 1024;
+    if (!on) return need;
+    if (need + static_bytes > total / 2) return (total - static_bytes) / 16 * 16;       // one workgroup per CU
+    if (need + static_bytes > total / 3) return (total / 2 - static_bytes) / 16 * 16;   // two
+    return need;                                                                          // three or more: left alone
+}
+
 #define LAV_HIP(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t lav_e_ = (expr);                                                                        \

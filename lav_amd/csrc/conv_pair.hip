@@ -515,6 +515,7 @@ struct PairChainArgs {
 // TRACE (LAV_PAIR_CHAIN_TRACE): thread 0 of every workgroup accumulates the shader-clock cycles of each phase over the run into
 // a.trace[workgroup][8]: 0 whole run, 1 counter waits, 2 neighbour rows (loads, conversion, LDS), 3 halo + barrier, 4 phase A,
 // 5 combine + intermediate row, 6 phase B, 7 epilogue + publication
+constexpr size_t CHAIN_STATIC_LDS = 2064;   // s_abort + s_epi of k_conv1d_pair_chain (hipcc: "LDS Size [bytes/block]: 2064")
 template <int KS, int R, bool TRACE = false>
 __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a) {
     long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0, tr_t0 = 0;
@@ -910,7 +911,7 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
 #define LAV_PAIRS_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
         static bool attr = false; \
         if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_split<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_conv1d_pair_split<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, sst, sa); }
+        hipLaunchKernelGGL((k_conv1d_pair_split<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lav::lds_claim(lds), sst, sa); }
         LAV_PAIRS_CASE(1, 1) LAV_PAIRS_CASE(1, 2) LAV_PAIRS_CASE(1, 4) LAV_PAIRS_CASE(2, 1) LAV_PAIRS_CASE(2, 2) LAV_PAIRS_CASE(2, 4)
 #undef LAV_PAIRS_CASE
         timer_end(tok2, sst);
@@ -941,7 +942,7 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
 #define LAV_PAIR_CASE(KS_, R_) if (ks == KS_ && ring == R_) { \
         static bool attr = false; \
         if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_conv1d_pair<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, st, a); }
+        hipLaunchKernelGGL((k_conv1d_pair<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lav::lds_claim(lds), st, a); }
     LAV_PAIR_CASE(1, 1) LAV_PAIR_CASE(1, 2) LAV_PAIR_CASE(1, 4) LAV_PAIR_CASE(2, 1) LAV_PAIR_CASE(2, 2) LAV_PAIR_CASE(2, 4)
 #undef LAV_PAIR_CASE
     if (a.trace && ++runs % 10 == 0) {   // debug: per-workgroup phase times of every 10th launch
@@ -1036,9 +1037,17 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
     const int ring2 = nch2 % 2 == 0 ? 2 : 1;
     const int tok = timer_begin("conv1d_pair", st);
 #define LAV_CHAIN_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
-        static bool attr = false;   /* (the kernel also holds ~2 KB of static LDS: the dynamic part may not claim all 160 KB) */ \
-        if (!attr) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr = true; } \
-        hipLaunchKernelGGL((k_conv1d_pair_chain<KS_, R_>), dim3(batch * h), dim3(256 * KS_), lds, st, a); }
+        static size_t cap = 0;   /* (the kernel also holds CHAIN_STATIC_LDS bytes of static LDS: the dynamic part may claim 160 KB minus that) */ \
+        if (!cap) { \
+            cap = (160 * 1024 - CHAIN_STATIC_LDS) / 16 * 16; \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) { \
+                (void)hipGetLastError(); \
+                cap = 152 * 1024; \
+                LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap)); \
+            } \
+            if (getenv("LAV_PAIR_CHAIN_DEBUG")) fprintf(stderr, "[pair chain] dynamic LDS cap %zu bytes, this launch %zu\n", cap, std::min(cap, lav::lds_claim(lds, CHAIN_STATIC_LDS))); \
+        } \
+        hipLaunchKernelGGL((k_conv1d_pair_chain<KS_, R_>), dim3(batch * h), dim3(256 * KS_), std::min(cap, lav::lds_claim(lds, CHAIN_STATIC_LDS)), st, a); }
     static const bool want_trace = getenv("LAV_PAIR_CHAIN_TRACE") != nullptr;
     static long long *d_trace = nullptr;
     a.trace = nullptr;
@@ -1047,7 +1056,7 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
         a.trace = d_trace;
         static bool attr_t = false;
         if (!attr_t) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_t = true; }
-        hipLaunchKernelGGL((k_conv1d_pair_chain<2, 2, true>), dim3(batch * h), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_conv1d_pair_chain<2, 2, true>), dim3(batch * h), dim3(512), lds, st, a);   // (trace build: exact size)
         static int runs = 0;
         if (++runs % 10 == 0 && batch * h <= 512) {
             std::vector<long long> hst((size_t)batch * h * 8);

@@ -51,6 +51,19 @@ if HOG.startswith("synth"):
     def hog(x):
         rc = hoglib.hog_launch(810, 153600, mode, 2000 if mode == 2 else 4000, x.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
+elif HOG in ("erfnet", "brake"):   # the frame's own camera networks as neighbours: ERFNet (persistent pair runs, direct / split convolutions, deconvolutions) or the brake net (fp32 tiled stems, direct + split ResNet layers, attention pooling)
+    from lav_amd import synth
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    if HOG == "erfnet":
+        net = RGBSegmentationModel([4, 6, 7, 10]); net.load_state_dict(synth.seeded_state_dict(net, prefix="seg."))
+        net = net.eval().to(dev)
+        hog_x = torch.rand(3, 3, 288, 256, device=dev) * 255
+        hog = lambda x: net(x)
+    else:
+        net = RGBBrakePredictionModel([4, 6, 7, 10]); net.load_state_dict(synth.seeded_state_dict(net, prefix="bra."))
+        net = net.eval().to(dev)
+        hog_x = (torch.rand(1, 3, 288, 768, device=dev) * 255, torch.rand(1, 3, 192, 480, device=dev) * 255)
+        hog = lambda x: net(*x)
 elif HOG == "head":
     hog_w = torch.randn(256, 384, 3, 3) / (384 * 9) ** 0.5
     hog = ConvLayer(hog_w, stride=1, padding=(1, 1), relu_post=True, precision=_lib.CONV_BF16X6, device=dev)
