@@ -64,6 +64,21 @@ elif HOG in ("erfnet", "brake"):   # the frame's own camera networks as neighbou
         net = net.eval().to(dev)
         hog_x = (torch.rand(1, 3, 288, 768, device=dev) * 255, torch.rand(1, 3, 192, 480, device=dev) * 255)
         hog = lambda x: net(*x)
+elif HOG in ("tiled", "erfup", "erfdown", "pool"):   # single ERFNet layers: first convolution (fp32 tiled kernel, LDS DMA), up- / down-convolution (direct kernel)
+    if HOG == "tiled":
+        hog = ConvLayer(torch.randn(13, 3, 3, 3) * 0.2, stride=2, padding=(1, 1), relu_post=True, device=dev)
+        hog_x = torch.randn(3, 3, 288, 256, device=dev)
+    elif HOG == "erfup":
+        hog = ConvLayer(torch.randn(128, 64, 3, 3) * 0.03, stride=2, padding=(1, 1), transposed=True, output_padding=1, relu_post=True, device=dev)
+        hog_x = torch.randn(3, 128, 36, 32, device=dev)
+    elif HOG == "erfdown":
+        hog = ConvLayer(torch.randn(64, 64, 3, 3) * 0.04, stride=2, padding=(1, 1), relu_post=True, device=dev)
+        hog_x = torch.randn(3, 64, 72, 64, device=dev)
+    else:
+        hog_x = torch.randn(3, 16, 144, 128, device=dev)
+        hog = lambda x: ops.maxpool3x3s2(x)
+    _hog1 = hog
+    hog = lambda x: [_hog1(x) for _ in range(8)]
 elif HOG == "head":
     hog_w = torch.randn(256, 384, 3, 3) / (384 * 9) ** 0.5
     hog = ConvLayer(hog_w, stride=1, padding=(1, 1), relu_post=True, precision=_lib.CONV_BF16X6, device=dev)
