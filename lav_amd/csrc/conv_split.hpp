@@ -663,7 +663,10 @@ int launch_split_g(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
     // anyway).  Round 4 found that a kernel whose waves share SIMDs with this one's - matrix instructions AND heavy LDS traffic -
     // can have its own LDS accesses corrupted (common.hpp, profiles/r04_plan_stress.txt: the persistent plan kernel beside the 7x7
     // stems); with no LDS left on the CU, no kernel that uses LDS can become that neighbour.  LAV_SPLIT_LDS_EXCLUSIVE=0: as needed.
-    static const bool exclusive = [] { const char *e = getenv("LAV_SPLIT_LDS_EXCLUSIVE"); return !e || atoi(e) != 0; }();
+    static const bool exclusive = [] {
+        const char *e = getenv("LAV_SPLIT_LDS_EXCLUSIVE"), *g = getenv("LAV_LDS_EXCLUSIVE");   // (the second one also switches lav::lds_claim off)
+        return (!e || atoi(e) != 0) && (!g || atoi(g) != 0);
+    }();
     hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT, G, TP>), grid, dim3(512), exclusive ? (size_t)160 * 1024 : lds, st, sa);
     return LAV_OK;
 }
