@@ -26,4 +26,12 @@ with torch.no_grad():
         feats = lm.backbone(canvas)
         lm.heads(feats)
         seg(imgs)
+# round 4: the 7x7 stride-2 crop stem (384 -> 64 on 96x96 crops) at 1 and 7 crops: the split kernel's tap-pair mode
+from lav_amd import _lib  # noqa: E402
+from lav_amd.ops import ConvLayer  # noqa: E402
+stem = ConvLayer(torch.randn(64, 384, 7, 7) / (384 * 49) ** 0.5, stride=2, padding=(3, 3), relu_post=True, precision=_lib.CONV_BF16X6, device=dev)
+for b in (1, 7):
+    x = torch.randn(b, 384, 96, 96, device=dev)
+    for _ in range(4):
+        stem(x)
 torch.cuda.synchronize()
