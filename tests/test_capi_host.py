@@ -295,6 +295,30 @@ def test_split_plan_takes_the_matrix_bound_layers_only():
     assert n32 == 64 * 64 * 9 and n16 == n32 + 64 * 64 * 9 * 3 // 2
 
 
+def test_crop_stems_are_planned_in_tap_pair_mode():
+    """The 7x7 stride-2 stems of the crop embedders (384 input channels, 96x96 crops) run on the split kernel's tap-pair mode
+    (round 4: info[7] = tap group + 100): 16x8-pixel tiles of 1x2 wave tiles, 150 KB of LDS, split-K so that the launch fills the
+    chip at 1 / 4 / 7 crops, at the others branch's capacity of 15 and at a training batch; the brake net's 3-channel stems
+    (cin % 16 != 0) and 3x3 layers never do, and LAV_CONV_PRECISION / precision f32 keeps the stems on the fp32 tiled kernel."""
+    lib = _lib.load()
+    info = (C.c_int * 9)()
+
+    def plan(B, cin, cout, k, s, p, H, W, precision=_lib.CONV_BF16X6):
+        d = Conv(B, cin, 0, cin, H, W, cout, k, k, s, p, p, 1, 1, 0, 0, cout, 0, 0, 0, 0, 0, 0.0, precision)
+        assert lib.lav_conv_tile_info(C.byref(d), info) == 0, lib.lav_last_error().decode()
+        return list(info)
+
+    for B in (1, 4, 7, 15, 32):
+        i = plan(B, 384, 64, 7, 2, 3, 96, 96)
+        assert i[0] == -1 and i[7] >= 100, f"batch {B}: {i}"
+        assert (i[1], i[2], i[3]) == (1, 2, 4) and (i[4], i[8]) == (16, 8) and i[5] <= 160 * 1024 and i[7] % 100 == 4
+        wgs = 18 * B * i[6]
+        assert B >= 15 or 200 <= wgs <= 256, f"batch {B}: split-K {i[6]} gives {wgs} workgroups"
+    assert plan(1, 3, 64, 7, 2, 3, 288, 768)[7] < 100          # brake stem: 3 input channels
+    assert plan(1, 384, 256, 3, 1, 1, 160, 160)[7] < 100       # 3x3 layers keep 16-channel chunks
+    assert plan(7, 384, 64, 7, 2, 3, 96, 96, precision=_lib.CONV_F32)[0] >= 1
+
+
 def test_grouped_deconv_rejects_unsupported_geometry_before_any_launch():
     lib = _lib.load()
     outs = (C.c_int * 2)(3, 9)
