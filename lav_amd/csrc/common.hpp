@@ -44,6 +44,22 @@ __device__ __forceinline__ void lds_store_fence() { asm volatile("" ::: "memory"
 __device__ __forceinline__ void lds_commit() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <class T>
 __device__ __forceinline__ void lds_keep(T &v) { asm volatile("" : "+v"(v)); }
+// What DOES make a victim immune (measured at the end of round 4, profiles/r04_plan_stress.txt): every LDS access issued together
+// with its wait in ONE asm block, one access in flight at a time.  With -DLAV_PLAN_LDS_SYNC=1 the persistent plan kernel is
+// bit-exact beside the synthetic matrix + LDS neighbour (0 of 400 launches, both polling schemes) and beside the real stem kernel
+// with the LDS claims switched OFF (0 of 200; 126 of 150 wrong without), at +60 us per plan (frame 420 -> 410 frames/s).  The same
+// accesses batched - several ds_read / ds_write in one asm block, all operands pinned, ONE wait - fail again (68 of 100): it is
+// having more than one LDS operation of a wave in flight that goes wrong beside such neighbours, not registers being rewritten.
+__device__ __forceinline__ float lds_read_sync(const float *p) {
+    float v;
+    const unsigned a = (unsigned)(size_t)p;   // (low half of the generic address = the LDS offset)
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write_sync(float *p, float v) {
+    const unsigned a = (unsigned)(size_t)p;
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
+}
 
 // Host side of the same finding: the kernels that combine bf16 matrix instructions with heavy LDS traffic (split-operand
 // convolutions, the ERFNet pair kernels) corrupt LDS-dependent results of kernels whose waves share their CUs (measured with the
