@@ -66,11 +66,15 @@ __device__ __forceinline__ void lds_write_sync(float *p, float v) {
 // persistent plan kernel as the victim: wrong in 171 of 300 launches beside the brake net's split convolutions, 3-10 of 300 beside
 // ERFNet, 0 of 300 once these kernels leave no LDS on their CUs; the fp32 tiled / direct kernels are harmless).  They therefore
 // CLAIM the LDS of their CU: all of it when one workgroup runs per CU, half each when two do.  LAV_LDS_EXCLUSIVE=0: exact sizes.
-inline size_t lds_claim(size_t need, size_t static_bytes = 0) {
-    static const bool on = [] { const char *e = getenv("LAV_LDS_EXCLUSIVE"); return !e || atoi(e) != 0; }();
+inline size_t lds_claim(size_t need, size_t static_bytes = 0, bool needs_two_per_cu = false) {
+    // LAV_LDS_EXCLUSIVE: 1 (default) as above | 0 exact sizes | 2 the whole CU also for the kernels that could run two per CU (a CU that
+    // holds only ONE of their workgroups - grids below 2 x 256, launch tails - still has half its LDS free for a victim: the "rare
+    // ERFNet aggressor" of profiles/r04_plan_stress.txt; tools/coresidency.py measures all three settings).  needs_two_per_cu: a
+    // persistent launch whose workgroups must all be resident at once and outnumber the CUs keeps the half claim in every mode.
+    static const int mode = [] { const char *e = getenv("LAV_LDS_EXCLUSIVE"); return e ? atoi(e) : 1; }();
     const size_t total = 160 * 1024;
-    if (!on) return need;
-    if (need + static_bytes > total / 2) return (total - static_bytes) / 16 * 16;       // one workgroup per CU
+    if (mode == 0) return need;
+    if (need + static_bytes > total / 2 || (mode == 2 && !needs_two_per_cu && need + static_bytes > total / 3)) return (total - static_bytes) / 16 * 16;   // one workgroup per CU
     if (need + static_bytes > total / 3) return (total / 2 - static_bytes) / 16 * 16;   // two
     return need;                                                                          // three or more: left alone
 }

@@ -631,8 +631,16 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                     const int fd = yd < H ? __hip_atomic_load(a.flags + n * H + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
                     ok = fu >= p && fd >= p;
                     if (!ok) {
-                        if (++spins > a.spin_limit) {   // never hang the device: the result is void, the status word says so
-                            if (lane == 0) { s_abort = 1; atomicAdd(a.sticky, 1); }
+                        // never hang the device: a row that gives up raises the launch's abort word (sticky[2], cleared by k_zero_ints), every
+                        // other row sees it within 64 polls and leaves too, and k_chain_poison - next on the stream - voids the run's output
+                        ++spins;
+                        const bool timed_out = spins > a.spin_limit;
+                        const bool peer_gone = !timed_out && (spins & 63) == 0 && __hip_atomic_load(a.sticky + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (timed_out || peer_gone) {
+                            if (lane == 0) {
+                                s_abort = 1;
+                                if (timed_out) { atomicAdd(a.sticky, 1); __hip_atomic_store(a.sticky + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            }
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -640,6 +648,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                 }
             }
             __syncthreads();
+            if (*(volatile int *)&s_abort) return;   // (uniform after the barrier; the run's output is void)
             CH_MARK(1);
             stage_rows(a.out[p - 1], dA, std::false_type{}, true);
             CH_MARK(2);
@@ -971,7 +980,14 @@ namespace {
 __global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *launches) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0;
-    if (i == 0) atomicAdd(launches, 1);
+    if (i == 0) { atomicAdd(launches, 1); launches[1] = 0; }   // launches = sticky + 1; sticky[2] = this launch's abort word
+}
+// Behind every persistent run: a run in which a row gave up is VOID - its last output becomes NaN as a whole, so that a segmentation
+// computed on stale neighbour rows can never pass for one (it propagates through painting and the BEV network to waypoints the
+// agent refuses, as the plan kernel's poison does; the frame's non-finite check counts it).
+__global__ __launch_bounds__(256) void k_chain_poison(const int *__restrict__ abort_word, float *__restrict__ out, long n) {
+    if (*abort_word == 0) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = __uint_as_float(0x7fc00000u);
 }
 }  // namespace
 
@@ -1045,9 +1061,9 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
                 cap = 152 * 1024; \
                 LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap)); \
             } \
-            if (getenv("LAV_PAIR_CHAIN_DEBUG")) fprintf(stderr, "[pair chain] dynamic LDS cap %zu bytes, this launch %zu\n", cap, std::min(cap, lav::lds_claim(lds, CHAIN_STATIC_LDS))); \
+            if (getenv("LAV_PAIR_CHAIN_DEBUG")) fprintf(stderr, "[pair chain] dynamic LDS cap %zu bytes, this launch %zu\n", cap, std::min(cap, lav::lds_claim(lds, CHAIN_STATIC_LDS, batch * h > cus))); \
         } \
-        hipLaunchKernelGGL((k_conv1d_pair_chain<KS_, R_>), dim3(batch * h), dim3(256 * KS_), std::min(cap, lav::lds_claim(lds, CHAIN_STATIC_LDS)), st, a); }
+        hipLaunchKernelGGL((k_conv1d_pair_chain<KS_, R_>), dim3(batch * h), dim3(256 * KS_), std::min(cap, lav::lds_claim(lds, CHAIN_STATIC_LDS, batch * h > cus)), st, a); }
     static const bool want_trace = getenv("LAV_PAIR_CHAIN_TRACE") != nullptr;
     static long long *d_trace = nullptr;
     a.trace = nullptr;
@@ -1072,6 +1088,7 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
     LAV_CHAIN_CASE(1, 1) LAV_CHAIN_CASE(1, 2) LAV_CHAIN_CASE(2, 1) LAV_CHAIN_CASE(2, 2)
     }
 #undef LAV_CHAIN_CASE
+    hipLaunchKernelGGL(k_chain_poison, dim3(64), dim3(256), 0, st, a.sticky + 2, a.out[npairs - 1], (long)batch * channels * h * w);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

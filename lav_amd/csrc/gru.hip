@@ -621,6 +621,246 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
 }
 #undef LDSR
 #undef LDSW
+
+// ------------------------------------------------------------------------------------------------- plan, persistent, LDS-free (round 5)
+// The default since round 5.  One WAVE per workgroup, H/8 workgroups: the wave holds all three gates of its 8 hidden units (24 rows of
+// W_hh + the two rows of Linear(H->2): 208 registers per lane), so that a unit's r / z / n pre-activations meet inside the wave and
+// nothing of the recurrence ever goes through LDS: no DS instruction (the cross-lane sums are v_permlane32_swap / v_permlane16_swap /
+// DPP adds, not ds_bpermute), no barrier, no LDS allocation - the victim surface of DESIGN 4.4c (LDS-dependent results going wrong beside
+// matrix + LDS heavy neighbours) does not exist in this kernel, and tests/test_capi_host.py disassembles the library to keep it so.
+// The waypoints of the previous iteration live in registers (lane t holds waypoint t; v_readlane feeds the gate inputs).
+// Same arithmetic as k_plan_step / k_plan_persistent: per lane an 8-term fmaf chain over k = lane + 64 i, then the xor butterfly
+// 32, 16, 8, 4, 2, 1 - the swaps + adds below ARE that butterfly (fp addition is commutative, both partners of a pair end up with the
+// same bits), 26 sums folded 32 -> 16 -> 8 registers on the way down instead of 26 x 6 exchanges: bit-identical results.
+// Polling traffic per workgroup = the quarter-poll scheme's (every granule is read once per round by one wave).
+struct Swap2 { float a, b; };
+__device__ __forceinline__ float fold32(float x, float y) {   // lanes 0-31: x[l] + x[l+32]; lanes 32-63: y[l-32] + y[l]  (or the halves exchanged)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float x, float y) {   // even rows of 16 lanes: x's row pair summed; odd rows: y's
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_allsum(float x) {   // xor butterfly 8, 4, 2, 1 inside each row of 16 lanes (rotations of a period-2d value)
+    x = dpp_add<0x128>(x);   // row_ror:8
+    x = dpp_add<0x124>(x);   // row_ror:4
+    x = dpp_add<0x122>(x);   // row_ror:2
+    x = dpp_add<0x121>(x);   // row_ror:1
+    return x;
+}
+// p[q][j]: this lane's partial sum of slot (quarter q, j): j < 6 -> unit 2q + j / 3, gate j % 3; (0, 6) and (0, 7): the two waypoint rows.
+// Returns in z[j] the complete sum of slot (Q, j), where Q is the quarter of this lane's row of 16 lanes (kernel entry calibrates Q).
+__device__ __forceinline__ void plan_fold(const float (&p)[4][6], float s0, float s1, float (&z)[8]) {
+    float a0[8], a1[8];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { a0[j] = fold32(p[0][j], p[2][j]); a1[j] = fold32(p[1][j], p[3][j]); }
+    a0[6] = fold32(s0, 0.f);
+    a0[7] = fold32(s1, 0.f);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) z[j] = row_allsum(fold16(a0[j], a1[j]));
+    z[6] = row_allsum(fold16(a0[6], 0.f));
+    z[7] = row_allsum(fold16(a0[7], 0.f));
+}
+
+template <int RC, int NKT>   // NKT: H / 64 known at compile time (8 for the uniplanner's H = 512: every load unconditional), 0: any H
+__global__ __launch_bounds__(64) void k_plan_wave(PlanArgs a, unsigned long long *__restrict__ gran, int *__restrict__ status, long long spin_limit) {
+    const int H = NKT ? 64 * NKT : a.H, T = a.T, R = a.R;
+    const int lane = threadIdx.x;
+    const int nk = NKT ? NKT : H / 64;
+    const unsigned long long t_entry = wall_clock64();
+    if (lane == 0) atomicAdd(status + 1, 1);
+    const int j0 = blockIdx.x * PLAN_UNITS;
+    // which quarter's sums this lane's row ends up with, and where quarter 0's (the waypoint sums) can be read: folded once over
+    // known values instead of trusting a reading of the swap instructions' lane polarity
+    int Q, wp_lane;
+    {
+        float p[4][6], z[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) p[q][j] = (float)q;
+        plan_fold(p, 0.f, 0.f, z);
+        Q = (int)(z[0] * (1.f / 64.f));
+        wp_lane = (int)__builtin_ctzll(__ballot(Q == 0));
+    }
+    const int my_u = 2 * Q + (lane & 1);                        // the unit whose gates this lane evaluates (16 lanes per quarter: 8 copies each)
+    const bool odd = (lane & 1) != 0, publisher = (lane & 15) < 2;
+    float w[4][6][PLAN_MAXK], m0[PLAN_MAXK], m1[PLAN_MAXK];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float *wr = a.w_hh + (long)((j % 3) * H + j0 + 2 * q + j / 3) * H;
+#pragma unroll
+            for (int i = 0; i < PLAN_MAXK; ++i) w[q][j][i] = i < nk ? wr[lane + 64 * i] : 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < PLAN_MAXK; ++i) {
+        m0[i] = i < nk ? a.mlp_w[lane + 64 * i] : 0.f;
+        m1[i] = i < nk ? a.mlp_w[H + lane + 64 * i] : 0.f;
+    }
+    float wih[3][4], bih[3], bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const int row = g * H + j0 + my_u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wih[g][k] = a.w_ih[row * 4 + k];
+        bih[g] = a.b_ih[row];
+        bh[g] = a.b_hh[row];
+    }
+    const float mb0 = a.mlp_b[0], mb1 = a.mlp_b[1];
+    // per state row: target point in crop units (uniform), the previous iteration's waypoints (lane t = waypoint t), this unit's state
+    float u0[RC], u1[RC], locp0[RC], locp1[RC], locn0[RC], locn1[RC], hself[RC], hinit[RC];
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+        int b, ci, c;
+        row_decode(a, min(rr, R - 1), b, ci, c);
+        u0[rr] = a.nxp[b * 2 + 0] * a.ppm / a.crop * 2.f - 1.f;
+        u1[rr] = a.nxp[b * 2 + 1] * a.ppm / a.crop * 2.f - 1.f;
+        const float *src = a.cast_locs + (((long)b * a.num_cmds + c) * T + min(lane, T - 1)) * 2;   // iteration 0 refines the cast waypoints
+        locp0[rr] = src[0];
+        locp1[rr] = src[1];
+        locn0[rr] = locn1[rr] = 0.f;
+        hinit[rr] = a.embd[(long)b * H + j0 + my_u];
+        hself[rr] = 0.f;
+    }
+
+    for (int it = 0; it < a.iters; ++it) {
+        float run0[RC], run1[RC];
+#pragma unroll
+        for (int rr = 0; rr < RC; ++rr) run0[rr] = run1[rr] = 0.f;
+        for (int t = 0; t <= T; ++t) {   // t == T only gathers h_{T-1} to finish the iteration's waypoints
+            const unsigned epoch = (unsigned)(it * T + t);   // the state published by the previous step carries this tag
+            float hv[RC][PLAN_MAXK];
+            if (t == 0) {
+#pragma unroll
+                for (int rr = 0; rr < RC; ++rr) {
+                    int b, ci, c;
+                    row_decode(a, min(rr, R - 1), b, ci, c);
+#pragma unroll
+                    for (int i = 0; i < PLAN_MAXK; ++i) hv[rr][i] = i < nk ? a.embd[(long)b * H + lane + 64 * i] : 0.f;
+                }
+            } else {
+                const unsigned long long *g = gran + (long)((epoch - 1) & 1) * R * H;
+                long long spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int rr = 0; rr < RC; ++rr) {
+                        if (rr < R) {
+#pragma unroll
+                            for (int i = 0; i < PLAN_MAXK; ++i) {
+                                if (i < nk) {
+                                    const unsigned long long x = __hip_atomic_load(g + (long)rr * H + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    ok = ok && (unsigned)(x >> 32) == epoch;
+                                    hv[rr][i] = __uint_as_float((unsigned)x);
+                                } else {
+                                    hv[rr][i] = 0.f;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < PLAN_MAXK; ++i) hv[rr][i] = 0.f;
+                        }
+                    }
+                    const unsigned long long bad = __ballot(!ok);
+                    if (bad == 0) break;
+                    ++spins;
+                    // give up: never hang the device (k_plan_poison, next on the stream, voids the output).  A wave also leaves when another
+                    // one has given up (status word, looked at every 64th round), so an aborted launch ends within microseconds.
+                    const bool peer_gone = (spins & 63) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    if (spins > spin_limit || peer_gone) {
+                        if (!peer_gone && lane == (int)__builtin_ctzll(bad)) {
+                            atomicExch(status, 1);
+                            if (atomicCAS(status + 2, 0, (int)blockIdx.x + 1) == 0) {   // the first wave of the grid to give up
+                                int bi = 0;
+                                unsigned bt = 0;
+                                for (int rr = R - 1; rr >= 0; --rr)
+                                    for (int i = nk - 1; i >= 0; --i) {
+                                        const unsigned long long x = __hip_atomic_load(g + (long)rr * H + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if ((unsigned)(x >> 32) != epoch) { bi = rr * H + lane + 64 * i; bt = (unsigned)(x >> 32); }
+                                    }
+                                status[3] = 0; status[4] = (int)epoch; status[5] = (int)min(spins, 0x7fffffffll);
+                                status[6] = bi; status[7] = (int)bt;
+                                status[8] = (int)((wall_clock64() - t_entry) / 100);   // 100 MHz constant clock
+                            }
+                        }
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < RC; ++rr) {
+                if (rr < R) {   // uniform
+                    float p[4][6], s0 = 0.f, s1 = 0.f, z[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int i = 0; i < PLAN_MAXK; ++i) acc = fmaf(w[q][j][i], hv[rr][i], acc);
+                            p[q][j] = acc;
+                        }
+#pragma unroll
+                    for (int i = 0; i < PLAN_MAXK; ++i) {
+                        s0 = fmaf(m0[i], hv[rr][i], s0);
+                        s1 = fmaf(m1[i], hv[rr][i], s1);
+                    }
+                    plan_fold(p, s0, s1, z);
+                    if (t > 0) {   // waypoint t-1 of this iteration from h_{t-1} (every workgroup needs it as next iteration's input)
+                        const float w0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z[6]), wp_lane));
+                        const float w1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z[7]), wp_lane));
+                        run0[rr] += w0 + mb0;
+                        run1[rr] += w1 + mb1;
+                        const float o0 = run0[rr] + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(locp0[rr]), t - 1));
+                        const float o1 = run1[rr] + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(locp1[rr]), t - 1));
+                        locn0[rr] = lane == t - 1 ? o0 : locn0[rr];
+                        locn1[rr] = lane == t - 1 ? o1 : locn1[rr];
+                        if (blockIdx.x == 0 && lane == 0) {
+                            int b, ci, c;
+                            row_decode(a, rr, b, ci, c);
+                            float *o = a.out + ((((long)b * a.iters + it) * a.NC + ci) * T + (t - 1)) * 2;
+                            o[0] = o0;
+                            o[1] = o1;
+                        }
+                    }
+                    if (t < T) {
+                        if (t == 0) hself[rr] = hinit[rr];
+                        const float uu[4] = {u0[rr], u1[rr], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(locp0[rr]), t)),
+                                             __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(locp1[rr]), t))};
+                        float gi[3], gh[3];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc = fmaf(wih[g][k], uu[k], acc);
+                            gi[g] = acc + bih[g];
+                            gh[g] = (odd ? z[3 + g] : z[g]) + bh[g];
+                        }
+                        const float rg = sigmoidf_(gi[0] + gh[0]);
+                        const float zg = sigmoidf_(gi[1] + gh[1]);
+                        const float ng = tanhf(gi[2] + rg * gh[2]);
+                        hself[rr] = (1.f - zg) * ng + zg * hself[rr];
+                        if (publisher) {
+                            const unsigned long long x = ((unsigned long long)(epoch + 1) << 32) | __float_as_uint(hself[rr]);
+                            __hip_atomic_store(gran + (long)(epoch & 1) * R * H + (long)rr * H + j0 + my_u, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RC; ++rr) { locp0[rr] = locn0[rr]; locp1[rr] = locn1[rr]; }
+    }
+    if (lane == 0) atomicAdd(status + 9, 1);
+}
 }  // namespace
 
 extern "C" size_t lav_gru_cast_workspace_bytes(int, int, int, int, int) { return 0; }
@@ -720,12 +960,21 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
         // (conv_split.hpp: launch_split_g), so no kernel that uses LDS - this one does - shares a CU with it; beside that stem kernel both
         // variants are bit-identical to the step path in 300 of 300 launches.  tests/test_gpu_paint_gru.py runs that comparison, and
         // bench.py re-computes the plans of frames after its timed ones on the step path (`plan_vs_step_path_max_abs`).
+        // Default: k_plan_wave (round 5, no LDS at all).  LAV_PLAN_IMPL=lds: rounds 2-4's four-wave kernel (quarter poll, LAV_PLAN_POLL=all:
+        // every wave polls everything) - kept as the known victim of tools/coresidency.py, not used by the frame.
         static const char *poll_env = getenv("LAV_PLAN_POLL");
         const bool quarter = H % 256 == 0 && !(poll_env && poll_env[0] == 'a');
+        if (impl && impl[0] == 'l') {
 #define LAV_PLAN_CASE(P_, RC_) hipLaunchKernelGGL((k_plan_persistent<P_, RC_>), dim3(H / PLAN_UNITS), dim3(256), 0, st, a, gran, status, spin_limit)
-        if (a.R == 1) { if (quarter) LAV_PLAN_CASE(1, 1); else LAV_PLAN_CASE(0, 1); }
-        else { if (quarter) LAV_PLAN_CASE(1, PLAN_RC); else LAV_PLAN_CASE(0, PLAN_RC); }
+            if (a.R == 1) { if (quarter) LAV_PLAN_CASE(1, 1); else LAV_PLAN_CASE(0, 1); }
+            else { if (quarter) LAV_PLAN_CASE(1, PLAN_RC); else LAV_PLAN_CASE(0, PLAN_RC); }
 #undef LAV_PLAN_CASE
+        } else {
+#define LAV_PLAN_CASE(RC_, NK_) hipLaunchKernelGGL((k_plan_wave<RC_, NK_>), dim3(H / PLAN_UNITS), dim3(64), 0, st, a, gran, status, spin_limit)
+            if (a.R == 1) { if (H == 512) LAV_PLAN_CASE(1, 8); else LAV_PLAN_CASE(1, 0); }
+            else { if (H == 512) LAV_PLAN_CASE(PLAN_RC, 8); else LAV_PLAN_CASE(PLAN_RC, 0); }
+#undef LAV_PLAN_CASE
+        }
         const long n_out = (long)a.B * a.iters * a.NC * T * 2;
         hipLaunchKernelGGL(k_plan_poison, dim3((unsigned)std::min<long>((n_out + 255) / 256, 64)), dim3(256), 0, st, status, sticky, a.out, n_out);
         timer_end(tok, st);

@@ -54,8 +54,6 @@ class _Engine(nn.Module):
         eng = self.__dict__.get("_eng")
         if eng is None or eng.get("device") != device:
             return None
-        if "tensor_ids" not in eng:
-            eng["tensor_ids"] = self._tensor_ids()
         if self.__dict__.get("_stale"):
             if eng["tensor_ids"] != self._tensor_ids():
                 self._drop()
@@ -134,6 +132,7 @@ class ConvBackbone(_Engine):
                                  out_c_total=self.out_channels, out_c_offset=off, device=device))
             off += ct.weight.shape[1]
         eng = dict(device=device, s1=stage(self.conv1), s2=stage(self.conv2), s3=stage(self.conv3), ups=ups)
+        eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use
         object.__setattr__(self, "_eng", eng)
         return eng
 
@@ -196,6 +195,7 @@ class Head(_Engine):
             eng = dict(device=x.device,
                        conv=ConvLayer(conv.weight, padding=1, bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True, device=x.device),
                        deconv=self.deconv_layer(x.device))
+            eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use
             object.__setattr__(self, "_eng", eng)
         return self._eng["deconv"](self._eng["conv"](x))
 
@@ -236,6 +236,7 @@ class LiDARModel(_Engine):
             eng[names] = dict(outs=outs,
                               conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=device),
                               deconv=GroupedDeconv(cts, sigmoid_from=sum(outs[:-1]) if sig[-1] else -1, device=device))
+            eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use
             object.__setattr__(self, "_eng", eng)
         return self._eng[names]
 

@@ -624,7 +624,9 @@ class Conv1dPairChain:
         if bufs is None:
             bufs = self._bufs[key] = [torch.empty_like(x) for _ in range(n - 1)]
         out = bufs + [torch.empty_like(x)]
-        ws = _workspace("pair_chain", lib.lav_conv1d_pair_chain_workspace_bytes(B, h), x.device)
+        # sized ONCE for the largest run the chip can hold (2 rows per CU): the buffer never grows, so the sticky time-out / launch
+        # counters of already captured graphs stay the ones pair_chain_status() reads
+        ws = _workspace("pair_chain", max(lib.lav_conv1d_pair_chain_workspace_bytes(B, h), 256 + 4 * 2 * _cu_count(x.device)), x.device)
         ia = lambda vals: (C.c_int * n)(*vals)
         pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
         ps = self.pairs

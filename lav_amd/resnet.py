@@ -59,6 +59,7 @@ class ResNet(_Engine):
                 blocks.append(dict(c1=cl(blk.conv1, blk.bn1, relu_post=True), c2=cl(blk.conv2, blk.bn2, relu_post=True),
                                    down=None if blk.downsample is None else cl(blk.downsample[0], blk.downsample[1])))
         eng = dict(device=device, stem=cl(self.conv1, self.bn1, relu_post=True), blocks=blocks)
+        eng["tensor_ids"] = self._tensor_ids()   # (recorded where the engine is built: lidar.py:_Engine._fresh)
         object.__setattr__(self, "_eng", eng)
         return eng
 

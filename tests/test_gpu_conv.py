@@ -352,11 +352,13 @@ def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):
     torch.cuda.synchronize()
     t0, n0 = ops.pair_chain_status(DEV)
     monkeypatch.setenv("LAV_CHAIN_SPIN_LIMIT", "0")
-    chain(x)
+    void = chain(x)
     torch.cuda.synchronize()          # (returns: nobody waits forever)
     monkeypatch.delenv("LAV_CHAIN_SPIN_LIMIT")
     t1, n1 = ops.pair_chain_status(DEV)
     assert n1 == n0 + 1 and t1 > t0, "108 rows never finish a pair at the same instant: some workgroup must have given up"
+    # round 5: a run in which a row gave up is poisoned as a whole - rows computed on stale neighbours never pass for a result
+    assert torch.isnan(void).all(), "an aborted persistent run must return NaN, not a partly stale map"
     back = chain(x)
     torch.cuda.synchronize()
     t2, n2 = ops.pair_chain_status(DEV)

@@ -52,10 +52,11 @@ def test_paint_large_and_edge(models):
     assert empty.shape == (0, 8)
 
 
-@pytest.mark.parametrize("impl", ["persistent", "steps"])
+@pytest.mark.parametrize("impl", ["persistent", "lds", "steps"])
 def test_gru_cast_plan_vs_reference_golden(golden, models, impl, monkeypatch):
-    """plan: one persistent launch with granule all-gathers (default, used when <= 6 state rows) and the
-    step-per-launch variant (LAV_PLAN_IMPL=steps, any batch)."""
+    """plan: one persistent launch with granule all-gathers (default, used when <= 6 state rows: round 5's one-wave-per-workgroup
+    kernel without LDS; LAV_PLAN_IMPL=lds: rounds 2-4's four-wave kernel) and the step-per-launch variant (LAV_PLAN_IMPL=steps,
+    any batch)."""
     monkeypatch.setenv("LAV_PLAN_IMPL", impl)
     g = golden["planner"]
     _, up = models

@@ -45,6 +45,6 @@ for _ in range(100):
     g.replay()
 torch.cuda.synchronize()
 plan_ms = (time.perf_counter() - t0) / 100 * 1e3
-print(f"LAV_PLAN_POLL={os.environ.get('LAV_PLAN_POLL', 'default')}: plan launch {plan_ms:.3f} ms alone, frame {frame_ms:.3f} ms = {1e3 / frame_ms:.1f} frames/s, "
+print(f"LAV_PLAN_IMPL={os.environ.get('LAV_PLAN_IMPL', 'default (wave)')} LAV_PLAN_POLL={os.environ.get('LAV_PLAN_POLL', 'default')}: plan launch {plan_ms:.3f} ms alone, frame {frame_ms:.3f} ms = {1e3 / frame_ms:.1f} frames/s, "
       f"persistent vs steps |diff| {err:.2e}, plan_aborts {h['plan_aborts']}/{h['plan_launches']}, nonfinite {h['nonfinite_outputs']}, "
       f"finite plan {bool(torch.isfinite(out['ego_plan_locs']).all())}")
