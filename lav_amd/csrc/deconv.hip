@@ -137,8 +137,156 @@ __global__ __launch_bounds__(256) void k_deconv_grouped(DeconvArgs a) {
     }
 }
 
+// Round 5: the 3x3 stride-2 case (the four head tails: 26 MB in, 3.7 MB out) as a STAGED kernel.  The gathering kernel above is a
+// chain of L2 round trips at 1.6 waves per SIMD (47 us for the heads = 0.08 of the HBM roof), its weights arrive through the scalar
+// cache behind a full lgkmcnt(0) wait per batch.  Here a workgroup owns a tile of 8 x 32 input-grid positions of one group: the
+// (8 + 1) x (32 + 1) input pixels its positions read are streamed through LDS 16 channels at a time with coalesced 16-byte row loads
+// (unconditional, from clamped addresses; the next chunk's loads are in flight while this chunk is multiplied), the group's weights
+// sit in LDS as one 16-byte aligned row per channel (read as broadcasts), a thread reads its four pixels per channel from LDS and
+// multiplies two output channels per instruction (v_pk_fma_f32).  Same products in the same order as the gathering kernel (channels
+// ascending, taps ascending inside a channel): bit-identical results (tests/test_gpu_conv.py).
+constexpr int DT_Y = 8, DT_X = 32, DT_CH = 16, DT_RS = DT_X + 4, DT_ROWS = DT_Y + 1;   // row: [3] = left halo, [4, 36) = the tile's columns
+constexpr int DT_MAXC = 64;                                                            // channels per group the weight rows are sized for
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_deconv_tile(DeconvArgs a, int tiles_y) {
+    constexpr int K = 3, S = 2, NW = (K * K * NC + 3) / 4 * 4;   // floats per weight row [tap][NC], padded to 16 bytes
+    __shared__ __attribute__((aligned(16))) float s_in[2][DT_CH][DT_ROWS][DT_RS];
+    __shared__ __attribute__((aligned(16))) float s_w[DT_MAXC][NW];
+    const int g = blockIdx.z;
+    const int n = blockIdx.y / tiles_y, qy0 = (blockIdx.y - n * tiles_y) * DT_Y, qx0 = blockIdx.x * DT_X;
+    const int tid = threadIdx.x, tx = tid & (DT_X - 1), ty = tid / DT_X;
+    const int co0 = a.cout_off[g], nc = a.cout_off[g + 1] - co0;
+    const long cplane = (long)a.H * a.W;
+    const float *xg = a.x + ((long)n * a.cin + (long)g * a.cin_g) * cplane;
+    const float *wg = a.w + a.w_off[g];
+    const int nchunk = (a.cin_g + DT_CH - 1) / DT_CH;
+
+    // what this thread stages per chunk: 16-byte pieces idx = tid + 256 i of the DT_CH x DT_ROWS row segments (8 per segment) and, for
+    // tid < DT_CH * DT_ROWS, the segment's left halo pixel.  Every load is unconditional from a clamped address; what lies outside
+    // the image (or past the last channel) is masked to zero on its way into LDS - not at the load, which would wait for it.
+    constexpr int NV4 = DT_CH * DT_ROWS * (DT_X / 4), NI = (NV4 + 255) / 256;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 rv[NI];
+    unsigned rh = 0, keep[NI], keeph = 0;
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = min(tid + 256 * i, NV4 - 1), seg = idx / (DT_X / 4), v4 = idx - seg * (DT_X / 4);
+            const int c = seg / DT_ROWS, r = seg - c * DT_ROWS;
+            const int iy = qy0 - 1 + r, ix = qx0 + 4 * v4, ch = k * DT_CH + c;
+            keep[i] = (iy >= 0 && iy < a.H && ix < a.W && ch < a.cin_g) ? 0xffffffffu : 0u;
+            rv[i] = *reinterpret_cast<const u4 *>(xg + (long)min(ch, a.cin_g - 1) * cplane + (long)min(max(iy, 0), a.H - 1) * a.W + min(ix, a.W - 4));
+        }
+        {
+            const int seg = min(tid, DT_CH * DT_ROWS - 1), c = seg / DT_ROWS, r = seg - c * DT_ROWS;
+            const int iy = qy0 - 1 + r, ix = qx0 - 1, ch = k * DT_CH + c;
+            keeph = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ch < a.cin_g) ? 0xffffffffu : 0u;
+            rh = __float_as_uint(xg[(long)min(ch, a.cin_g - 1) * cplane + (long)min(max(iy, 0), a.H - 1) * a.W + min(max(ix, 0), a.W - 1)]);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < NV4) {
+                const int seg = idx / (DT_X / 4), v4 = idx - seg * (DT_X / 4), c = seg / DT_ROWS, r = seg - c * DT_ROWS;
+                *reinterpret_cast<u4 *>(&s_in[buf][c][r][4 + 4 * v4]) = rv[i] & keep[i];
+            }
+        }
+        if (tid < DT_CH * DT_ROWS) s_in[buf][tid / DT_ROWS][tid % DT_ROWS][3] = __uint_as_float(rh & keeph);
+    };
+
+    fetch(0);
+    // the group's weights [cin_g][nc][3][3] -> one row [tap][NC] per channel (output channels past nc: zero, never multiplied)
+    for (int i = tid; i < a.cin_g * NW; i += 256) {
+        const int c = i / NW, j = i - c * NW, tap = j / NC, co = j - tap * NC;
+        s_w[c][j] = (tap < K * K && co < nc) ? wg[((long)c * nc + co) * (K * K) + tap] : 0.f;
+    }
+    stage(0);
+    __syncthreads();
+
+    // acc[parity][co pair]: two output channels per packed multiply-add
+    constexpr int NP = (NC + 1) / 2;
+    v2f acc[S][S][NP];
+#pragma unroll
+    for (int ry = 0; ry < S; ++ry)
+#pragma unroll
+        for (int rx = 0; rx < S; ++rx)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[ry][rx][p] = v2f{0.f, 0.f};
+
+    for (int k = 0; k < nchunk; ++k) {
+        const bool more = k + 1 < nchunk;
+        if (more) fetch(k + 1);
+        const int buf = k & 1, cn = min(DT_CH, a.cin_g - k * DT_CH);
+        auto channel = [&](int c) __attribute__((always_inline)) {
+            float v[2][2];   // input pixels (qy - jy, qx - jx)
+            v[0][0] = s_in[buf][c][ty + 1][4 + tx];
+            v[0][1] = s_in[buf][c][ty + 1][3 + tx];
+            v[1][0] = s_in[buf][c][ty][4 + tx];
+            v[1][1] = s_in[buf][c][ty][3 + tx];
+            float wrow[NW];
+            const float4 *wp = reinterpret_cast<const float4 *>(&s_w[k * DT_CH + c][0]);   // the same address in every lane: a broadcast read
+#pragma unroll
+            for (int q = 0; q < NW / 4; ++q) { const float4 t = wp[q]; wrow[4 * q] = t.x; wrow[4 * q + 1] = t.y; wrow[4 * q + 2] = t.z; wrow[4 * q + 3] = t.w; }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {   // output parity (ky % S, kx % S), input row qy - ky / S
+                    const float x = v[ky / S][kx / S];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int t0 = (ky * K + kx) * NC + 2 * p;
+                        const v2f w2 = v2f{wrow[t0], 2 * p + 1 < NC ? wrow[t0 + 1] : 0.f};
+                        acc[ky % S][kx % S][p] = __builtin_elementwise_fma(v2f{x, x}, w2, acc[ky % S][kx % S][p]);
+                    }
+                }
+        };
+        if (cn == DT_CH) {
+#pragma unroll 4
+            for (int c = 0; c < DT_CH; ++c) channel(c);
+        } else {
+            for (int c = 0; c < cn; ++c) channel(c);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+    const int qy = qy0 + ty, qx = qx0 + tx;
+    if (qy >= a.QH || qx >= a.QW) return;
+    const long oplane = (long)a.OH * a.OW;
+#pragma unroll
+    for (int co = 0; co < NC; ++co) {
+        if (co >= nc) break;
+        const int cg = co0 + co;
+        const float b = a.bias ? a.bias[cg] : 0.f;
+        float *yo = a.y + ((long)n * a.cout + cg) * oplane;
+#pragma unroll
+        for (int ry = 0; ry < S; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < S; ++rx) {
+                const int oy = S * qy + ry - a.pad, ox = S * qx + rx - a.pad;
+                if (oy < 0 || oy >= a.OH || ox < 0 || ox >= a.OW) continue;
+                float v = acc[ry][rx][co / 2][co % 2] + b;
+                if (a.sigmoid_from >= 0 && cg >= a.sigmoid_from) v = 1.f / (1.f + expf(-v));
+                yo[(long)oy * a.OW + ox] = v;
+            }
+    }
+}
+
 template <int K, int S, int NC>
 void launch(const DeconvArgs &a, int groups, hipStream_t st) {
+    if constexpr (K == 3 && S == 2) {
+        // staged kernel: rows of whole 16-byte pieces at 16-byte aligned addresses, no softmax epilogue (LAV_DECONV_IMPL=gather: the old one)
+        const char *impl = getenv("LAV_DECONV_IMPL");
+        const bool gather = impl && impl[0] == 'g';
+        if (!gather && a.W % 4 == 0 && a.W >= 4 && a.cin_g <= DT_MAXC && reinterpret_cast<uintptr_t>(a.x) % 16 == 0 && a.sigmoid_from != -2) {
+            const int tiles_x = (a.QW + DT_X - 1) / DT_X, tiles_y = (a.QH + DT_Y - 1) / DT_Y;
+            hipLaunchKernelGGL((k_deconv_tile<NC>), dim3(tiles_x, tiles_y * a.B, groups), dim3(256), 0, st, a, tiles_y);
+            return;
+        }
+    }
     const long nq = (long)a.B * a.QH * a.QW;
     static const int unroll = [] { const char *e = getenv("LAV_DECONV_UNROLL"); return e ? atoi(e) : 8; }();
     const dim3 grid((unsigned)((nq + 255) / 256), groups);

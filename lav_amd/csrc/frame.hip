@@ -87,8 +87,15 @@ __global__ __launch_bounds__(256) void k_stack_sweeps(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ peaks
-constexpr int PT_W = 32, PT_H = 8;  // pixels per workgroup
+// Round 5 rewrite (56.6 -> measured in profiles/r05_*): 32 x 32 pixel tiles (a quarter of the workgroups, so a quarter of the
+// same-address slot / ticket atomics), separable 7 + 7 tap max instead of 49 taps, the tile's survivors compacted before they are
+// ranked against each other, and a last-arriver selection without barriers in its rounds: the two waves that own a class keep the
+// class's candidates in registers and each extract their own best max_det (u64 max over the wave on v_permlane swaps + DPP, no DS
+// instruction), one barrier, then the 2 x max_det keys of a class are ranked against each other.  Same rows as before: descending
+// score, ties by ascending pixel index.
+constexpr int PT = 32;              // tile side in pixels; 256 threads, four pixels each
 constexpr int PEAK_MAX_KS = 15, PEAK_MAX_DET = 64, PEAK_MAX_CLS = 8;
+constexpr int PEAK_PER_LANE = 16;   // candidates a lane of the selection keeps in registers: 2 waves x 64 x 16 = 2048 per class
 
 __device__ __forceinline__ unsigned ordered(float f) {  // monotone float -> uint
     const unsigned u = __float_as_uint(f);
@@ -97,12 +104,33 @@ __device__ __forceinline__ unsigned ordered(float f) {  // monotone float -> uin
 __device__ __forceinline__ float unordered(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+// max of a 64-bit key over the wave, result in every lane (xor butterfly 32, 16, then rotations inside the rows of 16 lanes)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    auto take = [&](unsigned lo, unsigned hi) {
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    };
+    {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        take(a[0] ^ a[1] ^ lo, b[0] ^ b[1] ^ hi);   // (x, x) swapped: one of the two results is the own value, the other the partner's
+    }
+    {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        take(a[0] ^ a[1] ^ lo, b[0] ^ b[1] ^ hi);
+    }
+#define LAV_ROT(ctrl) take((unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, ctrl, 0xf, 0xf, false), (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), ctrl, 0xf, 0xf, false))
+    LAV_ROT(0x128); LAV_ROT(0x124); LAV_ROT(0x122); LAV_ROT(0x121);   // row_ror 8, 4, 2, 1
+#undef LAV_ROT
+    return v;
+}
 
 struct PeakArgs {
     const float *heat, *size, *ori;
-    int ncls, H, W, ks, max_det, apply_sigmoid, size_c, ori_c, lds_cand;
+    int ncls, H, W, ks, max_det, apply_sigmoid, size_c, ori_c, cand_stride;
     float *out;                       // [ncls][max_det][3 + size_c + ori_c]
-    unsigned long long *cand;         // [ncls][H*W]
+    unsigned long long *cand;         // [ncls][cand_stride]
     int *count;                       // [ncls] + ticket at [ncls]
     unsigned long long *trace;        // debug (LAV_PEAKS_TRACE): [workgroup][8] wall-clock stamps, or null
 };
@@ -110,14 +138,19 @@ struct PeakArgs {
 __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
 #define PK_STAMP(i) do { if (a.trace && threadIdx.x == 0) a.trace[((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
     PK_STAMP(0);
-    __shared__ unsigned long long s_u64[256];
-    __shared__ float s_tile[(PT_H + PEAK_MAX_KS - 1) * (PT_W + PEAK_MAX_KS - 1)];
-    __shared__ int s_flag, s_cnt, s_base;
+    constexpr int TMAX = PT + PEAK_MAX_KS - 1;
+    __shared__ float s_tile[TMAX * TMAX];
+    __shared__ float s_hmax[TMAX * PT];
+    __shared__ unsigned long long s_list[PT * PT];
+    __shared__ unsigned long long s_keep[PEAK_MAX_DET];
+    __shared__ unsigned long long s_top[PEAK_MAX_CLS][2][PEAK_MAX_DET];
     __shared__ unsigned long long s_win[PEAK_MAX_CLS * PEAK_MAX_DET];
+    __shared__ int s_flag, s_n, s_base;
     const int tid = threadIdx.x, cls = blockIdx.z;
-    const int r = a.ks / 2, TW = PT_W + 2 * r, TH = PT_H + 2 * r;
-    const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
+    const int r = a.ks / 2, TW = PT + 2 * r, TH = PT + 2 * r;
+    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
     const float *hm = a.heat + (long)cls * a.H * a.W;
+    if (tid == 0) s_n = 0;
     for (int j = tid; j < TW * TH; j += 256) {
         const int ty = j / TW, tx = j - ty * TW;
         const int y = y0 + ty - r, x = x0 + tx - r;
@@ -130,39 +163,46 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
     }
     __syncthreads();
     PK_STAMP(1);
-    const int lx = tid % PT_W, ly = tid / PT_W;
-    const int x = x0 + lx, y = y0 + ly;
+    // max over the ks x ks window = max over its rows of the row maxima (fmaxf ignores NaN in any order)
+    for (int j = tid; j < TH * PT; j += 256) {
+        const int ty = j / PT, lx = j - ty * PT;
+        float m = s_tile[ty * TW + lx];
+        for (int dx = 1; dx < a.ks; ++dx) m = fmaxf(m, s_tile[ty * TW + lx + dx]);
+        s_hmax[j] = m;
+    }
+    __syncthreads();
     // possible_det = heat - (max > heat)*1e5: only non-suppressed pixels can reach the top-k while there are at least
-    // max_det of them; NaN never compares greater, exactly like the reference's (max > heat).  Of a tile's survivors
-    // only its own top max_det can be in the global top max_det (flat regions make EVERY pixel a survivor).
-    unsigned long long key = 0;
-    if (x < a.W && y < a.H) {
-        const float c = s_tile[(ly + r) * TW + lx + r];
-        float m = c;
-        for (int dy = 0; dy < a.ks; ++dy)
-            for (int dx = 0; dx < a.ks; ++dx) m = fmaxf(m, s_tile[(ly + dy) * TW + lx + dx]);
-        if (!(m > c)) key = ((unsigned long long)ordered(c) << 32) | (0xffffffffu - (unsigned)(y * a.W + x));
+    // max_det of them; NaN never compares greater, exactly like the reference's (max > heat)
+#pragma unroll
+    for (int i = 0; i < PT * PT / 256; ++i) {
+        const int p = tid + 256 * i, lx = p % PT, ly = p / PT;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < a.W && y < a.H) {
+            const float c = s_tile[(ly + r) * TW + lx + r];
+            float m = c;
+            for (int dy = 0; dy < a.ks; ++dy) m = fmaxf(m, s_hmax[(ly + dy) * PT + lx]);
+            if (!(m > c)) s_list[atomicAdd(&s_n, 1)] = ((unsigned long long)ordered(c) << 32) | (0xffffffffu - (unsigned)(y * a.W + x));
+        }
     }
+    __syncthreads();
     PK_STAMP(2);
-    s_u64[tid] = key;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    int local = -1;
-    if (key) {
+    // Of a tile's survivors only its own top max_det can be in the global top max_det (flat regions make EVERY pixel a survivor).
+    const int n = s_n;
+    for (int j = tid; j < n; j += 256) {
+        const unsigned long long key = s_list[j];
         int rank = 0;
-#pragma unroll 16
-        for (int j = 0; j < 256; ++j) rank += s_u64[j] > key;   // independent LDS reads, 16 in flight
-        if (rank < a.max_det) local = atomicAdd(&s_cnt, 1);   // LDS atomic: order inside the tile is irrelevant
+        for (int i = 0; i < n; ++i) rank += s_list[i] > key;
+        if (rank < a.max_det) s_keep[rank] = key;   // keys are unique: ranks 0 .. min(n, max_det) - 1 are each taken once
     }
     __syncthreads();
-    // ONE global atomic per workgroup reserves the tile's slots (12 000 same-address atomics cost ~100 us otherwise)
-    if (tid == 0) s_base = s_cnt ? atomicAdd(&a.count[cls], s_cnt) : 0;
+    const int nk = min(n, a.max_det);
+    // ONE global atomic per workgroup reserves the tile's slots
+    if (tid == 0) s_base = nk ? atomicAdd(&a.count[cls], nk) : 0;
     __syncthreads();
-    if (local >= 0)  // write-through (sc1) store: visible device-wide once it has left this wave, no L2 write-back fence needed
-        __hip_atomic_store(&a.cand[(long)cls * a.H * a.W + s_base + local], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < nk)  // write-through (sc1) store: visible device-wide once it has left this wave, no L2 write-back fence needed
+        __hip_atomic_store(&a.cand[(long)cls * a.cand_stride + s_base + tid], s_keep[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- hand-off to the last workgroup (MI355X guide G16, write-through form: sc1 payload stores, every wave drains
     // its stores, barrier, one relaxed agent-scope ticket; the last arriver takes ONE acquire before plain loads).
-    // A release fence per workgroup (buffer_wbl2 from 800 workgroups) made this kernel 107 us instead of ~15.
     PK_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -176,44 +216,55 @@ __global__ __launch_bounds__(256) void k_extract_peaks(PeakArgs a) {
     __syncthreads();
     PK_STAMP(4);
     if (!s_flag) return;
+    // ---- final selection by the last workgroup.  Waves 2p, 2p + 1 own the classes p, p + 2, ...; wave (2p + h) keeps the candidates
+    // h*64 + lane + 128 j of the class in registers and extracts ITS best max_det in score order: no barrier, no LDS inside the rounds.
     const int ncol = 3 + a.size_c + a.ori_c;
-    // final selection by the last workgroup: candidates of one class into LDS (when they fit), then max_det rounds of
-    // "largest key below the previous pick" - wave reduction by DPP shuffles, one barrier per round
-    constexpr int PER_THREAD = 24;   // candidates a thread keeps in registers: 256 * 24 = 6144 >= 400 tiles * 15
-    for (int c = 0; c < a.ncls; ++c) {
-        const int n = min(__hip_atomic_load(&a.count[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.H * a.W);
-        const unsigned long long *cand = a.cand + (long)c * a.H * a.W;
-        const bool in_regs = n <= 256 * PER_THREAD;
-        unsigned long long mine[PER_THREAD];
-        if (in_regs) {
+    const int lane = tid & 63, wv = tid >> 6, pr = wv >> 1, hf = wv & 1;
+    for (int c = pr; c < a.ncls; c += 2) {
+        const int nc_ = min(__hip_atomic_load(&a.count[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.cand_stride);
+        const unsigned long long *cand = a.cand + (long)c * a.cand_stride;
+        const bool in_regs = nc_ <= 128 * PEAK_PER_LANE;
+        unsigned long long mine[PEAK_PER_LANE];
 #pragma unroll
-            for (int j = 0; j < PER_THREAD; ++j) mine[j] = j * 256 + tid < n ? cand[j * 256 + tid] : 0ull;
+        for (int j = 0; j < PEAK_PER_LANE; ++j) {
+            const int i = hf * 64 + lane + 128 * j;
+            mine[j] = in_regs && i < nc_ ? cand[i] : 0ull;
         }
         unsigned long long bound = ~0ull;  // keys are unique (they carry the pixel index): select strictly below the last pick
         for (int d = 0; d < a.max_det; ++d) {
             unsigned long long best = 0;
             if (in_regs) {
 #pragma unroll
-                for (int j = 0; j < PER_THREAD; ++j)
+                for (int j = 0; j < PEAK_PER_LANE; ++j)
                     if (mine[j] < bound && mine[j] > best) best = mine[j];
-            } else {
-                for (int j = tid; j < n; j += 256) {
-                    const unsigned long long k = cand[j];
+            } else {   // (more candidates than the registers hold: maps beyond 8 x 16 tiles; scan the list)
+                for (int i = hf * 64 + lane; i < nc_; i += 128) {
+                    const unsigned long long k = cand[i];
                     if (k < bound && k > best) best = k;
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned lo = __shfl_xor((unsigned)best, off), hi = __shfl_xor((unsigned)(best >> 32), off);
-                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-                best = o > best ? o : best;
-            }
-            unsigned long long *slot = s_u64 + (d & 1) * 4;  // two slot sets: one barrier per round is enough
-            if ((tid & 63) == 0) slot[tid >> 6] = best;
-            __syncthreads();
-            best = max(max(slot[0], slot[1]), max(slot[2], slot[3]));
-            if (tid == 0) s_win[c * PEAK_MAX_DET + d] = best;   // gathers happen once, after all rounds (no memory latency per round)
-            bound = best;
+            best = wave_max_u64(best);
+            if (lane == 0) s_top[c][hf][d] = best;
+            bound = best ? best : 0ull;   // (0: this wave has run out of candidates - every later round yields 0 as well)
+        }
+    }
+    __syncthreads();
+    // the class's 2 x max_det keys ranked against each other: rank r < max_det is row r (0 = no candidate)
+    for (int e = tid; e < a.ncls * 2 * a.max_det; e += 256) {
+        const int c = e / (2 * a.max_det), i = e - c * 2 * a.max_det;
+        const unsigned long long key = s_top[c][i / a.max_det][i % a.max_det];
+        if (key) {
+            int rank = 0;
+            for (int j = 0; j < 2 * a.max_det; ++j) rank += s_top[c][j / a.max_det][j % a.max_det] > key;
+            if (rank < a.max_det) s_win[c * PEAK_MAX_DET + rank] = key;
+        }
+    }
+    {   // rows beyond the number of candidates
+        for (int e = tid; e < a.ncls * a.max_det; e += 256) {
+            const int c = e / a.max_det, d = e - c * a.max_det;
+            int have = 0;
+            for (int j = 0; j < 2 * a.max_det; ++j) have += s_top[c][j / a.max_det][j % a.max_det] != 0ull;
+            if (d >= have) s_win[c * PEAK_MAX_DET + d] = 0ull;
         }
     }
     __syncthreads();
@@ -324,8 +375,8 @@ extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int 
     a.count = reinterpret_cast<int *>(static_cast<char *>(workspace) + workspace_bytes - align_up((size_t)(ncls + 1) * sizeof(int), 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tok = timer_begin("extract_peaks", st);
-    const dim3 grid((w + PT_W - 1) / PT_W, (h + PT_H - 1) / PT_H, ncls);
-    a.lds_cand = 0;
+    const dim3 grid((w + PT - 1) / PT, (h + PT - 1) / PT, ncls);
+    a.cand_stride = h * w;
     a.trace = nullptr;
     static const bool want_trace = getenv("LAV_PEAKS_TRACE") != nullptr;
     static unsigned long long *d_trace = nullptr;

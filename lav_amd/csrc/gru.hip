@@ -30,6 +30,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Cross-lane sums without LDS hardware (__shfl_xor compiles to ds_bpermute_b32, a DS instruction): gfx950's v_permlane32_swap /
+// v_permlane16_swap exchange halves / rows of 16 lanes between two registers, DPP row rotations do the rest.
+__device__ __forceinline__ float fold32(float x, float y) {   // lanes 0-31: x[l] + x[l+32]; lanes 32-63: y[l-32] + y[l]  (or the halves exchanged)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float x, float y) {   // even rows of 16 lanes: x's row pair summed; odd rows: y's
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_allsum(float x) {   // xor butterfly 8, 4, 2, 1 inside each row of 16 lanes (rotations of a period-2d value)
+    x = dpp_add<0x128>(x);   // row_ror:8
+    x = dpp_add<0x124>(x);   // row_ror:4
+    x = dpp_add<0x122>(x);   // row_ror:2
+    x = dpp_add<0x121>(x);   // row_ror:1
+    return x;
+}
+// the xor butterfly 32, 16, 8, 4, 2, 1 of one value on those instructions: bit-identical to wave_sum (fp addition is commutative)
+__device__ __forceinline__ float wave_sum_valu(float v) { return row_allsum(fold16(fold32(v, v), fold32(v, v))); }
+
 // ------------------------------------------------------------------------------------------------- cast
 // H = 64 fixed by the register layout (one W_hh row of 64 floats per thread, 3H = 192 threads)
 constexpr int CAST_H = 64;
@@ -371,6 +395,12 @@ __global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ sta
 #ifndef LAV_PLAN_LDS_SYNC
 #define LAV_PLAN_LDS_SYNC 0
 #endif
+// -DLAV_PLAN_VARIANT=bits: experiments on this kernel as the known victim (tools/plan_variants.sh, profiles/r05_coresidency.md):
+// 1 no s_sleep between poll rounds, 2 the wave sums on v_permlane swaps + DPP instead of ds_bpermute_b32 (no DS instruction but the
+// kernel's own LDS reads and writes), 4 abort flag read once per step instead of three times.
+#ifndef LAV_PLAN_VARIANT
+#define LAV_PLAN_VARIANT 0
+#endif
 #if LAV_PLAN_LDS_SYNC
 #define LDSR(x) lav::lds_read_sync(&(x))
 #define LDSW(x, v) lav::lds_write_sync(&(x), (v))
@@ -497,7 +527,7 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                             }
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
+                        if (!(LAV_PLAN_VARIANT & 1)) __builtin_amdgcn_s_sleep(2);
                     }
                 } while (!ok);
                 if constexpr (POLL) {   // the four quarters meet in LDS (also the rendezvous of an abort: every wave leaves together)
@@ -538,10 +568,15 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
                                 s0 = fmaf(m0[i], hv[rr][i], s0);
                                 s1 = fmaf(m1[i], hv[rr][i], s1);
                             }
+                            if (LAV_PLAN_VARIANT & 2) {
+                                s0 = wave_sum_valu(s0);
+                                s1 = wave_sum_valu(s1);
+                            } else {
 #pragma unroll
-                            for (int d = 32; d >= 1; d >>= 1) {
-                                s0 += __shfl_xor(s0, d, 64);
-                                s1 += __shfl_xor(s1, d, 64);
+                                for (int d = 32; d >= 1; d >>= 1) {
+                                    s0 += __shfl_xor(s0, d, 64);
+                                    s1 += __shfl_xor(s1, d, 64);
+                                }
                             }
                             if (lane == 0) {
                                 float r0 = LDSR(run_s[rr][0]) + (s0 + a.mlp_b[0]), r1 = LDSR(run_s[rr][1]) + (s1 + a.mlp_b[1]);
@@ -575,10 +610,15 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
 #pragma unroll
                         for (int i = 0; i < PLAN_MAXK; ++i) acc[q] = fmaf(w[q][i], hv[rr][i], acc[q]);
                     }
+                    if (LAV_PLAN_VARIANT & 2) {
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1)
+                        for (int q = 0; q < 6; ++q) acc[q] = wave_sum_valu(acc[q]);
+                    } else {
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) acc[q] += __shfl_xor(acc[q], d, 64);
+                        for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+                            for (int q = 0; q < 6; ++q) acc[q] += __shfl_xor(acc[q], d, 64);
+                    }
                     if (lane == 0) {
                         {   // committed LDS stores (common.hpp: ds_write data hazards beside matrix-heavy neighbours)
                             float gv[6];
@@ -633,26 +673,6 @@ __global__ __launch_bounds__(256) void k_plan_persistent(PlanArgs a, unsigned lo
 // 32, 16, 8, 4, 2, 1 - the swaps + adds below ARE that butterfly (fp addition is commutative, both partners of a pair end up with the
 // same bits), 26 sums folded 32 -> 16 -> 8 registers on the way down instead of 26 x 6 exchanges: bit-identical results.
 // Polling traffic per workgroup = the quarter-poll scheme's (every granule is read once per round by one wave).
-struct Swap2 { float a, b; };
-__device__ __forceinline__ float fold32(float x, float y) {   // lanes 0-31: x[l] + x[l+32]; lanes 32-63: y[l-32] + y[l]  (or the halves exchanged)
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float fold16(float x, float y) {   // even rows of 16 lanes: x's row pair summed; odd rows: y's
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {
-    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row_allsum(float x) {   // xor butterfly 8, 4, 2, 1 inside each row of 16 lanes (rotations of a period-2d value)
-    x = dpp_add<0x128>(x);   // row_ror:8
-    x = dpp_add<0x124>(x);   // row_ror:4
-    x = dpp_add<0x122>(x);   // row_ror:2
-    x = dpp_add<0x121>(x);   // row_ror:1
-    return x;
-}
 // p[q][j]: this lane's partial sum of slot (quarter q, j): j < 6 -> unit 2q + j / 3, gate j % 3; (0, 6) and (0, 7): the two waypoint rows.
 // Returns in z[j] the complete sum of slot (Q, j), where Q is the quarter of this lane's row of 16 lanes (kernel entry calibrates Q).
 __device__ __forceinline__ void plan_fold(const float (&p)[4][6], float s0, float s1, float (&z)[8]) {

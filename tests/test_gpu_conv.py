@@ -279,6 +279,27 @@ def test_grouped_deconv_matches_torch(outs, cin_g, k, pad, opad, B, H, W, sig):
     assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=f"grouped deconv {outs}")
 
 
+@pytest.mark.parametrize("outs,cin_g,opad,B,H,W", [((2, 2, 2, 3), 64, 1, 1, 160, 160), ((1, 2, 2, 4), 40, 1, 2, 37, 44), ((2,), 48, 0, 1, 8, 300), ((3, 3), 16, 1, 3, 5, 4)])
+def test_staged_grouped_deconv_is_bit_identical_to_the_gathering_kernel(outs, cin_g, opad, B, H, W, monkeypatch):
+    """Round 5: k_deconv_tile (3x3 stride 2: tiles of 8 x 32 input-grid positions staged through LDS 16 channels at a time) against
+    k_deconv_grouped (every thread gathers its four pixels per channel from L2): same products in the same order, so the same bits -
+    the heads' own shape, ragged channel chunks / tiles / batch, output_padding 0, a map narrower than a tile."""
+    from lav_amd.ops import GroupedDeconv
+    torch.manual_seed(7)
+    cts = [torch.nn.ConvTranspose2d(cin_g, o, 3, stride=2, padding=1, output_padding=opad) for o in outs]
+    x = rnd((B, cin_g * len(outs), H, W), 33).to(DEV)
+    layer = GroupedDeconv(cts, sigmoid_from=sum(outs[:-1]), device=DEV)
+    staged = layer(x).clone()
+    monkeypatch.setenv("LAV_DECONV_IMPL", "gather")
+    gathered = layer(x).clone()
+    monkeypatch.delenv("LAV_DECONV_IMPL")
+    assert torch.equal(staged, gathered), f"max |diff| {float((staged - gathered).abs().max())}"
+    with torch.no_grad():
+        ref = torch.cat([ct(x.cpu()[:, i * cin_g:(i + 1) * cin_g]) for i, ct in enumerate(cts)], dim=1)
+        ref[:, sum(outs[:-1]):] = torch.sigmoid(ref[:, sum(outs[:-1]):])
+    assert_close(staged.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what=f"staged grouped deconv {outs}")
+
+
 @pytest.mark.parametrize("ch,h,w,dils", [(128, 36, 32, (2, 4, 8, 16)), (64, 72, 64, (1, 1, 1)), (64, 20, 64, (1, 3)), (16, 144, 128, (1, 1))])
 def test_pair_chain_is_bit_identical_to_the_pairs_launched_one_by_one(ch, h, w, dils):
     """lav_conv1d_pair_chain (one persistent launch for a run of non_bottleneck_1d blocks, rows handed between workgroups through

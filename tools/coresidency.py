@@ -105,6 +105,34 @@ _seg = _seg.eval().to(dev)
 _seg_x = torch.rand(3, 3, 288, 256, device=dev) * 255
 aggressors["ERFNet (persistent pair runs + its other layers)"] = lambda: _seg(_seg_x)
 
+# ERFNet's persistent runs one width at a time (lav_conv1d_pair_chain: bf16 matrix instructions + LDS, row-resident workgroups that
+# claim their CU's LDS - all of it at 64 / 128 channels, HALF of it at 16 channels, where 432 rows need two workgroups per CU)
+import torch.nn as nn  # noqa: E402
+from lav_amd.ops import Conv1dPair, Conv1dPairChain  # noqa: E402
+
+
+def _chain(ch, h, w, dil):
+    pairs = [Conv1dPair(nn.Conv2d(ch, ch, (3, 1), padding=(d, 0), dilation=(d, 1)), nn.Conv2d(ch, ch, (1, 3), padding=(0, d), dilation=(1, d)),
+                        nn.BatchNorm2d(ch, eps=1e-3).eval(), device=dev) for d in dil]
+    chain = Conv1dPairChain(pairs, [i % 2 == 1 for i in range(len(pairs))])
+    x = torch.randn((3, ch, h, w), device=dev)
+    assert chain.supported(x), (ch, h, w)
+    return lambda: chain(x)
+
+
+aggressors["pair chain 16 ch @144x128 x3 (432 rows, two per CU: half claims)"] = _chain(16, 144, 128, (1,) * 10)
+aggressors["pair chain 64 ch @72x64 x3 (216 rows, one per CU: whole claim)"] = _chain(64, 72, 64, (1,) * 10)
+aggressors["pair chain 128 ch @36x32 x3 (108 rows, one per CU: whole claim)"] = _chain(128, 36, 32, (1, 2, 1, 4, 1, 8, 1, 16))
+
+
+def _erfnet_single_pairs():
+    os.environ["LAV_ERFNET_CHAIN"] = "0"
+    _seg(_seg_x)
+    os.environ.pop("LAV_ERFNET_CHAIN")
+
+
+aggressors["ERFNet, pairs launched one by one (LAV_ERFNET_CHAIN=0)"] = _erfnet_single_pairs
+
 here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes")
 so = os.path.join(here, "liblds_hog.so")
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(here, "lds_hog.hip")):

@@ -34,4 +34,4 @@ with torch.no_grad():
     for _ in range(50):
         fn()
     torch.cuda.synchronize()
-    print(f"LAV_DECONV_UNROLL={os.environ.get('LAV_DECONV_UNROLL', 'default')}: " + ", ".join(f"{k} {read(k)[0]:.1f} us" for k in ("conv2d", "deconv_grouped", "extract_peaks")))
+    print(f"LAV_DECONV_IMPL={os.environ.get('LAV_DECONV_IMPL', 'staged')}: " + ", ".join(f"{k} {read(k)[0]:.1f} us" for k in ("conv2d", "deconv_grouped", "extract_peaks")))
