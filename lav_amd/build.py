@@ -22,7 +22,14 @@ SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "gru_seq.hip", "con
 # helpers __fadd_rn/__fmul_rn are plain operators that clang would otherwise fuse after inlining).
 EXTRA_FLAGS = {"pillar.hip": ["-ffp-contract=off"], "paint.hip": ["-ffp-contract=off"], "crop.hip": ["-ffp-contract=off"],
                "frame.hip": ["-ffp-contract=off"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# -fno-slp-vectorize (round 5): the SLP vectoriser turns pairs of scalar float operations into packed fp32 instructions
+# (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) and selects halves of register pairs with op_sel.  On gfx950 a packed fp32 instruction
+# whose op_sel bit is set (low result from the HIGH register of a source pair) returns wrong values in lanes 48-63 when waves of a
+# bf16-matrix + LDS heavy kernel share its SIMD (tools/lds_hazard.py pattern 55: 535 936 wrong of 1.26e10 beside ERFNet's 16-channel
+# run, 0 alone) - the "finite but wrong" results of DESIGN 4.4c.  Without the vectoriser hipcc emits no packed fp32 at all; the
+# kernels that use it on purpose (deconv.hip) write the instruction themselves with op_sel = 0.  tests/test_capi_host.py disassembles
+# the library and fails on any packed fp32 instruction with an op_sel bit set.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
 

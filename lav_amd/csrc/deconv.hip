@@ -152,7 +152,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int NC>
 __global__ __launch_bounds__(256) void k_deconv_tile(DeconvArgs a, int tiles_y) {
     constexpr int K = 3, S = 2, NW = (K * K * NC + 3) / 4 * 4;   // floats per weight row [tap][NC], padded to 16 bytes
-    __shared__ __attribute__((aligned(16))) float s_in[2][DT_CH][DT_ROWS][DT_RS];
+    // (+ 4 floats: the last column's (own, right) pair reads one element past its row - the next row's first pad word, or this tail)
+    __shared__ __attribute__((aligned(16))) float s_in_flat[2 * DT_CH * DT_ROWS * DT_RS + 4];
+    float (*s_in)[DT_CH][DT_ROWS][DT_RS] = reinterpret_cast<float (*)[DT_CH][DT_ROWS][DT_RS]>(s_in_flat);
     __shared__ __attribute__((aligned(16))) float s_w[DT_MAXC][NW];
     const int g = blockIdx.z;
     const int n = blockIdx.y / tiles_y, qy0 = (blockIdx.y - n * tiles_y) * DT_Y, qx0 = blockIdx.x * DT_X;
@@ -222,11 +224,15 @@ __global__ __launch_bounds__(256) void k_deconv_tile(DeconvArgs a, int tiles_y) 
         if (more) fetch(k + 1);
         const int buf = k & 1, cn = min(DT_CH, a.cin_g - k * DT_CH);
         auto channel = [&](int c) __attribute__((always_inline)) {
-            float v[2][2];   // input pixels (qy - jy, qx - jx)
-            v[0][0] = s_in[buf][c][ty + 1][4 + tx];
-            v[0][1] = s_in[buf][c][ty + 1][3 + tx];
-            v[1][0] = s_in[buf][c][ty][4 + tx];
-            v[1][1] = s_in[buf][c][ty][3 + tx];
+            // input pixels (qy - jy, qx - jx), each as the LOW half of a register pair: the packed multiply-add then broadcasts it with
+            // op_sel_hi = 0 only.  (A value sitting in the HIGH register of a pair would be selected with op_sel = 1 - the form that
+            // returns wrong lanes beside matrix + LDS neighbours on gfx950, DESIGN 4.4c / profiles/r05_coresidency.md; a CPU test
+            // disassembles the library and rejects it.)
+            v2f v[2][2];
+            v[0][1] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty + 1][3 + tx]);   // (left, own): left in the low half
+            v[0][0] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty + 1][4 + tx]);   // (own, right)
+            v[1][1] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty][3 + tx]);
+            v[1][0] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty][4 + tx]);
             float wrow[NW];
             const float4 *wp = reinterpret_cast<const float4 *>(&s_w[k * DT_CH + c][0]);   // the same address in every lane: a broadcast read
 #pragma unroll
@@ -235,12 +241,12 @@ __global__ __launch_bounds__(256) void k_deconv_tile(DeconvArgs a, int tiles_y) 
             for (int ky = 0; ky < K; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {   // output parity (ky % S, kx % S), input row qy - ky / S
-                    const float x = v[ky / S][kx / S];
+                    const v2f xp = v[ky / S][kx / S];
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         const int t0 = (ky * K + kx) * NC + 2 * p;
                         const v2f w2 = v2f{wrow[t0], 2 * p + 1 < NC ? wrow[t0 + 1] : 0.f};
-                        acc[ky % S][kx % S][p] = __builtin_elementwise_fma(v2f{x, x}, w2, acc[ky % S][kx % S][p]);
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[ky % S][kx % S][p]) : "v"(xp), "v"(w2));
                     }
                 }
         };

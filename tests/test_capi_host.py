@@ -431,3 +431,32 @@ def test_plan_kernel_has_no_lds_instruction_and_no_barrier(tmp_path):
             assert not bad, f"{name}: {bad}"
             assert any(op.startswith("v_permlane32_swap") for op in ops_) and any("dpp" in op for op in ops_), name
     assert found == 4, f"{found} k_plan_wave instantiations found (expected <1,8>, <1,0>, <6,8>, <6,0>)"
+
+
+def test_library_holds_no_packed_fp32_with_op_sel(tmp_path):
+    """Round 5, the root cause of round 4's finite-but-wrong results (profiles/r05_coresidency.md): on gfx950 a packed
+    fp32 instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) whose op_sel bit is set for a source - the LOW result takes the
+    HIGH register of the 64-bit source pair - returns wrong values in lanes 48-63 while waves of a bf16-matrix + LDS heavy kernel
+    share its SIMD (tools/lds_hazard.py pattern 55: one such v_pk_mul_f32 in a loop, evaluated twice on the same inputs, disagrees
+    with itself 535 936 times in 1.26e10 beside ERFNet's 16-channel persistent run and never alone).  hipcc's SLP vectoriser emits
+    that form freely; rounds 2-4's plan kernel held exactly one (the waypoint sum) and lav_crop_rotate three.  The library is built
+    with -fno-slp-vectorize and writes its packed instructions by hand with op_sel = 0; none with an op_sel bit may be left."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from lav_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or the built library is missing")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert objs, "no gfx950 code object found in the library"
+    bad = []
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", o], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+        for line in asm.splitlines():
+            if re.search(r"\bv_pk_\w+_f32\b", line) and re.search(r"op_sel:\[[01,]*1", line):
+                bad.append(line.split("//")[0].strip())
+    assert not bad, f"{len(bad)} packed fp32 instructions with an op_sel bit in liblav_amd.so, e.g. {bad[:3]}"
