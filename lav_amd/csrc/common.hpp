@@ -25,31 +25,30 @@ inline int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-// gfx950 hazard found in round 4 (tools/plan_stress.py, profiles/r04_plan_stress.txt): hipcc merges two adjacent 64-bit LDS stores
-// into one ds_write2_b64 (128 bits of data read from the VGPR file over more than one cycle) and then schedules VALU instructions
-// that OVERWRITE those data registers right behind it - its hazard recognizer only pads stores whose first data operand is wider than
-// 64 bits (ds_write_b96 / b128).  Alone on its SIMD the wave gets away with it; with another kernel's waves issuing matrix
-// instructions on the same SIMD the LDS instruction reads its operands late and stores the NEW register contents: the persistent plan
-// kernel's gate pre-activations of every fourth row, whenever a 7x7 crop stem (tap-pair split kernel) shared its CUs.  Call this
-// between LDS stores that the compiler could pair into 2 x 64 bits; tests/test_capi_host.py fails if a ds_write2_b64 is left in the
-// library.
+// Finite-but-wrong results beside matrix + LDS heavy neighbours (round 4: profiles/r04_plan_stress.txt; resolved in round 5:
+// profiles/r05_coresidency.md, tools/lds_hazard.py).  What round 4 saw: the persistent plan kernel (and, rarely, lav_crop_rotate)
+// returned finite but wrong values whenever waves of a split-operand convolution, an ERFNet pair kernel or a synthetic bf16-matrix +
+// LDS neighbour shared its CUs.  It was taken for an LDS effect (a ds_write2_b64 whose data registers hipcc rewrites right behind it;
+// "more than one LDS operation in flight") and fenced with the helpers below and with LDS claims on the aggressors.  What it is:
+// a packed fp32 instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) with an op_sel bit set - the low result takes the HIGH
+// register of a 64-bit source pair - returns wrong values in lanes 48-63 (the instruction's last pass) while such a neighbour shares
+// the SIMD.  One v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,0] in a loop, evaluated twice on identical inputs with no memory access
+// at all, disagrees with itself 535 936 times in 1.26e10 beside ERFNet's 16-channel run and never alone; the same instruction without
+// op_sel, every LDS pattern tried (store / load write-after-read on data and address registers, 8 loads in flight, partial waits,
+// ds_write2_b64 with its data overwritten at once, ds_bpermute beside loads) and registers at rest never fail.  hipcc's SLP vectoriser
+// emits the form freely: the old plan kernel held exactly one (its waypoint sum), lav_crop_rotate three.  The library is therefore
+// built with -fno-slp-vectorize (lav_amd/build.py), writes the packed instructions it wants by hand with op_sel = 0 (deconv.hip), and
+// tests/test_capi_host.py rejects any packed fp32 instruction with an op_sel bit in the disassembly.
+//
+// The round-4 helpers stay where they are used (they cost nothing): lds_store_fence keeps two 64-bit LDS stores from being merged into
+// a ds_write2_b64 (tools/lds_hazard.py patterns 10 / 11 could not make that instruction fail, alone or beside any neighbour; the CPU
+// test that forbids it is kept as a tripwire, not as a known hazard), lds_commit / lds_keep wait for a wave's LDS stores with the
+// stored values pinned, lds_read_sync / lds_write_sync issue one LDS access at a time (-DLAV_PLAN_LDS_SYNC=1 builds of the old plan
+// kernel: "immune" in round 4 because the changed code no longer contained the packed instruction).
 __device__ __forceinline__ void lds_store_fence() { asm volatile("" ::: "memory"); }
-// The same stress test then showed the 64-bit form as well (ds_write_b64 of {r0, r1} with a v_pk_add_f32 into the same registers as
-// the very next instruction) once the neighbour waves issue matrix instructions AND LDS traffic (the real stem kernel; the
-// synthetic one of tools/probes/lds_hog.hip in mode 1): an LDS store waiting in a congested LDS queue reads its data registers
-// when it gets there, not when it was issued.  A long-running kernel that shares CUs with such neighbours therefore COMMITS its LDS
-// stores: wait until they have left (lgkmcnt 0), and keep every stored value pinned in its register until then -
-//     s[i] = v; ...; lds_commit(); lds_keep(v); ...
-// (lds_keep is an empty asm that "modifies" v, so the register allocator cannot hand v's register to anything else before it).
 __device__ __forceinline__ void lds_commit() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <class T>
 __device__ __forceinline__ void lds_keep(T &v) { asm volatile("" : "+v"(v)); }
-// What DOES make a victim immune (measured at the end of round 4, profiles/r04_plan_stress.txt): every LDS access issued together
-// with its wait in ONE asm block, one access in flight at a time.  With -DLAV_PLAN_LDS_SYNC=1 the persistent plan kernel is
-// bit-exact beside the synthetic matrix + LDS neighbour (0 of 400 launches, both polling schemes) and beside the real stem kernel
-// with the LDS claims switched OFF (0 of 200; 126 of 150 wrong without), at +60 us per plan (frame 420 -> 410 frames/s).  The same
-// accesses batched - several ds_read / ds_write in one asm block, all operands pinned, ONE wait - fail again (68 of 100): it is
-// having more than one LDS operation of a wave in flight that goes wrong beside such neighbours, not registers being rewritten.
 __device__ __forceinline__ float lds_read_sync(const float *p) {
     float v;
     const unsigned a = (unsigned)(size_t)p;   // (low half of the generic address = the LDS offset)
@@ -61,17 +60,12 @@ __device__ __forceinline__ void lds_write_sync(float *p, float v) {
     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
 }
 
-// Host side of the same finding: the kernels that combine bf16 matrix instructions with heavy LDS traffic (split-operand
-// convolutions, the ERFNet pair kernels) corrupt LDS-dependent results of kernels whose waves share their CUs (measured with the
-// persistent plan kernel as the victim: wrong in 171 of 300 launches beside the brake net's split convolutions, 3-10 of 300 beside
-// ERFNet, 0 of 300 once these kernels leave no LDS on their CUs; the fp32 tiled / direct kernels are harmless).  They therefore
-// CLAIM the LDS of their CU: all of it when one workgroup runs per CU, half each when two do.  LAV_LDS_EXCLUSIVE=0: exact sizes.
+// LDS claims (round 4's fence, an opt-in since round 5): LAV_LDS_EXCLUSIVE=1 makes the split-operand convolutions and the ERFNet pair
+// kernels ask for all of their CU's LDS (half each where two workgroups share a CU), so that no kernel that uses LDS runs beside them;
+// 2: the whole CU also for kernels that could run two per CU; default 0: exact sizes.  needs_two_per_cu: a persistent launch whose
+// workgroups must all be resident at once and outnumber the CUs keeps the half claim in every mode.
 inline size_t lds_claim(size_t need, size_t static_bytes = 0, bool needs_two_per_cu = false) {
-    // LAV_LDS_EXCLUSIVE: 1 (default) as above | 0 exact sizes | 2 the whole CU also for the kernels that could run two per CU (a CU that
-    // holds only ONE of their workgroups - grids below 2 x 256, launch tails - still has half its LDS free for a victim: the "rare
-    // ERFNet aggressor" of profiles/r04_plan_stress.txt; tools/coresidency.py measures all three settings).  needs_two_per_cu: a
-    // persistent launch whose workgroups must all be resident at once and outnumber the CUs keeps the half claim in every mode.
-    static const int mode = [] { const char *e = getenv("LAV_LDS_EXCLUSIVE"); return e ? atoi(e) : 1; }();
+    static const int mode = [] { const char *e = getenv("LAV_LDS_EXCLUSIVE"); return e ? atoi(e) : 0; }();
     const size_t total = 160 * 1024;
     if (mode == 0) return need;
     if (need + static_bytes > total / 2 || (mode == 2 && !needs_two_per_cu && need + static_bytes > total / 3)) return (total - static_bytes) / 16 * 16;   // one workgroup per CU

@@ -659,13 +659,14 @@ int launch_split_g(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
         LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split<MP, MC, WPX, NT, G, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    // The workgroup takes the CU's whole LDS whatever its tiles need (every variant holds 150+ VGPRs x 8 waves: one workgroup per CU
-    // anyway).  Round 4 found that a kernel whose waves share SIMDs with this one's - matrix instructions AND heavy LDS traffic -
-    // can have its own LDS accesses corrupted (common.hpp, profiles/r04_plan_stress.txt: the persistent plan kernel beside the 7x7
-    // stems); with no LDS left on the CU, no kernel that uses LDS can become that neighbour.  LAV_SPLIT_LDS_EXCLUSIVE=0: as needed.
+    // Round 4 made this workgroup take the CU's whole LDS whatever its tiles need, to keep LDS-using kernels off its CUs: the
+    // finite-but-wrong results beside it were taken for an LDS effect.  Round 5 found the cause - packed fp32 instructions with an
+    // op_sel bit in the VICTIMS (common.hpp) - and removed those instructions from the library, so the launch asks for what it needs
+    // again (+0.5 % frames/s: the side streams' kernels overlap with it once more).  LAV_LDS_EXCLUSIVE=1 / LAV_SPLIT_LDS_EXCLUSIVE=1
+    // bring the claim back (tools/coresidency.py measures both settings).
     static const bool exclusive = [] {
-        const char *e = getenv("LAV_SPLIT_LDS_EXCLUSIVE"), *g = getenv("LAV_LDS_EXCLUSIVE");   // (the second one also switches lav::lds_claim off)
-        return (!e || atoi(e) != 0) && (!g || atoi(g) != 0);
+        const char *e = getenv("LAV_SPLIT_LDS_EXCLUSIVE"), *g = getenv("LAV_LDS_EXCLUSIVE");
+        return (e && atoi(e) != 0) || (g && atoi(g) != 0);
     }();
     hipLaunchKernelGGL((k_conv_split<MP, MC, WPX, NT, G, TP>), grid, dim3(512), exclusive ? (size_t)160 * 1024 : lds, st, sa);
     return LAV_OK;

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_deconv_grouped(DeconvArgs a) {
 constexpr int DT_Y = 8, DT_X = 32, DT_CH = 16, DT_RS = DT_X + 4, DT_ROWS = DT_Y + 1;   // row: [3] = left halo, [4, 36) = the tile's columns
 constexpr int DT_MAXC = 64;                                                            // channels per group the weight rows are sized for
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v2f_a4 __attribute__((ext_vector_type(2), aligned(4)));   // a pair at a 4-byte aligned LDS address: two 32-bit reads (ds_read2_b32)
 
 template <int NC>
 __global__ __launch_bounds__(256) void k_deconv_tile(DeconvArgs a, int tiles_y) {
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(256) void k_deconv_tile(DeconvArgs a, int tiles_y) 
             // returns wrong lanes beside matrix + LDS neighbours on gfx950, DESIGN 4.4c / profiles/r05_coresidency.md; a CPU test
             // disassembles the library and rejects it.)
             v2f v[2][2];
-            v[0][1] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty + 1][3 + tx]);   // (left, own): left in the low half
-            v[0][0] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty + 1][4 + tx]);   // (own, right)
-            v[1][1] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty][3 + tx]);
-            v[1][0] = *reinterpret_cast<const v2f *>(&s_in[buf][c][ty][4 + tx]);
+            v[0][1] = *reinterpret_cast<const v2f_a4 *>(&s_in[buf][c][ty + 1][3 + tx]);   // (left, own): left in the low half
+            v[0][0] = *reinterpret_cast<const v2f_a4 *>(&s_in[buf][c][ty + 1][4 + tx]);   // (own, right)
+            v[1][1] = *reinterpret_cast<const v2f_a4 *>(&s_in[buf][c][ty][3 + tx]);
+            v[1][0] = *reinterpret_cast<const v2f_a4 *>(&s_in[buf][c][ty][4 + tx]);
             float wrow[NW];
             const float4 *wp = reinterpret_cast<const float4 *>(&s_w[k * DT_CH + c][0]);   // the same address in every lane: a broadcast read
 #pragma unroll

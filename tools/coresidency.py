@@ -5,8 +5,8 @@ kernels known or suspected to disturb LDS-dependent results of waves sharing the
 for bit with the same launch on a quiet chip.  Two alternating inputs per victim, so that a value left over from the previous
 launch would show.  One process = one setting of the aggressors' LDS claims (lav::lds_claim reads LAV_LDS_EXCLUSIVE once):
 
-    python tools/coresidency.py [launches]                        # claims on (the library's default)
-    LAV_LDS_EXCLUSIVE=0 python tools/coresidency.py [launches]    # exact LDS sizes: victims can share CUs with the aggressors
+    python tools/coresidency.py [launches]                        # exact LDS sizes (the library's default since round 5)
+    LAV_LDS_EXCLUSIVE=1 python tools/coresidency.py [launches]    # round 4's claims: the aggressors take their CU's LDS
     LAV_LDS_EXCLUSIVE=2 ...                                       # every claiming kernel takes the CU's whole LDS (also the two-per-CU ones)
 
 Output: one line per (victim, aggressor): wrong / launches; profiles/r05_coresidency.md is assembled from the two runs.
@@ -151,7 +151,7 @@ aggressors["lds_hog mode 1 (matrix + LDS, 150 KB: 10 KB left per CU)"] = _synth
 
 # ------------------------------------------------------------------------------------------------------------------ run
 s_hog, s_vic = torch.cuda.Stream(), torch.cuda.Stream()
-print(f"# {torch.cuda.get_device_name(0)}  LAV_LDS_EXCLUSIVE={os.environ.get('LAV_LDS_EXCLUSIVE', '(default: 1)')}  launches per cell {N}", flush=True)
+print(f"# {torch.cuda.get_device_name(0)}  LAV_LDS_EXCLUSIVE={os.environ.get('LAV_LDS_EXCLUSIVE', '(default: 0 = exact LDS sizes)')}  launches per cell {N}", flush=True)
 for vname, vic in victims.items():
     if ONLY_V and not any(k in vname for k in ONLY_V):
         continue

@@ -82,6 +82,10 @@ PATTERNS = {
     57: "NO LDS: v_pk_fma_f32 op_sel_hi:[0,1,1], twice",
     58: "NO LDS: plain v_pk_mul_f32 + v_pk_add_f32 op_sel_hi:[1,0], twice",
     59: "NO LDS: v_pk_fma_f32 without modifiers (control), twice",
+    60: "NO LDS: v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (second source swapped), twice",
+    61: "NO LDS: v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (second source swapped), twice",
+    62: "NO LDS: v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (first source swapped), twice",
+    63: "NO LDS: v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] (high register for both results), twice",
     40: "registers at REST: 24 VGPRs written once, the wave sleeps, re-reads them",
     41: "registers at rest while the wave runs an fma chain on other registers",
     32: "15 without sinf / cosf", 33: "15 without expf", 34: "15 without the masked weights (bool masks, s_and_b64, v_cndmask)",
@@ -90,7 +94,7 @@ PATTERNS = {
 }
 if os.environ.get("HAZARD_PATTERNS"):
     PATTERNS = {k: v for k, v in PATTERNS.items() if str(k) in os.environ["HAZARD_PATTERNS"].split(",")}
-PER_ITER = {13: 6, 14: 6, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1, 22: 1, 23: 1, 24: 1, 25: 1, 26: 1, 27: 1, 28: 1, 29: 1, 30: 1, 31: 1, 45: 1, 46: 1, 47: 1, 48: 1, 49: 1, 50: 1, 51: 1, 52: 1, 53: 1, 54: 1, 55: 1, 56: 1, 57: 1, 58: 1, 59: 1, 40: 24, 41: 24, 42: 1, 43: 1, 44: 1, 32: 1, 33: 1, 34: 1, 35: 1, 36: 1, 37: 1, 38: 1, 39: 1, 0: 1, 1: 1, 2: 2, 3: 1, 4: 2, 5: 8, 6: 2, 7: 1, 8: 2, 9: 2, 10: 4, 11: 4, 12: 2}
+PER_ITER = {13: 6, 14: 6, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1, 22: 1, 23: 1, 24: 1, 25: 1, 26: 1, 27: 1, 28: 1, 29: 1, 30: 1, 31: 1, 45: 1, 46: 1, 47: 1, 48: 1, 49: 1, 50: 1, 51: 1, 52: 1, 53: 1, 54: 1, 55: 1, 56: 1, 57: 1, 58: 1, 59: 1, 60: 1, 61: 1, 62: 1, 63: 1, 40: 24, 41: 24, 42: 1, 43: 1, 44: 1, 32: 1, 33: 1, 34: 1, 35: 1, 36: 1, 37: 1, 38: 1, 39: 1, 0: 1, 1: 1, 2: 2, 3: 1, 4: 2, 5: 8, 6: 2, 7: 1, 8: 2, 9: 2, 10: 4, 11: 4, 12: 2}
 NEIGHBOURS = [("alone", None), ("matrix only (hog 0)", 0), ("matrix + LDS (hog 1)", 1), ("LDS only (hog 3)", 3), ("ERFNet 16-ch pair run", "chain16")]
 # the frame's own strongest neighbour: ERFNet's 16-channel persistent pair run (432 row workgroups x 256 threads, 66-80 KB of LDS each:
 # the only matrix + LDS kernel of the frame that leaves tens of KB of LDS free on its CUs) - tools/crop_victim.py
@@ -100,6 +104,13 @@ from lav_amd.ops import Conv1dPair, Conv1dPairChain  # noqa: E402
 _pairs = [Conv1dPair(nn.Conv2d(16, 16, (3, 1), padding=(1, 0)), nn.Conv2d(16, 16, (1, 3), padding=(0, 1)), nn.BatchNorm2d(16, eps=1e-3).eval(), device="cuda") for _ in range(10)]
 _chain = Conv1dPairChain(_pairs, [i % 2 == 1 for i in range(10)])
 _cx = torch.randn((3, 16, 144, 128), device="cuda")
+from lav_amd import _lib as _lavlib  # noqa: E402
+from lav_amd.ops import ConvLayer  # noqa: E402
+_stem = ConvLayer(torch.randn(64, 384, 7, 7) / (384 * 49) ** 0.5, stride=2, padding=(3, 3), relu_post=True, precision=_lavlib.CONV_BF16X6, device="cuda")
+_stem_x = torch.randn(15, 384, 96, 96, device="cuda")
+_c64 = Conv1dPairChain([Conv1dPair(nn.Conv2d(64, 64, (3, 1), padding=(1, 0)), nn.Conv2d(64, 64, (1, 3), padding=(0, 1)), nn.BatchNorm2d(64, eps=1e-3).eval(), device="cuda") for _ in range(10)], [i % 2 == 1 for i in range(10)])
+_c64x = torch.randn((3, 64, 72, 64), device="cuda")
+NEIGHBOURS += [("7x7 stem (split kernel)", "stem"), ("ERFNet 64-ch pair run", "chain64")]
 if os.environ.get("HAZARD_NEIGHBOURS"):
     NEIGHBOURS = [nb for nb in NEIGHBOURS if ("alone" if nb[1] is None else str(nb[1])) in os.environ["HAZARD_NEIGHBOURS"].split(",")]
 s_hog, s_vic = torch.cuda.Stream(), torch.cuda.Stream()
@@ -117,6 +128,12 @@ for p, label in PATTERNS.items():
             if mode == "chain16":
                 with torch.cuda.stream(s_hog):
                     _chain(_cx)
+            elif mode == "stem":
+                with torch.cuda.stream(s_hog):
+                    _stem(_stem_x)
+            elif mode == "chain64":
+                with torch.cuda.stream(s_hog):
+                    _c64(_c64x)
             elif mode is not None:
                 rc = hog.hog_launch(810, 153600, mode, 2000 if mode == 2 else 4000, sink.data_ptr(), s_hog.cuda_stream)
                 assert rc == 0, rc

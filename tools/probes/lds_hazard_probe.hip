@@ -50,6 +50,9 @@
 //  54-59  one packed fp32 instruction each, 48 in a dependent chain: 54 v_pk_mul_f32 op_sel_hi:[0,1] | 55 v_pk_mul_f32 op_sel:[0,1]
 //      op_sel_hi:[0,0] | 56 v_pk_fma_f32 neg_lo:[0,0,1] neg_hi:[0,0,1] | 57 v_pk_fma_f32 op_sel_hi:[0,1,1] | 58 v_pk_add_f32 op_sel_hi:[1,0]
 //      (second source: low half for both) | 59 v_pk_fma_f32 without modifiers (= 27, the control)
+//  60-63  the other packed fp32 forms with an op_sel bit: 60 v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] | 61 v_pk_fma_f32 op_sel:[0,1,0]
+//      op_sel_hi:[1,0,1] | 62 v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (first source swapped) | 63 v_pk_mul_f32 op_sel:[0,1]
+//      op_sel_hi:[1,1] (both results from the second source's HIGH register)
 //  30-31  a lane mask in a GENERAL SGPR pair: 30 v_cmp_gt_f32 s[2:3] -> v_cndmask_b32 ..., s[2:3] back to back | 31 two masks alive at once
 #include <hip/hip_runtime.h>
 
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void k_hazard(int pattern, int iters, unsigned
     const unsigned salt = blockIdx.x * 2654435761u + tid * 40503u;
     auto wr = [](unsigned addr, unsigned v) { asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory"); };
     auto rd = [](unsigned addr) { unsigned v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory"); return v; };
-    if ((pattern >= 16 && pattern <= 31) || (pattern >= 42 && pattern <= 44) || (pattern >= 46 && pattern <= 59)) {
+    if ((pattern >= 16 && pattern <= 31) || (pattern >= 42 && pattern <= 44) || (pattern >= 46 && pattern <= 63)) {
         auto kind = [](int pat, float x, float y) __attribute__((noinline)) {
             float r = x;
             if (pat == 16) {
@@ -200,6 +203,17 @@ __global__ __launch_bounds__(256) void k_hazard(int pattern, int iters, unsigned
                     cs = cs * 0.999f + 0.0001f; sn = sn * 0.998f + 0.0002f;
                 }
                 r = x0 + x1 + t0 + t1 + g0 + g1;
+            } else if (pat >= 60 && pat <= 63) {
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f a = v2f{x, y}, b = v2f{0.99f - 0.01f * y, 0.98f + 0.01f * x}, c = v2f{0.01f * x, -0.01f * y};
+#pragma unroll
+                for (int i = 0; i < 48; ++i) {
+                    if (pat == 60) asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(a) : "v"(b), "v"(c));
+                    else if (pat == 61) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(a) : "v"(b), "v"(c));
+                    else if (pat == 62) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[1,0] op_sel_hi:[0,1]\n\tv_pk_add_f32 %0, %0, %2" : "+v"(a) : "v"(b), "v"(c));
+                    else asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]\n\tv_pk_add_f32 %0, %0, %2" : "+v"(a) : "v"(b), "v"(c));
+                }
+                r = a[0] + a[1];
             } else if (pat >= 54 && pat <= 59) {
                 typedef float v2f __attribute__((ext_vector_type(2)));
                 v2f a = v2f{x, y}, b = v2f{0.99f - 0.01f * y, 0.98f + 0.01f * x}, c = v2f{0.01f * x, -0.01f * y};
