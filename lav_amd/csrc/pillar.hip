@@ -95,13 +95,14 @@ struct PillarArgs {   // scalars first: they share the first cache line of the k
     int NUP;     // stride of one sub-counter array = number of units rounded up to 4 (16-byte loads)
     int cap;     // records per (unit, sub) bucket
     int nwg;     // workgroups of k_rows (classes of the unit ownership)
+    int rstride; // dwords between records (rec_stride_host)
     unsigned long long *trace;  // debug (LAV_PILLAR_TRACE): [workgroups][16] wall-clock stamps of thread 0, else null
     int n[MAX_BATCH];
 };
 
 // What k_rows needs of the above: small enough to arrive with the first kernel-argument fetch.
 struct RowsArgs {
-    int batch, nx, ny, UPR, NUP, cap;
+    int batch, nx, ny, UPR, NUP, cap, rstride;
     float min_x, min_y, ppm;
     const int *perm;   // perm[workgroup] = ownership class it works on (written by k_bin from the previous call's loads)
     int *load;         // load[class] = points the class held in this call (the next call's hint)
@@ -110,7 +111,14 @@ struct RowsArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int rec_size(int D) { return D + 1 <= 8 ? 8 : 12; }  // dwords per record; the last one is the packed cell
+constexpr int rec_size(int D) { return D + 1 <= 8 ? 8 : 12; }  // dwords per record that carry data; the last one is the packed cell
+// dwords from one record to the next.  Round 5: 64-byte records for the 11-float points (LAV_PILLAR_REC=48 restores 48): a 48-byte
+// record straddles 64-byte sectors, every bucket write was a partial-sector write (k_bin wrote 1.9x its records' bytes, r04_pmc_pillar).
+constexpr int REC_STRIDE_MAX = 16;
+inline int rec_stride_host(int D) {
+    static const bool wide = [] { const char *e = getenv("LAV_PILLAR_REC"); return !(e && atoi(e) == 48); }();
+    return rec_size(D) == 12 && wide ? 16 : rec_size(D);
+}
 
 // PointNet weights in the order the matrix instructions of k_rows consume them, one float4 per lane and fragment row:
 //   rows 0 .. KS1-1      layer-1 A operand of k-step s, the four 16-channel tiles:  W1[4s + lg][16 ct + lp]  (bias at k = K1)
@@ -144,9 +152,26 @@ __global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ s
                                              float *__restrict__ buckets, float *__restrict__ ovf, int *__restrict__ key_out,
                                              const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
                                              const float *__restrict__ b2, float *__restrict__ wpack, const int *__restrict__ load,
-                                             int *__restrict__ perm) {
+                                             int *__restrict__ perm, float *__restrict__ canvas, long canvas_floats, int nzero) {
     constexpr int RS = rec_size(D);
     const int nbin = max(1, (int)(((long)a.batch * a.max_points + 255) / 256));   // workgroups that bin points
+    const int nrank = (a.nwg + 63) / 64;                                           // workgroups that rank the ownership classes
+    if ((int)blockIdx.x >= nbin + nrank) {
+        // Round 5: the LAST `nzero` workgroups stream zeros over the whole canvas while the others bin (binning is a chain of
+        // latencies - launch, points, one returning atomic, record stores - that leaves HBM idle: the 26 MB of zeros cost this kernel
+        // ~1 us and take 60 % of the bytes out of k_rows, which then writes only the 16-byte quads that points touched).  The kernel
+        // boundary orders these stores before k_rows' (same stream): write-after-write needs nothing else.
+        const long z = (long)((int)blockIdx.x - nbin - nrank) * 256 + threadIdx.x, stride = (long)nzero * 256;
+        if ((reinterpret_cast<uintptr_t>(canvas) & 15) == 0) {
+            f32x4 *c4 = reinterpret_cast<f32x4 *>(canvas);
+            const long n4 = canvas_floats >> 2;
+            for (long i = z; i < n4; i += stride) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, c4 + i);
+            for (long i = (n4 << 2) + z; i < canvas_floats; i += stride) canvas[i] = 0.f;
+        } else {
+            for (long i = z; i < canvas_floats; i += stride) canvas[i] = 0.f;
+        }
+        return;
+    }
     if ((int)blockIdx.x >= nbin) {
         // Extra workgroups (past the ones that bin points): which ownership class each workgroup of k_rows takes.  The point
         // count of a class barely changes from one LiDAR frame to the next, so the loads k_rows recorded in the PREVIOUS call
@@ -227,12 +252,13 @@ __global__ __launch_bounds__(256) void k_bin(PillarArgs a, State *__restrict__ s
     v[RS - 1] = __int_as_float((b << 24) | (xi << 12) | yi);
     float *o;
     if (slot < a.cap) {
-        o = buckets + (((size_t)unit * NSUB + sub) * a.cap + slot) * RS;
+        o = buckets + (((size_t)unit * NSUB + sub) * a.cap + slot) * a.rstride;
     } else {
-        o = ovf + (size_t)atomicAdd(&st->n_ovf[set], 1) * RS;
+        o = ovf + (size_t)atomicAdd(&st->n_ovf[set], 1) * a.rstride;
     }
 #pragma unroll
     for (int q = 0; q < RS / 4; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    if (a.rstride > RS) reinterpret_cast<float4 *>(o)[RS / 4] = make_float4(0.f, 0.f, 0.f, 0.f);   // the whole 64-byte sector is written
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
@@ -268,7 +294,8 @@ struct Group {
 };
 constexpr int NBKT = GMAX * NSUB;  // buckets of a group
 
-template <int D, bool USE_MFMA, bool VEC4, bool TRACE = false>
+// ZB: the canvas arrives ZERO-FILLED (k_bin's zero workgroups): nothing is written but the quads of columns that points touched.
+template <int D, bool USE_MFMA, bool VEC4, bool TRACE = false, bool ZB = false>
 __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__ st, int *__restrict__ counters,
                                                  const float *__restrict__ buckets, const float *__restrict__ ovf,
                                                  const float *__restrict__ w1, const float *__restrict__ b1,
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         const int q = (i >= p0.y) + (i >= p0.z) + (i >= p0.w) + (i >= p1.x) + (i >= p1.y) + (i >= p1.z) + (i >= p1.w) + (i >= p2.x) +
                       (i >= p2.y) + (i >= p2.z) + (i >= p2.w) + (i >= p3.x) + (i >= p3.y) + (i >= p3.z) + (i >= p3.w);
         const size_t unit = (size_t)w + (size_t)(g.first + q / NSUB) * W;
-        return buckets + ((unit * NSUB + q % NSUB) * a.cap + (i - gpre[wid][g.slot][q])) * RS;
+        return buckets + ((unit * NSUB + q % NSUB) * a.cap + (i - gpre[wid][g.slot][q])) * a.rstride;
     };
     auto load_rec = [&](const float *p, float4 (&r)[RQ]) {
 #pragma unroll
@@ -422,6 +449,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         // border).
         auto store_units = [&](auto FROM_LDS_) {
             constexpr bool FROM_LDS = decltype(FROM_LDS_)::value;
+            if constexpr (ZB && !FROM_LDS) return;   // the zeros are already there
             const int un0 = w + g.first * W;
             const int rb0 = un0 / a.UPR;
             int cu = un0 - rb0 * a.UPR, b = rb0 / a.ny, r = rb0 - b * a.ny;
@@ -447,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                                 for (int h = 0; h < 2; ++h) val[h] = *reinterpret_cast<const float4 *>(tile + (ch0 + 32 * h) * TS + k * UW + 4 * j4);
                             }
                         }
-                        if (4 * j4 < wd) {
+                        if (4 * j4 < wd && (!ZB || ((flags >> k) & 1))) {
 #pragma unroll
                             for (int h = 0; h < 2; ++h)
                                 __builtin_nontemporal_store(f32x4{val[h].x, val[h].y, val[h].z, val[h].w},
@@ -457,10 +485,12 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                         for (int idx = tid; idx < C * wd; idx += 256) {
                             const int ch = idx / wd, j = idx - ch * wd;
                             float val = 0.f;
+                            bool touched = false;
                             if constexpr (FROM_LDS) {
-                                if (occ4[(k * UW + j) >> 2] == gi + 1) val = tile[ch * TS + k * UW + j];
+                                touched = occ4[(k * UW + j) >> 2] == gi + 1;
+                                if (touched) val = tile[ch * TS + k * UW + j];
                             }
-                            dst[ch * cstride + j] = val;
+                            if (!ZB || touched) dst[ch * cstride + j] = val;
                         }
                     }
                 }
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                     add_point(s0.x, s0.y, s0.z, __float_as_int(s1.w), true, -1);
                 }
                 for (int i = tid; i < n_ovf; i += 256) {
-                    const float *p = ovf + (size_t)i * RS;
+                    const float *p = ovf + (size_t)i * a.rstride;
                     const float4 s0 = reinterpret_cast<const float4 *>(p)[0];
                     const float4 s1 = reinterpret_cast<const float4 *>(p)[RQ - 1];
                     add_point(s0.x, s0.y, s0.z, __float_as_int(s1.w), false, -1);
@@ -600,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                     if (last_layer) prefetch_next();
                     for (int i = tid; i < g.n + n_ovf; i += 256) {
                         float4 rq[RQ];
-                        load_rec(i < g.n ? rec_ptr(g, i) : ovf + (size_t)(i - g.n) * RS, rq);
+                        load_rec(i < g.n ? rec_ptr(g, i) : ovf + (size_t)(i - g.n) * a.rstride, rq);
                         float v[RS];
 #pragma unroll
                         for (int q = 0; q < RQ; ++q) { v[4 * q] = rq[q].x; v[4 * q + 1] = rq[q].y; v[4 * q + 2] = rq[q].z; v[4 * q + 3] = rq[q].w; }
@@ -628,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
                 } else {
                     // (b) jobs of 16 records; virtual job v runs on wave (v + rot) & 3
                     auto job_ptr = [&](int j) {
-                        return j < JA ? rec_ptr(g, min(16 * j + lp, g.n - 1)) : ovf + (size_t)min(16 * (j - JA) + lp, n_ovf - 1) * RS;
+                        return j < JA ? rec_ptr(g, min(16 * j + lp, g.n - 1)) : ovf + (size_t)min(16 * (j - JA) + lp, n_ovf - 1) * a.rstride;
                     };
                     int v = v0;
                     float4 cur[RQ];
@@ -936,8 +966,8 @@ size_t carve(Arena &ar, Workspace &w, int batch, int max_points, const lav_grid 
     w.totals = ar.take<int>(4);
     w.cell_sums = ar.take<unsigned long long>((ncells < total ? ncells : total) * 3 + 3);
     if (with_buckets) {
-        w.buckets = ar.take<float>(nunits * NSUB * w.cap * 12);
-        w.ovf = ar.take<float>(total * 12 + 12);
+        w.buckets = ar.take<float>(nunits * NSUB * w.cap * REC_STRIDE_MAX);
+        w.ovf = ar.take<float>(total * REC_STRIDE_MAX + REC_STRIDE_MAX);
     } else {
         w.buckets = w.ovf = nullptr;
     }
@@ -1008,8 +1038,15 @@ template <int D>
 int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, bool want_keys, hipStream_t st) {
     const long total = (long)a.batch * a.max_points;
     const int tok_prep = timer_begin("pillar_prep", st);
-    hipLaunchKernelGGL((k_bin<D>), dim3((unsigned)(std::max(1l, (total + 255) / 256) + (a.nwg + 63) / 64)), dim3(256), 0, st, a, w.state, w.counters, w.buckets,
-                       w.ovf, want_keys ? w.key : nullptr, net->w1, net->b1, net->w2, net->b2, w.wpack, w.load, w.perm);
+    // where the canvas' zeros come from: k_rows streams them itself (default) | LAV_PILLAR_ZERO=bin: extra workgroups of k_bin fill the
+    // whole canvas while the others bin, k_rows writes only the quads that points touched.  Built in round 5,
+    // bit-exact, measured SLOWER: config #2 stage 25.1-25.4 -> 27.9-28.1 us (k_bin 7.3 -> 9.2, k_rows 18.0 -> 18.7: taking 60 % of the
+    // bytes out of k_rows does not shorten it - it is not store bound; profiles/r05_pillar_experiments.txt).  Kept as the A/B knob.
+    static const bool zero_in_bin = [] { const char *e = getenv("LAV_PILLAR_ZERO"); return e && e[0] == 'b'; }();
+    const long canvas_floats = (long)a.batch * C * a.ny * a.nx;
+    const int nzero = zero_in_bin ? (int)std::min<long>(2 * persistent_workgroups(), std::max<long>(1, canvas_floats / 1024)) : 0;
+    hipLaunchKernelGGL((k_bin<D>), dim3((unsigned)(std::max(1l, (total + 255) / 256) + (a.nwg + 63) / 64 + nzero)), dim3(256), 0, st, a, w.state, w.counters, w.buckets,
+                       w.ovf, want_keys ? w.key : nullptr, net->w1, net->b1, net->w2, net->b2, w.wpack, w.load, w.perm, canvas, canvas_floats, nzero);
     timer_end(tok_prep, st);
     LAV_LAUNCH_CHECK();
     const int W = a.nwg;
@@ -1018,7 +1055,7 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     static unsigned long long *d_trace = nullptr;
     static int trace_runs = 0;
     RowsArgs at;
-    at.batch = a.batch; at.nx = a.nx; at.ny = a.ny; at.UPR = a.UPR; at.NUP = a.NUP; at.cap = a.cap;
+    at.batch = a.batch; at.nx = a.nx; at.ny = a.ny; at.UPR = a.UPR; at.NUP = a.NUP; at.cap = a.cap; at.rstride = a.rstride;
     at.min_x = a.min_x; at.min_y = a.min_y; at.ppm = a.ppm; at.trace = nullptr;
     at.perm = w.perm; at.load = w.load;
 
@@ -1029,8 +1066,14 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     }
     const int tok = timer_begin("pointnet_scatter", st);
 #define LAV_ROWS(MFMA, VEC, TR)                                                                                                 \
-    hipLaunchKernelGGL((k_rows<D, MFMA, VEC, TR>), dim3(W), dim3(256), 0, st, at, w.state, w.counters, w.buckets, w.ovf, net->w1, \
-                       net->b1, net->w2, net->b2, w.wpack, canvas)
+    do {                                                                                                                        \
+        if (zero_in_bin)                                                                                                        \
+            hipLaunchKernelGGL((k_rows<D, MFMA, VEC, TR, true>), dim3(W), dim3(256), 0, st, at, w.state, w.counters, w.buckets, w.ovf, net->w1, \
+                               net->b1, net->w2, net->b2, w.wpack, canvas);                                                     \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_rows<D, MFMA, VEC, TR, false>), dim3(W), dim3(256), 0, st, at, w.state, w.counters, w.buckets, w.ovf, net->w1, \
+                               net->b1, net->w2, net->b2, w.wpack, canvas);                                                     \
+    } while (0)
     if constexpr (D == 11) {   // debug variants exist for the v2 agent's point width only
         if (want_trace && vec4) {
             LAV_ROWS(true, true, true);
@@ -1071,6 +1114,7 @@ int fill_args(PillarArgs &a, const float *points, const int *h_num_points, int b
     a.UPR = w.upr;
     a.NUP = (int)align_up((size_t)batch * grid->ny * w.upr, 4);
     a.cap = w.cap;
+    a.rstride = rec_stride_host(D);
     a.nwg = std::min(std::min(persistent_workgroups(), batch * grid->ny * w.upr), 2048);   // 2048: the pairing tables (load / perm, k_bin's s_key)
     a.trace = nullptr;
     return LAV_OK;
