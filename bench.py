@@ -167,6 +167,15 @@ def train_bench(args):
                         hand_kernels_ms_per_step={n: round(v["ms_per_step"], 3) for n, v in hk["kernels"].items()},
                         note="a step of these GRUs is a 192..400 x 512 x 1536 GEMM: latency-bound, not matrix-bound; the convolutions of the "
                              "step run on MIOpen (BatchNorm + ReLU: the fused lav_bn_train_* pairs): this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
+    if rank == 0 and roofline is not None and hk and "conv_wgrad" in hk["kernels"] and hk["work_per_step"].get("conv_wgrad_flops"):
+        # round 5: the 3x3 stride-1 weight gradients of the BEV backbone and the fused heads convolution on lav_conv_wgrad (bf16x6:
+        # six bf16 matrix products per fp32 product, so the executed rate against the dense bf16 peak is 6x the algorithmic one)
+        k = hk["kernels"]["conv_wgrad"]
+        tf = hk["work_per_step"]["conv_wgrad_flops"] / (k["ms_per_step"] * 1e-3) / 1e12
+        roofline["conv_wgrad"] = dict(bound="mfma", achieved=round(6 * tf, 1), peak=2500.0, unit="TFLOP/s (bf16, executed = 6 x algorithmic)", frac=round(6 * tf / 2500.0, 4),
+                                      fp32_equivalent_tflops=round(tf, 1), ms_per_step=round(k["ms_per_step"], 3), launches_per_step=round(k["calls_per_step"], 1))
+        roofline["note"] = ("round 5: the 3x3 / 7x7 convolutions' forward and stride-1 data gradients are lav_conv2d launches, the large 3x3 weight gradients "
+                            "lav_conv_wgrad; transposed / 1x1 / stride-2-adjoint / small-map weight-gradient convolutions stay on MIOpen")
     if rank == 0 and roofline is not None and hk and "bn_train_fwd" in hk["kernels"]:
         # the fused train-mode BatchNorm + ReLU (+ residual) pairs (lav_bn_train_*): HBM bound, algorithmic bytes = passes over the activation
         for d in ("fwd", "bwd"):

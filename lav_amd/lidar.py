@@ -260,8 +260,8 @@ class LiDARModel(_Engine):
         hs = [getattr(self, n) for n in names]
         if len(hs) == 1 or not features.is_cuda:
             return tuple(h(features) for h in hs)
-        from .train.hipnn import bn_act_many
-        mid = F.conv2d(features, torch.cat([h.net[0].weight for h in hs], dim=0), None, 1, 1)
+        from .train.hipnn import bn_act_many, conv2d
+        mid = conv2d(features, torch.cat([h.net[0].weight for h in hs], dim=0), 1, 1)
         mid = bn_act_many([h.net[2] for h in hs], mid, relu_pre=True)
         outs, off = [], 0
         for h in hs:

@@ -65,12 +65,12 @@ class ResNet(_Engine):
 
     def forward_train(self, x):
         """Train mode (autograd, BatchNorm on batch statistics): plain torch ops over the same modules."""
-        from .train.hipnn import bn_act   # batch-statistics BatchNorm + ReLU (+ identity) as one fused forward / backward pair
-        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu_post=True))
+        from .train.hipnn import bn_act, conv_module as cv   # fused BatchNorm + ReLU (+ identity); convolutions on liblav_amd (round 5)
+        x = self.maxpool(bn_act(self.bn1, cv(self.conv1, x), relu_post=True))
         for i in range(1, 5):
             for blk in getattr(self, f"layer{i}"):
                 identity = x if blk.downsample is None else bn_act(blk.downsample[1], blk.downsample[0](x))
-                x = bn_act(blk.bn2, blk.conv2(bn_act(blk.bn1, blk.conv1(x), relu_post=True)), relu_post=True, residual=identity)
+                x = bn_act(blk.bn2, cv(blk.conv2, bn_act(blk.bn1, cv(blk.conv1, x), relu_post=True)), relu_post=True, residual=identity)
         return x
 
     def forward(self, x):

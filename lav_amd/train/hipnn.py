@@ -121,5 +121,114 @@ def conv_relu_bn(seq, x):
     if len(mods) % 3:
         raise RuntimeError("expected [conv, relu, bn] triples")
     for j in range(0, len(mods), 3):
-        x = bn_act(mods[j + 2], mods[j](x), relu_pre=True)
+        c = mods[j]
+        y = conv_module(c, x) if isinstance(c, torch.nn.Conv2d) else c(x)    # (transposed convolutions: torch / MIOpen)
+        x = bn_act(mods[j + 2], y, relu_pre=True)
     return x
+
+
+# ------------------------------------------------------------------------------------------------------------------ convolutions
+# Round 5: the training graph's 3x3 / 7x7 convolutions on liblav_amd's own kernels.
+#   forward        lav_conv2d (split-operand bf16x6 / fp32 plans, the inference kernels) over the LIVE parameter: the packed weights are
+#                  re-gathered on the device before the launch (lav_conv_repack through the layer's index map: one small launch)
+#   data gradient  the same kernel on the adjoint problem - a transposed convolution with the same weight tensor (stride 1 only: the
+#                  stride-2 adjoints lose against MIOpen, profiles/r03_train_conv_probe.txt, and stay there)
+#   weight gradient lav_conv_wgrad (bf16x6 matrix-core kernel, csrc/conv_wgrad.hip) for stride-1 3x3 layers on 16-pixel aligned rows -
+#                  the BEV backbone and the fused heads convolution, where the step spends its convolution time -, torch / MIOpen for
+#                  the rest (LAV_TRAIN_WGRAD=torch: everywhere)
+# LAV_TRAIN_CONV=torch routes everything back to torch.nn.functional (A/B timing, the CPU tests).
+_CONV_ENGINES = {}
+
+
+def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding):
+    """One ConvLayer per (role, geometry, device, stream): the packed buffer is overwritten by every refresh, which is safe because
+    pack and launch are stream-ordered and nothing keeps the packed weights beyond its launch."""
+    from ..ops import ConvLayer
+    dev = w.device
+    key = (kind, tuple(w.shape), int(stride), tuple(padding), tuple(dilation), bool(transposed), int(output_padding), dev,
+           torch.cuda.current_stream(dev).cuda_stream)
+    eng = _CONV_ENGINES.get(key)
+    if eng is None:
+        eng = ConvLayer(w.detach(), stride=stride, padding=tuple(padding), dilation=tuple(dilation), transposed=transposed,
+                        output_padding=output_padding, device=dev)
+        _CONV_ENGINES[key] = eng
+    eng._src["weight"] = w.detach()
+    eng.refresh()
+    return eng
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, dilation):
+        x = x.contiguous()
+        y = _conv_engine("fwd", w, stride, padding, dilation, False, 0)(x)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, dilation)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = None
+        lav_dgrad = stride == 1 and os.environ.get("LAV_TRAIN_DGRAD", "hip") != "torch"
+        if ctx.needs_input_grad[0] and lav_dgrad:
+            kh, kw = w.shape[2], w.shape[3]
+            oph = x.shape[2] - ((dy.shape[2] - 1) * stride - 2 * padding[0] + dilation[0] * (kh - 1) + 1)
+            dx = _conv_engine("dgrad", w, stride, padding, dilation, True, oph)(dy)
+        need_dx_torch = ctx.needs_input_grad[0] and dx is None
+        dw_hip = None
+        if ctx.needs_input_grad[1]:
+            dw_hip = _wgrad_hip(x, dy, w, stride, padding, dilation)
+        if need_dx_torch or (ctx.needs_input_grad[1] and dw_hip is None):
+            gi, gw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], list(padding), list(dilation), False, [0, 0], 1,
+                                                            [need_dx_torch, ctx.needs_input_grad[1] and dw_hip is None, False])
+            if need_dx_torch:
+                dx = gi
+            if dw_hip is None:
+                dw = gw
+        if dw_hip is not None:
+            dw = dw_hip
+        return dx, dw, None, None, None
+
+
+def _wgrad_hip(x, dy, w, stride, padding, dilation):
+    """Weight gradient on lav_conv_wgrad where the kernel applies, else None."""
+    lib = _lib.load()
+    if os.environ.get("LAV_TRAIN_WGRAD", "hip") == "torch" or not hasattr(lib, "lav_conv_wgrad"):
+        return None
+    cout, cin, kh, kw = w.shape
+    B, _, H, W = x.shape
+    # (maps of at least 80 x 80 pixels: below that a task has too few 16-pixel steps behind its prologue and MIOpen wins -
+    # profiles/r05_wgrad_probe.txt: 128 -> 128 @40x40 181 vs 161 us, 64 -> 64 @24x24 x 96 crops 129 vs 68 us)
+    if not (kh == 3 and kw == 3 and stride == 1 and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and W % 4 == 0 and H * W >= 6400
+            and cin % 64 == 0 and cout % 64 == 0 and dy.shape[2] == H and dy.shape[3] == W):
+        return None
+    dw = torch.empty_like(w)
+    nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W)
+    ws = ops_mod._workspace("conv_wgrad", nbytes, x.device)
+    check(lib.lav_conv_wgrad(_ptr(x), _ptr(dy), B, cin, cout, H, W, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
+    ops_mod.train_work["conv_wgrad_flops"] = ops_mod.train_work.get("conv_wgrad_flops", 0) + 2 * B * H * W * cin * cout * 9
+    return dw
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding=(0, 0), dilation=(1, 1)) -> torch.Tensor:
+    """F.conv2d(x, w, None, stride, padding, dilation) with forward / data gradient / weight gradient on liblav_amd where its
+    kernels apply (kernel >= 3, float32, HBM), torch otherwise."""
+    if isinstance(padding, int):
+        padding = (padding, padding)
+    if isinstance(dilation, int):
+        dilation = (dilation, dilation)
+    if (not x.is_cuda or x.dtype != torch.float32 or w.shape[2] < 3 or not torch.is_grad_enabled()
+            or os.environ.get("LAV_TRAIN_CONV", "hip") == "torch"):
+        return F.conv2d(x, w, None, stride, tuple(padding), tuple(dilation))
+    return _Conv2d.apply(x, w, int(stride), tuple(padding), tuple(dilation))
+
+
+def conv_module(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d forward in train mode through conv2d() above (modules with a bias, groups or anisotropic strides: the module itself)."""
+    if (conv.bias is not None or conv.groups != 1 or conv.stride[0] != conv.stride[1] or conv.padding_mode != "zeros"
+            or not isinstance(conv.padding, tuple)):
+        return conv(x)
+    return conv2d(x, conv.weight, conv.stride[0], conv.padding, conv.dilation)

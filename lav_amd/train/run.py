@@ -87,7 +87,7 @@ def train_loop(what, global_batch, steps, warmup, cfg=None, max_points=None, log
         torch.cuda.synchronize()
         kernels = {}
         for name in ("crop_rotate_backward", "crop_rotate", "gru_seq_forward", "gru_seq_backward", "gru_plan", "scatter_max", "pillar_decorate",
-                     "bn_train_fwd", "bn_train_bwd"):
+                     "bn_train_fwd", "bn_train_bwd", "conv_wgrad", "conv2d"):
             ms, n = ctypes.c_double(), ctypes.c_int()
             lib.lav_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n))
             if n.value:

@@ -467,3 +467,57 @@ def test_cpu_baseline_leg_computes_the_same_step_as_the_gpu_trainer():
     for k, v in gpu.items():
         if isinstance(v, float):
             assert abs(cpu[k] - v) <= 2e-3 * max(1.0, abs(v)), (k, cpu[k], v)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 64, 20, 32), (3, 128, 64, 9, 40), (1, 64, 128, 33, 16), (2, 384, 256, 12, 48), (5, 64, 64, 7, 4)])
+def test_conv_wgrad_vs_float64(B, cin, cout, H, W):
+    """lav_conv_wgrad (round 5: 3x3 stride-1 weight gradient on the bf16 matrix cores, operands split exactly into three bf16 pieces)
+    against the float64 weight gradient of torch's convolution on the CPU: ragged 16-pixel segments (W = 40, 4), blocks of rows with
+    their halo rows (H = 33), several co / ci tiles, the heads' channel counts.  Bar: 2e-6 of sum |dy||x| per weight (what the forward
+    split kernel is held to, tests/test_gpu_glue.py), and run-to-run bit equality (partial sums are added in a fixed order)."""
+    import ctypes as C
+    from lav_amd import _lib
+    from lav_amd.ops import _ptr, _stream, _workspace, check
+    g = torch.Generator().manual_seed(B * 1000 + cin + H)
+    x = torch.randn((B, cin, H, W), generator=g)
+    dy = torch.randn((B, cout, H, W), generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=1, padding=1)
+    mag = torch.nn.grad.conv2d_weight(x.double().abs(), (cout, cin, 3, 3), dy.double().abs(), stride=1, padding=1)
+    lib = _lib.load()
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W)
+    assert nbytes > 0
+    ws = _workspace("conv_wgrad_test", nbytes, DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+        check(lib.lav_conv_wgrad(_ptr(xd), _ptr(dyd), B, cin, cout, H, W, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1]), "the weight gradient must be bit-reproducible"
+    err = ((outs[0].double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
+    assert err < 2e-6, f"max |dw - ref| / sum|dy||x| = {err:.3e}"
+    assert lib.lav_conv_wgrad_workspace_bytes(1, 48, 64, 8, 8) == 0       # 48 input channels: not a multiple of 64
+
+
+@pytest.mark.parametrize("B,cin,cout,k,s,H,W", [(2, 64, 64, 3, 1, 24, 32), (2, 64, 128, 3, 2, 20, 24), (3, 16, 64, 7, 2, 30, 30), (2, 128, 128, 3, 1, 12, 12)])
+def test_training_convolution_function_vs_torch(B, cin, cout, k, s, H, W):
+    """lav_amd.train.hipnn.conv2d - forward on lav_conv2d over the live parameter (device-side repack), data gradient on the adjoint
+    lav_conv2d plan (stride 1) or torch (stride 2), weight gradient on lav_conv_wgrad where it applies - against torch's own
+    convolution and its autograd, values and all gradients within 1e-4 of the largest reference value; a second call after the weight
+    changed in place must see the new weights (the packed buffer is re-gathered on every forward)."""
+    from lav_amd.train.hipnn import conv2d
+    torch.manual_seed(B + cin + k)
+    x = torch.randn((B, cin, H, W), device=DEV, requires_grad=True)
+    w = (torch.randn((cout, cin, k, k), device=DEV) / (cin * k * k) ** 0.5).requires_grad_(True)
+    for rep in range(2):
+        y = conv2d(x, w, s, (k // 2, k // 2))
+        dy = torch.randn_like(y)
+        gx, gw = torch.autograd.grad(y, (x, w), dy)
+        xr, wr = x.detach().cpu().double().requires_grad_(True), w.detach().cpu().double().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, wr, None, s, k // 2)
+        gxr, gwr = torch.autograd.grad(yr, (xr, wr), dy.cpu().double())
+        for name, got, want in (("y", y, yr), ("dx", gx, gxr), ("dw", gw, gwr)):
+            tol = 1e-4 * want.abs().max().item()
+            assert (got.detach().cpu().double() - want.detach()).abs().max().item() < tol, (name, rep)
+        with torch.no_grad():
+            w.mul_(0.5).add_(0.01)
