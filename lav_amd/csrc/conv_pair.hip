@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                     ok = fu >= p && fd >= p;
                     if (!ok) {
                         // never hang the device: a row that gives up raises the launch's abort word (sticky[2], cleared by k_zero_ints), every
-                        // other row sees it within 64 polls and leaves too, and k_chain_poison - next on the stream - voids the run's output
+                        // other row that still waits sees it within 64 polls and leaves too; each of them voids its row of the output (below)
                         ++spins;
                         const bool timed_out = spins > a.spin_limit;
                         const bool peer_gone = !timed_out && (spins & 63) == 0 && __hip_atomic_load(a.sticky + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -648,7 +648,15 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
                 }
             }
             __syncthreads();
-            if (*(volatile int *)&s_abort) return;   // (uniform after the barrier; the run's output is void)
+            if (*(volatile int *)&s_abort) {
+                // (uniform after the barrier.)  This row stops HERE - it never computes on a neighbour row that was not published and never
+                // raises its own counter again - and voids its row of the run's result: the output then holds rows that completed every
+                // pair (correct) and NaN rows, nothing computed from stale data.  NaN spreads through the layers behind the run (the
+                // frame's non-finite check counts it; the reference agent's rule for NaN waypoints applies).
+                float *o = a.out[a.npairs - 1] + (long)n * C * plane + (long)y * W;
+                for (int i = tid; i < C * W; i += 256 * KS) o[(long)(i / W) * plane + (i % W)] = __uint_as_float(0x7fc00000u);
+                return;
+            }
             CH_MARK(1);
             stage_rows(a.out[p - 1], dA, std::false_type{}, true);
             CH_MARK(2);
@@ -982,13 +990,7 @@ __global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *launches)
     if (i < n) p[i] = 0;
     if (i == 0) { atomicAdd(launches, 1); launches[1] = 0; }   // launches = sticky + 1; sticky[2] = this launch's abort word
 }
-// Behind every persistent run: a run in which a row gave up is VOID - its last output becomes NaN as a whole, so that a segmentation
-// computed on stale neighbour rows can never pass for one (it propagates through painting and the BEV network to waypoints the
-// agent refuses, as the plan kernel's poison does; the frame's non-finite check counts it).
-__global__ __launch_bounds__(256) void k_chain_poison(const int *__restrict__ abort_word, float *__restrict__ out, long n) {
-    if (*abort_word == 0) return;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = __uint_as_float(0x7fc00000u);
-}
+
 }  // namespace
 
 extern "C" size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h) {
@@ -1088,7 +1090,6 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
     LAV_CHAIN_CASE(1, 1) LAV_CHAIN_CASE(1, 2) LAV_CHAIN_CASE(2, 1) LAV_CHAIN_CASE(2, 2)
     }
 #undef LAV_CHAIN_CASE
-    hipLaunchKernelGGL(k_chain_poison, dim3(64), dim3(256), 0, st, a.sticky + 2, a.out[npairs - 1], (long)batch * channels * h * w);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

@@ -22,6 +22,7 @@
 //               stay in flight across it.
 //   reduction   every task writes its 64 x 64 x 9 partial sums; lav_conv_wgrad's second launch adds the partials of a tile in slice
 //               order (deterministic, no atomics) and writes dW in PyTorch layout.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -212,18 +213,34 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     dw[((long)co * cin + ci) * 9 + t] = s;
 }
 
-int wgrad_blocks(int B, int cin, int cout, int H) {
-    // enough tasks to fill the chip a few times over, blocks of at least 8 rows (every block re-stages two rows per segment)
-    const int tiles = (cin / T_CI) * (cout / T_CO);
-    int nb = 1;
-    while ((long)tiles * B * nb < 1024 && (H + nb) / (nb + 1) >= 8) ++nb;
-    return nb;
+int wgrad_blocks(int B, int cin, int cout, int H, int W) {
+    // Blocks of rows per image, by a cost in steps: a task walks nseg x (rows + 3) steps (three prologue steps per segment fill the row
+    // ring), the chip runs one task per CU at a time.  tools/wgrad_probe.py: 64 -> 64 @160 x 32 images 738 us at 20 blocks of 8 rows
+    // (640 tasks: three rounds, 27 % prologue) against 460 us at 8 blocks of 20 rows (256 tasks: one round).
+    static const int cus = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        return v > 0 ? v : 256;
+    }();
+    const long tiles = (long)(cin / T_CI) * (cout / T_CO);
+    const int nseg = (W + PX - 1) / PX;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int nb = 1; nb <= H; ++nb) {
+        const int rows = (H + nb - 1) / nb;
+        if (rows < 4 && nb > 1) break;
+        const long tasks = tiles * B * nb;
+        if (tasks > 65535l * tiles) break;
+        const double cost = (double)((tasks + cus - 1) / cus) * nseg * (rows + 3) + 0.5 * nb;   // (+ the reduce launch reads nb partials)
+        if (cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
 }
 }  // namespace
 
 extern "C" size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || cin % T_CI || cout % T_CO) return 0;
-    const int nb = wgrad_blocks(batch, cin, cout, h);
+    const int nb = wgrad_blocks(batch, cin, cout, h, w);
     return (size_t)batch * nb * (cin / T_CI) * (cout / T_CO) * 9 * T_CO * T_CI * sizeof(float);
 }
 
@@ -245,7 +262,7 @@ extern "C" int lav_conv_wgrad(const float *x, const float *dy, int batch, int ci
     a.x = x; a.dy = dy; a.partial = static_cast<float *>(workspace);
     a.B = batch; a.cin = cin; a.cout = cout; a.H = h; a.W = w;
     a.nseg = (w + PX - 1) / PX;
-    a.nblocks = wgrad_blocks(batch, cin, cout, h);
+    a.nblocks = wgrad_blocks(batch, cin, cout, h, w);
     a.rows_per_block = (h + a.nblocks - 1) / a.nblocks;
     a.ntile_ci = cin / T_CI; a.ntiles = a.ntile_ci * (cout / T_CO);
     const int nslices = batch * a.nblocks;

@@ -670,7 +670,7 @@ def _cu_count(device) -> int:
 # algorithmic work of the training-side kernels since the last reset (bench.py's training roofline reads it next to the
 # library's HIP-event timers): bytes the crop gradient must move, flops of the recurrent GEMMs
 train_work = {"crop_rotate_backward_bytes": 0, "crop_rotate_backward_calls": 0, "gru_seq_forward_flops": 0, "gru_seq_backward_flops": 0,
-              "bn_train_fwd_bytes": 0, "bn_train_bwd_bytes": 0}
+              "bn_train_fwd_bytes": 0, "bn_train_bwd_bytes": 0, "conv_wgrad_flops": 0}
 
 
 class _CropRotateIndexed(torch.autograd.Function):

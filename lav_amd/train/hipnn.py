@@ -200,9 +200,9 @@ def _wgrad_hip(x, dy, w, stride, padding, dilation):
         return None
     cout, cin, kh, kw = w.shape
     B, _, H, W = x.shape
-    # (maps of at least 80 x 80 pixels: below that a task has too few 16-pixel steps behind its prologue and MIOpen wins -
-    # profiles/r05_wgrad_probe.txt: 128 -> 128 @40x40 181 vs 161 us, 64 -> 64 @24x24 x 96 crops 129 vs 68 us)
-    if not (kh == 3 and kw == 3 and stride == 1 and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and W % 4 == 0 and H * W >= 6400
+    # (maps of at least 40 x 40 pixels: below that a task has too few 16-pixel steps behind its prologue and MIOpen wins -
+    # profiles/r05_wgrad_probe.txt: 64 -> 64 @24x24 x 96 crops 92 vs 68 us)
+    if not (kh == 3 and kw == 3 and stride == 1 and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and W % 4 == 0 and H * W >= 1600
             and cin % 64 == 0 and cout % 64 == 0 and dy.shape[2] == H and dy.shape[3] == W):
         return None
     dw = torch.empty_like(w)

@@ -586,6 +586,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["train_curve_b8"]:     # config #5's cloud size at batch 8, 100 steps (about an hour of CPU time)
         gold_train_curve(steps=int(os.environ.get("LAV_CURVE_STEPS", "100")), name="train_curve_b8", batch=8, points=120000, nbatches=2, seed0=60)
         sys.exit(0)
+    if sys.argv[1:] == ["train_curve_b32"]:    # config #5 AS STATED: batch 32 x 120 000-point clouds, 25 steps (round 5; ~4 min of CPU per step)
+        gold_train_curve(steps=int(os.environ.get("LAV_CURVE_STEPS", "25")), name="train_curve_b32", batch=32, points=120000, nbatches=1, seed0=80)
+        sys.exit(0)
     if sys.argv[1:] == ["datasets"]:     # only the data-loader fixture
         gold_datasets()
         sys.exit(0)

@@ -378,8 +378,12 @@ def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):
     monkeypatch.delenv("LAV_CHAIN_SPIN_LIMIT")
     t1, n1 = ops.pair_chain_status(DEV)
     assert n1 == n0 + 1 and t1 > t0, "108 rows never finish a pair at the same instant: some workgroup must have given up"
-    # round 5: a run in which a row gave up is poisoned as a whole - rows computed on stale neighbours never pass for a result
-    assert torch.isnan(void).all(), "an aborted persistent run must return NaN, not a partly stale map"
+    # round 5: a row that gives up (or sees that another one did) stops computing and voids its row of the result - the
+    # output holds rows that completed every pair (bit-identical to the good run) and NaN rows, nothing computed from stale neighbours
+    nan_rows = torch.isnan(void).all(dim=3).all(dim=1)                     # (batch, h)
+    same_rows = (void == good).all(dim=3).all(dim=1)
+    assert bool((nan_rows | same_rows).all()), "every row is either complete and right, or void"
+    assert bool(nan_rows.any()), "an aborted persistent run must not look like a result"
     back = chain(x)
     torch.cuda.synchronize()
     t2, n2 = ops.pair_chain_status(DEV)

@@ -244,18 +244,32 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     print(f"loss curve over {steps} steps: reference {smooth(tot_r, 25)[0]:.1f} -> {final_r:.1f}, MI355X {smooth(tot_o, 25)[0]:.1f} -> {final_o:.1f}; "
           f"deviation of the smoothed total: first 60 steps {early.max():.3f}, 100-step average {whole.max():.3f}")
     assert final_r < 0.3 * smooth(tot_r, 25)[0], "the reference run must actually learn for the comparison to mean something"
-    # Bars on the TOTAL follow what was measured across sessions (MIOpen picks its solvers by timing, so even the deterministic
-    # mode differs from session to session): first 60 smoothed steps 0.015-0.017 in four sessions and 0.057 in a fifth, 100-step
-    # average 0.25-0.375, final level 0.63-0.75x.  The CPU port of this very trainer alone spans 0.87-1.08x with a 103 % excursion
-    # (profiles/r04_loss_curve_bisect.md): the total is a chaotic observable - the tight bars are on the terms that are not, below.
-    assert early.max() < 0.10, f"the first 60 smoothed steps leave the band: {early.max():.3f}"
-    assert whole.max() < 0.60, f"the 100-step moving average leaves the band: {whole.max():.3f}"
-    assert 0.45 * final_r < final_o < 1.35 * final_r, f"final level {final_o:.2f} vs the reference's {final_r:.2f}"
-    # Per term (round 4, profiles/r04_loss_curve_bisect.md): the heat-map, segmentation and command terms are reproducible observables -
-    # every run measured, on the MI355X and on the CPU, holds the reference's 100-step average within 2 % over all 500 steps; the
-    # trajectory-forecast terms within 10-26 %.  (box / ori / plan are the chaotic ones: the CPU port of this very trainer, run with
-    # 3 instead of 4 threads, leaves the reference's average by up to 168 % - their bars are the total's, above.)
-    for k, bar in (("hm_loss", 0.05), ("seg_loss", 0.05), ("cmd_loss", 0.05), ("ego_cast_loss", 0.45), ("other_cast_loss", 0.45)):
+    # Round 5: bars from an ENVELOPE instead of bars widened to fit.  tests/golden/train_curve_envelope.npz holds the
+    # CPU port of this very trainer (torch CPU ops, tools/curve_cpu.py) run with 2 ... 8 threads: seven more float32 implementations
+    # of the same 500 steps.  Against the reference's single run they end at 0.64x ... 1.08x of its final level (5 and 8 threads: 0.64x -
+    # the level every MI355X session ends near: 0.63-0.75x, which round 4 had taken for a bias), leave its 100-step average by 17-103 %
+    # and its first 60 smoothed steps by 1.2-5.4 % (3 threads: 5.4 %; the one MI355X session at 5.7 % was such a sample too).
+    # The MI355X curve must lie inside what those samples and the reference span, +-10 %: per term and for the total, at every step of
+    # the 100-step moving average, and at the end.
+    env = golden["train_curve_envelope"]["curves"]                          # (samples, 500, 8)
+    assert [str(k) for k in golden["train_curve_envelope"]["keys"]] == keys and env.shape[0] >= 6 and env.shape[1:] == ref.shape
+    samples = np.concatenate([env, ref[None]], axis=0)
+    sm_tot = np.stack([smooth(c.sum(1), 100) for c in samples])
+    lo, hi = sm_tot.min(0), sm_tot.max(0)
+    so = smooth(tot_o, 100)
+    out_tot = np.maximum(lo * 0.9 - so, so - hi * 1.1).max()
+    assert out_tot <= 0, f"the 100-step average of the total leaves the envelope of the CPU samples by {out_tot:.3f}"
+    finals = samples[:, -100:, :].sum(2).mean(1)
+    assert 0.9 * finals.min() <= final_o <= 1.1 * finals.max(), f"final level {final_o:.2f} outside the samples' {finals.min():.2f} .. {finals.max():.2f}"
+    early_env = max((np.abs(smooth(c.sum(1), 25)[:60] - smooth(tot_r, 25)[:60]) / smooth(tot_r, 25)[:60]).max() for c in env)
+    assert early.max() <= 1.1 * early_env, f"the first 60 smoothed steps leave the reference's by {early.max():.3f} (CPU samples: up to {early_env:.3f})"
+    for j, k in enumerate(keys):
+        st = np.stack([smooth(c[:, j], 100) for c in samples])
+        o = smooth(ours[:, j], 100)
+        out = np.maximum(st.min(0) * 0.9 - 0.002 - o, o - st.max(0) * 1.1 - 0.002).max()   # (0.002: terms that have fallen to ~0.01)
+        assert out <= 0, f"{k}: the 100-step average leaves the envelope of the CPU samples by {out:.4f}"
+    # and the reproducible terms follow the reference itself closely (every run measured, on the MI355X and on the CPU, within 2 %)
+    for k, bar in (("hm_loss", 0.05), ("seg_loss", 0.05), ("cmd_loss", 0.05)):
         j = keys.index(k)
         dev = (np.abs(smooth(ours[:, j], 100) - smooth(ref[:, j], 100)) / smooth(ref[:, j], 100)).max()
         assert dev < bar, f"{k}: 100-step moving average leaves the reference's by {dev:.3f} (bar {bar})"
@@ -305,6 +319,45 @@ def test_train_lidar_loss_curve_batch8_config5_clouds(golden):
     for k in ("hm_loss", "seg_loss", "cmd_loss"):
         assert devs[k] < 0.05, (k, devs[k])
     for k in ("plan_loss", "ego_cast_loss", "other_cast_loss", "box_loss", "ori_loss"):   # measured 0.05-0.12
+        assert devs[k] < 0.30, (k, devs[k])
+
+
+def test_train_lidar_loss_curve_batch32_config5_as_stated(golden):
+    """BASELINE.json config #5 AS STATED - batch 32 x 120 000-point clouds (round 5): 25 steps of the reference trainer on CPU
+    (tests/golden/make_golden.py train_curve_b32, about a minute per step in the build container) against the MI355X trainer on the
+    same batch and weights.  Step 0 is the same arithmetic (2e-3); over 25 steps every term's 5-step average follows the
+    reference's (the bars of the batch-8 test: 5 % perception, 30 % planner terms, 20 % total)."""
+    from lav_amd.train.run import set_deterministic
+    g = golden["train_curve_b32"]
+    ref, keys = g["terms"], [str(k) for k in g["keys"]]
+    B, pts, nb, seed0 = int(g["batch"][0]), int(g["points"][0]), int(g["nbatches"][0]), int(g["seed0"][0])
+    assert (B, pts) == (32, 120000) and len(ref) >= 20
+    set_deterministic(True)
+    try:
+        torch.manual_seed(0)
+        lav = LAV(TrainConfig(log_inference=False), DEV, what="lidar")
+        batches = [synthetic_lidar_batch(B, seed=seed0 + i, max_points=pts, num_objs=3) for i in range(nb)]
+        rows = []
+        for step in range(len(ref)):
+            torch.manual_seed(1000 + step)
+            info = lav.train_lidar(*batches[step % nb])
+            rows.append([info[k] for k in keys])
+    finally:
+        set_deterministic(False)
+    ours = np.array(rows)
+    assert np.isfinite(ours).all()
+    np.testing.assert_allclose(ours[0], ref[0], rtol=2e-3, atol=1e-4, err_msg="step 0")
+    smooth = lambda a, w: np.convolve(a, np.ones(w) / w, mode="valid")
+    tot_o, tot_r = ours.sum(1), ref.sum(1)
+    dev_tot = (np.abs(smooth(tot_o, 5) - smooth(tot_r, 5)) / smooth(tot_r, 5)).max()
+    devs = {k: float((np.abs(smooth(ours[:, j], 5) - smooth(ref[:, j], 5)) / smooth(ref[:, j], 5)).max()) for j, k in enumerate(keys)}
+    print(f"batch-32 curve over {len(ref)} steps: reference {tot_r[0]:.1f} -> {tot_r[-5:].mean():.1f}, MI355X {tot_o[0]:.1f} -> {tot_o[-5:].mean():.1f}; "
+          f"max deviation of the 5-step average: total {dev_tot:.3f}, per term {({k: round(v, 3) for k, v in devs.items()})}")
+    assert tot_r[-5:].mean() < 0.8 * tot_r[0], "the reference run must learn"
+    assert dev_tot < 0.20, f"total loss leaves the reference's 5-step average by {dev_tot:.3f}"
+    for k in ("hm_loss", "seg_loss", "cmd_loss"):
+        assert devs[k] < 0.05, (k, devs[k])
+    for k in ("plan_loss", "ego_cast_loss", "other_cast_loss", "box_loss", "ori_loss"):
         assert devs[k] < 0.30, (k, devs[k])
 
 
