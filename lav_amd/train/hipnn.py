@@ -172,7 +172,7 @@ class _Conv2d(torch.autograd.Function):
         stride, padding, dilation = ctx.cfg
         dy = dy.contiguous()
         dx = dw = None
-        lav_dgrad = stride == 1 and os.environ.get("LAV_TRAIN_DGRAD", "hip") != "torch"
+        lav_dgrad = os.environ.get("LAV_TRAIN_DGRAD", "hip") != "torch" and (stride == 1 or os.environ.get("LAV_TRAIN_DGRAD_STRIDED", "hip") == "hip")
         if ctx.needs_input_grad[0] and lav_dgrad:
             kh, kw = w.shape[2], w.shape[3]
             oph = x.shape[2] - ((dy.shape[2] - 1) * stride - 2 * padding[0] + dilation[0] * (kh - 1) + 1)

@@ -555,7 +555,7 @@ def test_conv_wgrad_vs_float64(B, cin, cout, H, W):
 @pytest.mark.parametrize("B,cin,cout,k,s,H,W", [(2, 64, 64, 3, 1, 24, 32), (2, 64, 128, 3, 2, 20, 24), (3, 16, 64, 7, 2, 30, 30), (2, 128, 128, 3, 1, 12, 12)])
 def test_training_convolution_function_vs_torch(B, cin, cout, k, s, H, W):
     """lav_amd.train.hipnn.conv2d - forward on lav_conv2d over the live parameter (device-side repack), data gradient on the adjoint
-    lav_conv2d plan (stride 1) or torch (stride 2), weight gradient on lav_conv_wgrad where it applies - against torch's own
+    lav_conv2d plan (the transposed convolution with the same weights, strides 1 and 2), weight gradient on lav_conv_wgrad where it applies - against torch's own
     convolution and its autograd, values and all gradients within 1e-4 of the largest reference value; a second call after the weight
     changed in place must see the new weights (the packed buffer is re-gathered on every forward)."""
     from lav_amd.train.hipnn import conv2d
