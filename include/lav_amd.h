@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 23
+#define LAV_ABI_VERSION 24
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -465,19 +465,19 @@ int lav_bn_train_backward(const float *x, const float *y, const float *dy, int b
                           const float *save_mean, const float *save_rstd, int relu_pre, int relu_post, float *dx, float *dres,
                           float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Weight gradient of a 3x3, stride-1, padding-1 convolution (round 5): the weight half of torch.autograd's convolution backward for
+/* Weight gradient of a 3x3, padding-1 convolution of stride 1 or 2, or of a 7x7, padding-3, stride-2 convolution (round 5): the weight half of torch.autograd's convolution backward for
  * the stage convolutions of ConvBackbone (team_code_v2/models/lidar.py:57-108) and the four heads' first convolutions (lidar.py:147-161)
  * inside LAV.train_lidar's backward (lav/lav_final_v2.py:140-259), which the reference runs on cuDNN (here: MIOpen's igemm_wrw).
- *     dw[co][ci][ky][kx] = sum over (n, y, x) of dy[n][co][y][x] * x[n][ci][y + ky - 1][x + kx - 1]      (zero padding)
- * x [batch][cin][h][w], dy [batch][cout][h][w], dw [cout][cin][3][3] (PyTorch layouts, float32, device, 16-byte aligned);
- * cin and cout multiples of 64, w a multiple of 4.  bf16x6 arithmetic on the matrix cores (operands split exactly into three bf16
+ *     dw[co][ci][ky][kx] = sum over (n, y, x) of dy[n][co][y][x] * x[n][ci][stride y + ky - pad][stride x + kx - pad]      (zero padding, pad = ksize / 2)
+ * x [batch][cin][h][w], dy [batch][cout][h / stride][w / stride], dw [cout][cin][ksize][ksize] (PyTorch layouts, float32, device, 16-byte
+ * aligned); cin and cout multiples of 64, w a multiple of 4 (stride 2: h even, w a multiple of 8).  bf16x6 arithmetic on the matrix cores (operands split exactly into three bf16
  * pieces, six partial products, float32 accumulation), partial sums added in a fixed order: bit-reproducible.  The forward and the
  * data gradient of the same layers are lav_conv2d launches (the data gradient as the transposed convolution with the same weight
  * tensor); lav_amd/train/hipnn.py wires the three into one torch.autograd.Function.
  * workspace: lav_conv_wgrad_workspace_bytes (0 = shape not supported), private to the stream. */
-size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w);
-int lav_conv_wgrad(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, float *dw, void *workspace,
-                   size_t workspace_bytes, void *stream);
+size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w, int ksize, int stride);
+int lav_conv_wgrad(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, int ksize, int stride, float *dw,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8. Two stacked 1-D convolutions in one launch - one half of ERFNet's non_bottleneck_1d block

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 MAX_CAM = 4
 
 
@@ -69,8 +69,8 @@ SIGNATURES = {
     "lav_conv_pack_map": (_I, [C.POINTER(Conv), _P]),
     "lav_conv_repack": (_I, [C.POINTER(Conv), _P, _P, _P, _P]),
     "lav_bn_fold": (_I, [_P, _P, _P, _P, C.c_double, _I, _P, _P, _P]),
-    "lav_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
-    "lav_conv_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "lav_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "lav_conv_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "lav_conv_tile_info": (_I, [C.POINTER(Conv), C.POINTER(_I)]),
     "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -1,4 +1,5 @@
-// Weight gradient of the training graph's 3x3 stride-1 convolutions on the bf16 matrix cores (round 5).
+// Weight gradient of the training graph's 3x3 convolutions (stride 1 and 2, padding 1) and of its 7x7 stride-2 stems on the bf16 matrix
+// cores (round 5).
 //
 // Replaces the weight-gradient half of torch.autograd's convolution backward (MIOpen igemm_wrw: the largest kernel family of a
 // train_full step, profiles/r04_train_full_kernel_top.txt) for the layers of LAV.train_lidar that carry the convolution time:
@@ -22,6 +23,10 @@
 //               stay in flight across it.
 //   reduction   every task writes its 64 x 64 x 9 partial sums; lav_conv_wgrad's second launch adds the partials of a tile in slice
 //               order (deterministic, no atomics) and writes dW in PyTorch layout.
+//   stride 2    (the first convolution of every backbone stage: dY[n][co][oy][ox] * X[n][ci][2 oy + ky - 1][2 ox + kx - 1])  k_conv_wgrad_s2:
+//               the same tile, step and accumulators; a step consumes input rows 2 oy - 1, 2 oy, 2 oy + 1, so the loaders stage TWO new
+//               input rows per step into a ring of six slots, and the three kx copies of a row are its odd columns from 2 ox - 1, its even
+//               columns, and its odd columns from 2 ox + 1 (the first and third out of the same loaded registers).  LDS 6 x 18 + 12 KB.
 #include <cstdlib>
 #include <type_traits>
 
@@ -199,21 +204,334 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
         }
 }
 
+// eight floats -> three 16-byte bf16 pieces at dst, dst + ps, dst + 2 ps
+__device__ __forceinline__ void emit8(const float (&f)[8], unsigned char *dst, int ps) {
+    u32x4 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned q0, q1, q2;
+        split3x2(f[2 * e], f[2 * e + 1], q0, q1, q2);
+        p0[e] = q0; p1[e] = q1; p2[e] = q2;
+    }
+    *reinterpret_cast<u32x4 *>(dst) = p0;
+    *reinterpret_cast<u32x4 *>(dst + ps) = p1;
+    *reinterpret_cast<u32x4 *>(dst + 2 * ps) = p2;
+}
+
+constexpr int S2_SLOTS = 6;
+constexpr int LDS_BYTES_S2 = S2_SLOTS * ROW_SLOT + 2 * DY_BUF;   // 120 KB
+
+// Stride 2.  a.H, a.W = the INPUT map (both even), the dY planes are (H/2) x (W/2); rows_per_block / nseg count OUTPUT rows / 16-pixel
+// segments of an output row.  Relative input row rr = input row - (2 y_lo - 1) lives in ring slot rr % 6; iteration j (-2 .. nrows - 1)
+// multiplies output row y_lo + j (j >= 0: slots 2j, 2j+1, 2j+2) while the loaders stage rr = 2j + 3, 2j + 4 and dY row y_lo + j + 1.
+__global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *s_x = smem, *s_dy = smem + S2_SLOTS * ROW_SLOT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, slice = blockIdx.y;
+    const int t_co = tile / a.ntile_ci, t_ci = tile - t_co * a.ntile_ci;
+    const int n = slice / a.nblocks, blk = slice - n * a.nblocks;
+    const int OH = a.H >> 1, OW = a.W >> 1;
+    const int y_lo = blk * a.rows_per_block, y_hi = min(OH, y_lo + a.rows_per_block);
+    const long plane = (long)a.H * a.W, oplane = (long)OH * OW;
+    const float *xn = a.x + ((long)n * a.cin + (long)t_ci * T_CI) * plane;
+    const float *dyn = a.dy + ((long)n * a.cout + (long)t_co * T_CO) * oplane;
+    const int nrows = y_hi - y_lo;
+    const int r_base = 2 * y_lo - 1;   // input row of rr = 0
+    if (wid >= 4) {
+        // ------------------------------------------------------------------------------------------------ loaders
+        // entry (ch, kh) = 8 output pixels x0 .. x0 + 7 of channel ch = input columns c0 + (kx - 1) + 2 e, c0 = 2 x0 (a multiple of 16).
+        // Waves 0, 1 (kh = 0, 1): the ODD columns of both new rows - copies kx = 0 (from c0 - 1: one extra float) and kx = 2;
+        // waves 2, 3: the EVEN columns of both rows (copy kx = 1) and the dY row.
+        const int lt = tid - 256, lw = wid - 4;
+        const int ch = lt & 63, kh = lw & 1;
+        const bool odd_role = lw < 2;
+        float4 vr[2][4];          // the two input rows: columns c0 .. c0 + 15
+        float halo[2];            // column c0 - 1 (odd role)
+        float4 vd[2];             // dY: pixels x0 .. x0 + 7 (even role)
+        bool okr[2], okc[4], okd, okh;
+        auto issue = [&](int seg, int j) {
+            const int x0 = seg * PX + 8 * kh, c0 = 2 * x0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) okc[q] = c0 + 4 * q < a.W;
+            okh = c0 >= 1 && c0 - 1 < a.W;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = r_base + 2 * j + 3 + i;
+                okr[i] = row >= 0 && row < a.H;
+                const float *p = xn + (long)ch * plane + (long)min(max(row, 0), a.H - 1) * a.W;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vr[i][q] = *reinterpret_cast<const float4 *>(p + min(c0 + 4 * q, a.W - 4));
+                if (odd_role) halo[i] = p[min(max(c0 - 1, 0), a.W - 1)];
+            }
+            if (!odd_role) {
+                const int row = y_lo + j + 1;
+                okd = row >= y_lo && row < y_hi;
+                const float *p = dyn + (long)ch * oplane + (long)min(max(row, 0), OH - 1) * OW;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) vd[q] = *reinterpret_cast<const float4 *>(p + min(x0 + 4 * q, OW - 4));
+            }
+        };
+        auto stage = [&](int seg, int j, int base) {   // base = (2 j) mod 6
+            const int x0 = seg * PX + 8 * kh;
+            const int ps = 2 * T_CI * ENTRY;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int slot = base + 3 + i;
+                slot = slot >= S2_SLOTS ? slot - S2_SLOTS : slot;
+                unsigned char *xd = s_x + slot * ROW_SLOT + (kh * T_CI + ch) * ENTRY;
+                float fl[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = okr[i] && okc[q];
+                    fl[4 * q] = ok ? vr[i][q].x : 0.f; fl[4 * q + 1] = ok ? vr[i][q].y : 0.f; fl[4 * q + 2] = ok ? vr[i][q].z : 0.f; fl[4 * q + 3] = ok ? vr[i][q].w : 0.f;
+                }
+                float f[8];
+                if (odd_role) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fl[2 * e + 1];
+                    emit8(f, xd + 2 * ROW_COPY, ps);                           // kx = 2: columns c0 + 1 + 2 e
+#pragma unroll
+                    for (int e = 7; e > 0; --e) f[e] = f[e - 1];
+                    f[0] = okr[i] && okh && okc[0] ? halo[i] : 0.f;            // kx = 0: columns c0 - 1 + 2 e
+                    emit8(f, xd, ps);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fl[2 * e];
+                    emit8(f, xd + ROW_COPY, ps);                               // kx = 1: columns c0 + 2 e
+                }
+            }
+            if (!odd_role) {
+                float f[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool ok = okd && x0 + 4 * q < OW;
+                    f[4 * q] = ok ? vd[q].x : 0.f; f[4 * q + 1] = ok ? vd[q].y : 0.f; f[4 * q + 2] = ok ? vd[q].z : 0.f; f[4 * q + 3] = ok ? vd[q].w : 0.f;
+                }
+                emit8(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
+            }
+        };
+        for (int seg = 0; seg < a.nseg; ++seg) {
+            issue(seg, -2);
+            int base = 2;   // (2 * -2) mod 6
+            for (int j = -2; j < nrows; ++j) {
+                stage(seg, j, base);
+                if (j + 1 < nrows) issue(seg, j + 1);
+                barrier_lds();
+                base = base == 4 ? 0 : base + 2;
+            }
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------------ compute waves
+    const int h = wid & 1, g = wid >> 1;
+    const int l31 = lane & 31, kgrp = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int a_off = (kgrp * T_CO + 32 * h + l31) * ENTRY, b_off = (kgrp * T_CI + 32 * g + l31) * ENTRY;
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        int base = 2;
+        for (int j = -2; j < nrows; ++j) {
+            if (j >= 0) {
+                u32x4 av[3];
+                const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - 3 * ky;
+                    int slot = base + ky;
+                    slot = slot >= S2_SLOTS ? slot - S2_SLOTS : slot;
+                    const unsigned char *pb = s_x + slot * ROW_SLOT + kx * ROW_COPY + b_off;
+                    u32x4 bv[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                    constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t], 0, 0, 0);
+                }
+            }
+            barrier_lds();
+            base = base == 4 ? 0 : base + 2;
+        }
+    }
+    float *out = a.partial + (((long)slice * a.ntiles + tile) * 9) * (T_CO * T_CI);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = 32 * h + 8 * (i >> 2) + 4 * kgrp + (i & 3), ci = 32 * g + l31;
+            out[((long)t * T_CO + co) * T_CI + ci] = acc[t][i];
+        }
+}
+
+// 7x7, stride 2, padding 3 (the ResNet-18 stem of uniplanner's lidar_conv_emb on the 384-channel BEV crops: MIOpen's igemm_wrw spent
+// 3.7 ms on each of its two calls per train_full step).  49 taps x 16 accumulator registers do not fit a wave: a task takes ONE ky (seven
+// taps, 112 registers) of a 64 x 64 tile.  A step = 16 output pixels of one output row = ONE input row (2 oy + ky - 3), staged as seven
+// aligned copies (copy kx = columns 2 ox + kx - 3), double buffered: LDS 2 x 42 + 12 KB.  The four copies of the even kx are
+// shifts of the row's odd columns and the three of the odd kx shifts of its even columns, so a loader thread splits every value into
+// its three bf16 pieces ONCE per pairing (10 or 9 pair conversions for 4 or 3 copies) and only re-packs.
+constexpr int K7_ROW = 7 * ROW_COPY;                         // 42 KB
+constexpr int LDS_BYTES_K7 = 2 * K7_ROW + 2 * DY_BUF;        // 96 KB
+
+__global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *s_x = smem, *s_dy = smem + 2 * K7_ROW;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x / 7, ky = blockIdx.x - 7 * tile, slice = blockIdx.y;
+    const int t_co = tile / a.ntile_ci, t_ci = tile - t_co * a.ntile_ci;
+    const int n = slice / a.nblocks, blk = slice - n * a.nblocks;
+    const int OH = a.H >> 1, OW = a.W >> 1;
+    const int y_lo = blk * a.rows_per_block, y_hi = min(OH, y_lo + a.rows_per_block);
+    const long plane = (long)a.H * a.W, oplane = (long)OH * OW;
+    const float *xn = a.x + ((long)n * a.cin + (long)t_ci * T_CI) * plane;
+    const float *dyn = a.dy + ((long)n * a.cout + (long)t_co * T_CO) * oplane;
+    const int nrows = y_hi - y_lo;
+    // iteration j = -1 .. nrows - 1: the compute waves multiply output row y_lo + j out of buffer j & 1 while the loaders stage row
+    // y_lo + j + 1 (its input row and its dY row) into the other one
+    if (wid >= 4) {
+        // ------------------------------------------------------------------------------------------------ loaders
+        // entry (ch, kh) = 8 output pixels from x0 = 16 seg + 8 kh; fl[i] = input column c0 - 4 + i, c0 = 2 x0; copy kx holds
+        // fl[2 e + kx + 1], e = 0 .. 7.  Waves 0, 1: kx = 0, 2, 4, 6 (the odd fl); waves 2, 3: kx = 1, 3, 5 (the even fl) and dY.
+        const int lt = tid - 256, lw = wid - 4;
+        const int ch = lt & 63, kh = lw & 1;
+        const bool odd_role = lw < 2;
+        float4 vr[6], vd[2];
+        bool okq[6], okd;
+        auto issue = [&](int seg, int j) {
+            const int x0 = seg * PX + 8 * kh, c0 = 2 * x0;
+            const int row = 2 * (y_lo + j + 1) + ky - 3;
+            const bool rok = row >= 0 && row < a.H;
+            const float *p = xn + (long)ch * plane + (long)min(max(row, 0), a.H - 1) * a.W;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int c = c0 - 4 + 4 * q;
+                okq[q] = rok && c >= 0 && c < a.W;
+                vr[q] = *reinterpret_cast<const float4 *>(p + min(max(c, 0), a.W - 4));
+            }
+            if (!odd_role) {
+                const int orow = y_lo + j + 1;
+                okd = orow < y_hi;
+                const float *pd = dyn + (long)ch * oplane + (long)min(orow, OH - 1) * OW;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) vd[q] = *reinterpret_cast<const float4 *>(pd + min(x0 + 4 * q, OW - 4));
+            }
+        };
+        auto stage = [&](int seg, int j) {
+            const int x0 = seg * PX + 8 * kh;
+            const int ps = 2 * T_CI * ENTRY;
+            unsigned char *xd = s_x + ((j + 1) & 1) * K7_ROW + (kh * T_CI + ch) * ENTRY;
+            float fl[24];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                fl[4 * q] = okq[q] ? vr[q].x : 0.f; fl[4 * q + 1] = okq[q] ? vr[q].y : 0.f; fl[4 * q + 2] = okq[q] ? vr[q].z : 0.f; fl[4 * q + 3] = okq[q] ? vr[q].w : 0.f;
+            }
+            // v[m]: the role's columns in order (odd role: fl[1 + 2 m], m = 0 .. 10; even role: fl[2 + 2 m], m = 0 .. 9); pair conversions
+            // pe[i] = (v[2i], v[2i+1]) and po[i] = (v[2i+1], v[2i+2]); copy number t of the role = v[e + t], i.e. pe[t/2 ..] or po[(t-1)/2 ..]
+            auto copies = [&](auto ODD_) __attribute__((always_inline)) {
+                constexpr bool ODD = decltype(ODD_)::value;
+                constexpr int b = ODD ? 1 : 2, NT = ODD ? 4 : 3;
+                unsigned pe[5][3], po[5][3];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    split3x2(fl[b + 4 * i], fl[b + 4 * i + 2], pe[i][0], pe[i][1], pe[i][2]);
+                    if (ODD || i < 4) split3x2(fl[b + 4 * i + 2], fl[b + 4 * i + 4], po[i][0], po[i][1], po[i][2]);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    unsigned char *dst = xd + (ODD ? 2 * t : 2 * t + 1) * ROW_COPY;
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        u32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (t & 1) ? po[e + (t >> 1)][pc] : pe[e + (t >> 1)][pc];
+                        *reinterpret_cast<u32x4 *>(dst + pc * ps) = v;
+                    }
+                }
+            };
+            if (odd_role) copies(std::true_type{});
+            else copies(std::false_type{});
+            if (!odd_role) {
+                float f[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool ok = okd && x0 + 4 * q < OW;
+                    f[4 * q] = ok ? vd[q].x : 0.f; f[4 * q + 1] = ok ? vd[q].y : 0.f; f[4 * q + 2] = ok ? vd[q].z : 0.f; f[4 * q + 3] = ok ? vd[q].w : 0.f;
+                }
+                emit8(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
+            }
+        };
+        for (int seg = 0; seg < a.nseg; ++seg) {
+            issue(seg, -1);
+            for (int j = -1; j < nrows; ++j) {
+                stage(seg, j);
+                if (j + 1 < nrows) issue(seg, j + 1);
+                barrier_lds();
+            }
+        }
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------------ compute waves
+    const int h = wid & 1, g = wid >> 1;
+    const int l31 = lane & 31, kgrp = lane >> 5;
+    f32x16 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int a_off = (kgrp * T_CO + 32 * h + l31) * ENTRY, b_off = (kgrp * T_CI + 32 * g + l31) * ENTRY;
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        for (int j = -1; j < nrows; ++j) {
+            if (j >= 0) {
+                u32x4 av[3];
+                const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const unsigned char *pb = s_x + (j & 1) * K7_ROW + kx * ROW_COPY + b_off;
+                    u32x4 bv[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                    constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[kx], 0, 0, 0);
+                }
+            }
+            barrier_lds();
+        }
+    }
+    float *out = a.partial + (((long)slice * a.ntiles + tile) * 49 + ky * 7) * (T_CO * T_CI);
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = 32 * h + 8 * (i >> 2) + 4 * kgrp + (i & 3), ci = 32 * g + l31;
+            out[((long)t * T_CO + co) * T_CI + ci] = acc[t][i];
+        }
+}
+
 // dW[co][ci][tap] = sum over the slices, in slice order, of partial[slice][tile][tap][co % 64][ci % 64]
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, int nslices, int ntiles, int ntile_ci, int cin, int cout,
-                                                      float *__restrict__ dw) {
+                                                      int ntaps, float *__restrict__ dw) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;   // (tile, tap, co_l, ci_l) in the partial's own order
-    const long per_tile = 9l * T_CO * T_CI;
+    const long per_tile = (long)ntaps * T_CO * T_CI;
     if (e >= ntiles * per_tile) return;
     const int tile = (int)(e / per_tile);
     const int r = (int)(e - tile * per_tile), t = r / (T_CO * T_CI), co_l = (r / T_CI) % T_CO, ci_l = r % T_CI;
     float s = 0.f;
     for (int sl = 0; sl < nslices; ++sl) s += partial[(long)sl * ntiles * per_tile + e];
     const int co = (tile / ntile_ci) * T_CO + co_l, ci = (tile % ntile_ci) * T_CI + ci_l;
-    dw[((long)co * cin + ci) * 9 + t] = s;
+    dw[((long)co * cin + ci) * ntaps + t] = s;
 }
 
-int wgrad_blocks(int B, int cin, int cout, int H, int W) {
+// (H, W = the OUTPUT map of the layer = the dY planes; prologue = steps that only stage: 3 for stride 1, 2 for stride 2)
+int wgrad_blocks(int B, int cin, int cout, int H, int W, int prologue, int tasks_per_tile = 1) {
     // Blocks of rows per image, by a cost in steps: a task walks nseg x (rows + 3) steps (three prologue steps per segment fill the row
     // ring), the chip runs one task per CU at a time.  tools/wgrad_probe.py: 64 -> 64 @160 x 32 images 738 us at 20 blocks of 8 rows
     // (640 tasks: three rounds, 27 % prologue) against 460 us at 8 blocks of 20 rows (256 tasks: one round).
@@ -222,7 +540,7 @@ int wgrad_blocks(int B, int cin, int cout, int H, int W) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
         return v > 0 ? v : 256;
     }();
-    const long tiles = (long)(cin / T_CI) * (cout / T_CO);
+    const long tiles = (long)(cin / T_CI) * (cout / T_CO) * tasks_per_tile;
     const int nseg = (W + PX - 1) / PX;
     int best = 1;
     double best_cost = 1e30;
@@ -231,46 +549,63 @@ int wgrad_blocks(int B, int cin, int cout, int H, int W) {
         if (rows < 4 && nb > 1) break;
         const long tasks = tiles * B * nb;
         if (tasks > 65535l * tiles) break;
-        const double cost = (double)((tasks + cus - 1) / cus) * nseg * (rows + 3) + 0.5 * nb;   // (+ the reduce launch reads nb partials)
+        const double cost = (double)((tasks + cus - 1) / cus) * nseg * (rows + prologue) + 0.5 * nb;   // (+ the reduce launch reads nb partials)
         if (cost < best_cost) { best_cost = cost; best = nb; }
     }
     return best;
 }
 }  // namespace
 
-extern "C" size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w) {
+namespace {
+// row blocks per image of a (kernel size, stride) case; prologue steps and tasks per tile as the three kernels have them
+int wgrad_blocks_of(int batch, int cin, int cout, int h, int w, int ksize, int stride) {
+    return ksize == 7 ? wgrad_blocks(batch, cin, cout, h / 2, w / 2, 1, 7) : wgrad_blocks(batch, cin, cout, h / stride, w / stride, stride == 1 ? 3 : 2);
+}
+}  // namespace
+
+extern "C" size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w, int ksize, int stride) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || cin % T_CI || cout % T_CO) return 0;
-    const int nb = wgrad_blocks(batch, cin, cout, h, w);
-    return (size_t)batch * nb * (cin / T_CI) * (cout / T_CO) * 9 * T_CO * T_CI * sizeof(float);
+    if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 7 && stride == 2))) return 0;
+    if (w % 4 || (stride == 2 && (h % 2 || w % 8))) return 0;
+    const int nb = wgrad_blocks_of(batch, cin, cout, h, w, ksize, stride);
+    return (size_t)batch * nb * (cin / T_CI) * (cout / T_CO) * ksize * ksize * T_CO * T_CI * sizeof(float);
 }
 
-extern "C" int lav_conv_wgrad(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, float *dw, void *workspace,
-                              size_t workspace_bytes, void *stream) {
+extern "C" int lav_conv_wgrad(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, int ksize, int stride, float *dw,
+                              void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(x && dy && dw, "lav_conv_wgrad: null argument");
+    LAV_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 7 && stride == 2), "lav_conv_wgrad: %dx%d kernel of stride %d (3x3 of stride 1 / 2, 7x7 of stride 2)", ksize, ksize, stride);
     LAV_REQUIRE(batch >= 1 && h >= 1 && w >= 4 && w % 4 == 0, "lav_conv_wgrad: batch %d, map %dx%d (rows of whole 16-byte pieces)", batch, h, w);
+    LAV_REQUIRE(stride == 1 || (h % 2 == 0 && w % 8 == 0), "lav_conv_wgrad: stride 2 takes even heights and widths that are multiples of 8 (%dx%d)", h, w);
     LAV_REQUIRE(cin >= T_CI && cout >= T_CO && cin % T_CI == 0 && cout % T_CO == 0, "lav_conv_wgrad: %d -> %d channels (multiples of 64)", cin, cout);
     LAV_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0, "lav_conv_wgrad: x and dy must be 16-byte aligned");
-    const size_t need = lav_conv_wgrad_workspace_bytes(batch, cin, cout, h, w);
+    const size_t need = lav_conv_wgrad_workspace_bytes(batch, cin, cout, h, w, ksize, stride);
     if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr = false;
     if (!attr) {
         LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_s2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_S2));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_k7), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_K7));
         attr = true;
     }
+    const int oh = h / stride, ow = w / stride;
     WgradArgs a;
     a.x = x; a.dy = dy; a.partial = static_cast<float *>(workspace);
     a.B = batch; a.cin = cin; a.cout = cout; a.H = h; a.W = w;
-    a.nseg = (w + PX - 1) / PX;
-    a.nblocks = wgrad_blocks(batch, cin, cout, h, w);
-    a.rows_per_block = (h + a.nblocks - 1) / a.nblocks;
+    a.nseg = (ow + PX - 1) / PX;
+    a.nblocks = wgrad_blocks_of(batch, cin, cout, h, w, ksize, stride);
+    a.rows_per_block = (oh + a.nblocks - 1) / a.nblocks;
     a.ntile_ci = cin / T_CI; a.ntiles = a.ntile_ci * (cout / T_CO);
     const int nslices = batch * a.nblocks;
     LAV_REQUIRE(nslices <= 65535, "lav_conv_wgrad: %d slices", nslices);
     const int tok = timer_begin("conv_wgrad", st);
-    hipLaunchKernelGGL(k_conv_wgrad, dim3(a.ntiles, nslices), dim3(512), LDS_BYTES, st, a);
-    const long total = (long)a.ntiles * 9 * T_CO * T_CI;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.partial, nslices, a.ntiles, a.ntile_ci, cin, cout, dw);
+    if (ksize == 7) hipLaunchKernelGGL(k_conv_wgrad_k7, dim3(a.ntiles * 7, nslices), dim3(512), LDS_BYTES_K7, st, a);
+    else if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad, dim3(a.ntiles, nslices), dim3(512), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(k_conv_wgrad_s2, dim3(a.ntiles, nslices), dim3(512), LDS_BYTES_S2, st, a);
+    const int ntaps = ksize * ksize;
+    const long total = (long)a.ntiles * ntaps * T_CO * T_CI;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.partial, nslices, a.ntiles, a.ntile_ci, cin, cout, ntaps, dw);
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;

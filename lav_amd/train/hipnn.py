@@ -202,14 +202,18 @@ def _wgrad_hip(x, dy, w, stride, padding, dilation):
     B, _, H, W = x.shape
     # (maps of at least 40 x 40 pixels: below that a task has too few 16-pixel steps behind its prologue and MIOpen wins -
     # profiles/r05_wgrad_probe.txt: 64 -> 64 @24x24 x 96 crops 92 vs 68 us)
-    if not (kh == 3 and kw == 3 and stride == 1 and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and W % 4 == 0 and H * W >= 1600
-            and cin % 64 == 0 and cout % 64 == 0 and dy.shape[2] == H and dy.shape[3] == W):
+    shape_ok = kh == kw and ((kh == 3 and stride in (1, 2)) or (kh == 7 and stride == 2)) and tuple(padding) == (kh // 2, kh // 2)
+    if not (shape_ok and tuple(dilation) == (1, 1) and W % (4 * stride) == 0 and H % stride == 0 and dy.shape[2] * dy.shape[3] >= 1600
+            and cin % 64 == 0 and cout % 64 == 0 and dy.shape[2] == H // stride and dy.shape[3] == W // stride):
+        return None
+    if (stride == 2 and kh == 3 and os.environ.get("LAV_TRAIN_WGRAD_STRIDED", "hip") == "torch") or (
+            kh == 7 and os.environ.get("LAV_TRAIN_WGRAD_STEM", "hip") == "torch"):
         return None
     dw = torch.empty_like(w)
-    nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W)
+    nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W, kh, stride)
     ws = ops_mod._workspace("conv_wgrad", nbytes, x.device)
-    check(lib.lav_conv_wgrad(_ptr(x), _ptr(dy), B, cin, cout, H, W, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
-    ops_mod.train_work["conv_wgrad_flops"] = ops_mod.train_work.get("conv_wgrad_flops", 0) + 2 * B * H * W * cin * cout * 9
+    check(lib.lav_conv_wgrad(_ptr(x), _ptr(dy), B, cin, cout, H, W, kh, stride, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
+    ops_mod.train_work["conv_wgrad_flops"] = ops_mod.train_work.get("conv_wgrad_flops", 0) + 2 * B * dy.shape[2] * dy.shape[3] * cin * cout * kh * kw
     return dw
 
 

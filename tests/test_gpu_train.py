@@ -522,37 +522,43 @@ def test_cpu_baseline_leg_computes_the_same_step_as_the_gpu_trainer():
             assert abs(cpu[k] - v) <= 2e-3 * max(1.0, abs(v)), (k, cpu[k], v)
 
 
-@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 64, 20, 32), (3, 128, 64, 9, 40), (1, 64, 128, 33, 16), (2, 384, 256, 12, 48), (5, 64, 64, 7, 4)])
-def test_conv_wgrad_vs_float64(B, cin, cout, H, W):
-    """lav_conv_wgrad (round 5: 3x3 stride-1 weight gradient on the bf16 matrix cores, operands split exactly into three bf16 pieces)
-    against the float64 weight gradient of torch's convolution on the CPU: ragged 16-pixel segments (W = 40, 4), blocks of rows with
-    their halo rows (H = 33), several co / ci tiles, the heads' channel counts.  Bar: 2e-6 of sum |dy||x| per weight (what the forward
+@pytest.mark.parametrize("B,cin,cout,H,W,S,KS", [(2, 64, 64, 20, 32, 1, 3), (3, 128, 64, 9, 40, 1, 3), (1, 64, 128, 33, 16, 1, 3), (2, 384, 256, 12, 48, 1, 3),
+                                                 (5, 64, 64, 7, 4, 1, 3), (2, 64, 64, 40, 64, 2, 3), (3, 64, 128, 18, 80, 2, 3), (1, 128, 64, 66, 8, 2, 3),
+                                                 (2, 128, 256, 6, 40, 2, 3), (2, 128, 64, 24, 40, 2, 7), (3, 64, 64, 10, 8, 2, 7), (1, 384, 64, 96, 96, 2, 7)])
+def test_conv_wgrad_vs_float64(B, cin, cout, H, W, S, KS):
+    """lav_conv_wgrad (round 5: 3x3 weight gradient of stride 1 / 2 on the bf16 matrix cores, operands split exactly into three bf16
+    pieces) against the float64 weight gradient of torch's convolution on the CPU: ragged 16-pixel segments (W = 40, 4; stride 2:
+    output widths 40, 4, 20), blocks of rows with their halo rows (H = 33, 66), several co / ci tiles, the heads' channel counts; the 7x7 stride-2 stem (one ky per task) at ragged and at its real size.  Bar: 2e-6 of sum |dy||x| per weight (what the forward
     split kernel is held to, tests/test_gpu_glue.py), and run-to-run bit equality (partial sums are added in a fixed order)."""
     import ctypes as C
     from lav_amd import _lib
     from lav_amd.ops import _ptr, _stream, _workspace, check
     g = torch.Generator().manual_seed(B * 1000 + cin + H)
     x = torch.randn((B, cin, H, W), generator=g)
-    dy = torch.randn((B, cout, H, W), generator=g)
-    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=1, padding=1)
-    mag = torch.nn.grad.conv2d_weight(x.double().abs(), (cout, cin, 3, 3), dy.double().abs(), stride=1, padding=1)
+    dy = torch.randn((B, cout, H // S, W // S), generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, KS, KS), dy.double(), stride=S, padding=KS // 2)
+    mag = torch.nn.grad.conv2d_weight(x.double().abs(), (cout, cin, KS, KS), dy.double().abs(), stride=S, padding=KS // 2)
     lib = _lib.load()
     xd, dyd = x.to(DEV), dy.to(DEV)
-    nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W)
+    nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W, KS, S)
     assert nbytes > 0
     ws = _workspace("conv_wgrad_test", nbytes, DEV)
     outs = []
     for _ in range(2):
-        dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
-        check(lib.lav_conv_wgrad(_ptr(xd), _ptr(dyd), B, cin, cout, H, W, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
+        dw = torch.full((cout, cin, KS, KS), float("nan"), device=DEV)
+        check(lib.lav_conv_wgrad(_ptr(xd), _ptr(dyd), B, cin, cout, H, W, KS, S, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
         outs.append(dw.cpu())
     assert torch.equal(outs[0], outs[1]), "the weight gradient must be bit-reproducible"
     err = ((outs[0].double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
     assert err < 2e-6, f"max |dw - ref| / sum|dy||x| = {err:.3e}"
-    assert lib.lav_conv_wgrad_workspace_bytes(1, 48, 64, 8, 8) == 0       # 48 input channels: not a multiple of 64
+    assert lib.lav_conv_wgrad_workspace_bytes(1, 48, 64, 8, 8, 3, 1) == 0       # 48 input channels: not a multiple of 64
+    assert lib.lav_conv_wgrad_workspace_bytes(1, 64, 64, 8, 12, 3, 2) == 0      # stride 2: the width must be a multiple of 8
+    assert lib.lav_conv_wgrad_workspace_bytes(1, 64, 64, 8, 8, 3, 3) == 0
+    assert lib.lav_conv_wgrad_workspace_bytes(1, 64, 64, 8, 8, 7, 1) == 0       # 7x7: stride 2 only
 
 
-@pytest.mark.parametrize("B,cin,cout,k,s,H,W", [(2, 64, 64, 3, 1, 24, 32), (2, 64, 128, 3, 2, 20, 24), (3, 16, 64, 7, 2, 30, 30), (2, 128, 128, 3, 1, 12, 12)])
+@pytest.mark.parametrize("B,cin,cout,k,s,H,W", [(2, 64, 64, 3, 1, 24, 32), (2, 64, 128, 3, 2, 20, 24), (3, 16, 64, 7, 2, 30, 30), (2, 128, 128, 3, 1, 12, 12),
+                                                 (2, 64, 64, 7, 2, 96, 96), (2, 64, 64, 3, 2, 80, 96)])
 def test_training_convolution_function_vs_torch(B, cin, cout, k, s, H, W):
     """lav_amd.train.hipnn.conv2d - forward on lav_conv2d over the live parameter (device-side repack), data gradient on the adjoint
     lav_conv2d plan (the transposed convolution with the same weights, strides 1 and 2), weight gradient on lav_conv_wgrad where it applies - against torch's own
