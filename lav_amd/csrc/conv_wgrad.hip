@@ -47,6 +47,7 @@ constexpr int ROW_COPY = 3 * 2 * T_CI * ENTRY;          // one kx copy of an inp
 constexpr int ROW_SLOT = 3 * ROW_COPY;                  // three kx copies = 18 KB
 constexpr int DY_BUF = 3 * 2 * T_CO * ENTRY;            // [piece 3][k half 2][co 64] = 6 KB
 constexpr int LDS_BYTES = 4 * ROW_SLOT + 2 * DY_BUF;    // 84 KB
+constexpr int PF = 3;                                   // steps the loaders' global loads run ahead of their staging
 
 struct WgradArgs {
     const float *x, *dy;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
     const int nrows = y_hi - y_lo;
     // a segment is walked as steps j = -2 .. nrows - 1: step j computes output row y_lo + j (j >= 0) while the loaders stage input row
     // y_lo + j + 2 and dY row y_lo + j + 1 for the steps that follow; j = -2, -1 only stage (rows y_lo - 1, y_lo and dY row y_lo)
+    const int T = a.nseg * (nrows + 3), T_pad = (T + PF - 1) / PF * PF;   // iterations of the task; every role runs T_pad barriers
     if (wid >= 4) {
         // ------------------------------------------------------------------------------------------------ loaders
         const int lt = tid - 256;   // 0 .. 255; two items per thread and step.  Loader wave lw = 0, 1: copy kx = 0 of the input row, then
@@ -92,10 +94,15 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
         const int ch = lt & 63, kh = lw & 1;
         const int kx0 = lw >> 1;                         // first item: copy kx0 of the input row
         const bool second_is_x = lw < 2;                 // second item: copy 2 of the input row, or dY
-        float4 va[3], vb[3];                             // raw loads of the two items (three aligned 16-byte pieces each)
-        bool oka[3], okb[3];
+        // Loads run PF steps ahead of their staging (register sets, the loop unrolled by PF): one step of matrix work is ~0.7 us, a
+        // load from HBM under this kernel's own traffic takes longer - with one step of distance every step waited for memory
+        // (0.45 of the roof; profiles/r05_wgrad_probe.txt).  The sequence of steps runs on across the segments of the task.
+        float4 va[PF][3], vb[PF][3];                     // raw loads of the two items (three aligned 16-byte pieces each)
+        bool oka[PF][3], okb[PF][3];
+        int i_seg = 0, i_j = -3, s_j = -3;               // the step the next issue / the next staging works on
         // window of an X item: pixels w0 .. w0 + 7 with w0 = x0 + 8 kh + kx - 1; aligned base a0 = w0 rounded down to 4
-        auto issue = [&](int seg, int j) {
+        auto issue = [&](float4 (&va)[3], float4 (&vb)[3], bool (&oka)[3], bool (&okb)[3]) __attribute__((always_inline)) {
+            const int seg = min(i_seg, a.nseg - 1), j = i_j;   // (past the last step: a harmless reload, staged where nobody reads)
             const int x0 = seg * PX + 8 * kh;
             {   // first item: input row y_lo + j + 2, copy kx0
                 const int row = y_lo + j + 2, a0 = kx0 == 0 ? x0 - 4 : x0;
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
                     vb[q] = *reinterpret_cast<const float4 *>(p + min(c, a.W - 4));
                 }
             }
+            if (++i_j == nrows) { i_j = -3; ++i_seg; }
         };
         // eight consecutive floats starting SH floats into the 12 loaded ones -> three 16-byte bf16 pieces at `dst` (piece stride ps)
         auto emit = [&](auto SH_, const float4 (&v)[3], const bool (&ok)[3], unsigned char *dst, int ps) __attribute__((always_inline)) {
@@ -140,7 +148,8 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
             *reinterpret_cast<u32x4 *>(dst + 2 * ps) = p2;
         };
         using std::integral_constant;
-        auto stage = [&](int j) {   // what issue(seg, j) loaded
+        auto stage = [&](const float4 (&va)[3], const float4 (&vb)[3], const bool (&oka)[3], const bool (&okb)[3]) __attribute__((always_inline)) {
+            const int j = s_j;
             const int slot = (j + 2 + 1) & 3;   // input row y_lo + j + 2 -> ring slot (relative row + 1) mod 4
             unsigned char *xd = s_x + slot * ROW_SLOT + (kh * T_CI + ch) * ENTRY;
             // the first item's window starts 3 floats into its aligned base for kx 0 (a0 = x0 - 4), 0 floats for kx 1
@@ -148,13 +157,15 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
             else emit(integral_constant<int, 0>{}, va, oka, xd + ROW_COPY, 2 * T_CI * ENTRY);
             if (second_is_x) emit(integral_constant<int, 1>{}, vb, okb, xd + 2 * ROW_COPY, 2 * T_CI * ENTRY);
             else emit(integral_constant<int, 0>{}, vb, okb, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
+            if (++s_j == nrows) s_j = -3;
         };
-        for (int seg = 0; seg < a.nseg; ++seg) {
-            issue(seg, -3);
-            for (int j = -3; j < nrows; ++j) {
-                // loads of "j" are in registers (issued one step ago): stage them, then issue the next step's
-                stage(j);
-                if (j + 1 < nrows) issue(seg, j + 1);
+#pragma unroll
+        for (int d = 0; d < PF; ++d) issue(va[d], vb[d], oka[d], okb[d]);
+        for (int t = 0; t < T_pad; t += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                stage(va[d], vb[d], oka[d], okb[d]);
+                issue(va[d], vb[d], oka[d], okb[d]);
                 barrier_lds();
             }
         }
@@ -169,29 +180,29 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int a_off = (kgrp * T_CO + 32 * h + l31) * ENTRY, b_off = (kgrp * T_CI + 32 * g + l31) * ENTRY;
-    for (int seg = 0; seg < a.nseg; ++seg) {
-        for (int j = -3; j < nrows; ++j) {
-            if (j >= 0) {
-                u32x4 av[3];
-                const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
+    int j = -3;
+    for (int t = 0; t < T_pad; ++t) {
+        if (j >= 0 && t < T) {
+            u32x4 av[3];
+            const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ky = t / 3, kx = t - 3 * ky;
-                    // input row y + ky - 1 = relative row j + ky - 1 -> slot (j + ky - 1 + 1) & 3
-                    const unsigned char *pb = s_x + ((j + ky) & 3) * ROW_SLOT + kx * ROW_COPY + b_off;
-                    u32x4 bv[3];
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int ky = t9 / 3, kx = t9 - 3 * ky;
+                // input row y + ky - 1 = relative row j + ky - 1 -> slot (j + ky - 1 + 1) & 3
+                const unsigned char *pb = s_x + ((j + ky) & 3) * ROW_SLOT + kx * ROW_COPY + b_off;
+                u32x4 bv[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
-                    constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
+                for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t], 0, 0, 0);
-                }
+                for (int k = 0; k < 6; ++k)
+                    acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t9], 0, 0, 0);
             }
-            barrier_lds();
         }
+        barrier_lds();
+        if (++j == nrows) j = -3;
     }
     // partial sums of this task: [tap][co 64][ci 64]; acc register i of lane (l31, kgrp): row 8 (i / 4) + 4 kgrp + i % 4, column l31
     float *out = a.partial + (((long)slice * a.ntiles + tile) * 9) * (T_CO * T_CI);
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
     const float *dyn = a.dy + ((long)n * a.cout + (long)t_co * T_CO) * oplane;
     const int nrows = y_hi - y_lo;
     const int r_base = 2 * y_lo - 1;   // input row of rr = 0
+    const int T = a.nseg * (nrows + 2), T_pad = (T + PF - 1) / PF * PF;
     if (wid >= 4) {
         // ------------------------------------------------------------------------------------------------ loaders
         // entry (ch, kh) = 8 output pixels x0 .. x0 + 7 of channel ch = input columns c0 + (kx - 1) + 2 e, c0 = 2 x0 (a multiple of 16).
@@ -246,11 +258,13 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
         const int lt = tid - 256, lw = wid - 4;
         const int ch = lt & 63, kh = lw & 1;
         const bool odd_role = lw < 2;
-        float4 vr[2][4];          // the two input rows: columns c0 .. c0 + 15
-        float halo[2];            // column c0 - 1 (odd role)
-        float4 vd[2];             // dY: pixels x0 .. x0 + 7 (even role)
-        bool okr[2], okc[4], okd, okh;
-        auto issue = [&](int seg, int j) {
+        float4 vr[PF][2][4];      // the two input rows: columns c0 .. c0 + 15
+        float halo[PF][2];        // column c0 - 1 (odd role)
+        float4 vd[PF][2];         // dY: pixels x0 .. x0 + 7 (even role)
+        bool okr[PF][2], okc[PF][4], okdq[PF][2], okh[PF];
+        int i_seg = 0, i_j = -2, s_j = -2, s_base = 2;   // the step the next issue / staging works on; s_base = (2 s_j) mod 6
+        auto issue = [&](float4 (&vr)[2][4], float (&halo)[2], float4 (&vd)[2], bool (&okr)[2], bool (&okc)[4], bool (&okdq)[2], bool &okh) __attribute__((always_inline)) {
+            const int seg = min(i_seg, a.nseg - 1), j = i_j;
             const int x0 = seg * PX + 8 * kh, c0 = 2 * x0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) okc[q] = c0 + 4 * q < a.W;
@@ -266,14 +280,19 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
             }
             if (!odd_role) {
                 const int row = y_lo + j + 1;
-                okd = row >= y_lo && row < y_hi;
+                const bool okd = row >= y_lo && row < y_hi;
                 const float *p = dyn + (long)ch * oplane + (long)min(max(row, 0), OH - 1) * OW;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) vd[q] = *reinterpret_cast<const float4 *>(p + min(x0 + 4 * q, OW - 4));
+                for (int q = 0; q < 2; ++q) {
+                    okdq[q] = okd && x0 + 4 * q < OW;
+                    vd[q] = *reinterpret_cast<const float4 *>(p + min(x0 + 4 * q, OW - 4));
+                }
             }
+            if (++i_j == nrows) { i_j = -2; ++i_seg; }
         };
-        auto stage = [&](int seg, int j, int base) {   // base = (2 j) mod 6
-            const int x0 = seg * PX + 8 * kh;
+        auto stage = [&](const float4 (&vr)[2][4], const float (&halo)[2], const float4 (&vd)[2], const bool (&okr)[2], const bool (&okc)[4], const bool (&okdq)[2],
+                         const bool &okh) __attribute__((always_inline)) {
+            const int j = s_j, base = s_base;
             const int ps = 2 * T_CI * ENTRY;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -305,20 +324,21 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
                 float f[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const bool ok = okd && x0 + 4 * q < OW;
-                    f[4 * q] = ok ? vd[q].x : 0.f; f[4 * q + 1] = ok ? vd[q].y : 0.f; f[4 * q + 2] = ok ? vd[q].z : 0.f; f[4 * q + 3] = ok ? vd[q].w : 0.f;
+                    f[4 * q] = okdq[q] ? vd[q].x : 0.f; f[4 * q + 1] = okdq[q] ? vd[q].y : 0.f; f[4 * q + 2] = okdq[q] ? vd[q].z : 0.f; f[4 * q + 3] = okdq[q] ? vd[q].w : 0.f;
                 }
                 emit8(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
             }
+            s_base = s_base == 4 ? 0 : s_base + 2;
+            if (++s_j == nrows) { s_j = -2; s_base = 2; }
         };
-        for (int seg = 0; seg < a.nseg; ++seg) {
-            issue(seg, -2);
-            int base = 2;   // (2 * -2) mod 6
-            for (int j = -2; j < nrows; ++j) {
-                stage(seg, j, base);
-                if (j + 1 < nrows) issue(seg, j + 1);
+#pragma unroll
+        for (int d = 0; d < PF; ++d) issue(vr[d], halo[d], vd[d], okr[d], okc[d], okdq[d], okh[d]);
+        for (int t = 0; t < T_pad; t += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                stage(vr[d], halo[d], vd[d], okr[d], okc[d], okdq[d], okh[d]);
+                issue(vr[d], halo[d], vd[d], okr[d], okc[d], okdq[d], okh[d]);
                 barrier_lds();
-                base = base == 4 ? 0 : base + 2;
             }
         }
         return;
@@ -332,32 +352,31 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int a_off = (kgrp * T_CO + 32 * h + l31) * ENTRY, b_off = (kgrp * T_CI + 32 * g + l31) * ENTRY;
-    for (int seg = 0; seg < a.nseg; ++seg) {
-        int base = 2;
-        for (int j = -2; j < nrows; ++j) {
-            if (j >= 0) {
-                u32x4 av[3];
-                const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
+    int j = -2, base = 2;
+    for (int t = 0; t < T_pad; ++t) {
+        if (j >= 0 && t < T) {
+            u32x4 av[3];
+            const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ky = t / 3, kx = t - 3 * ky;
-                    int slot = base + ky;
-                    slot = slot >= S2_SLOTS ? slot - S2_SLOTS : slot;
-                    const unsigned char *pb = s_x + slot * ROW_SLOT + kx * ROW_COPY + b_off;
-                    u32x4 bv[3];
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int ky = t9 / 3, kx = t9 - 3 * ky;
+                int slot = base + ky;
+                slot = slot >= S2_SLOTS ? slot - S2_SLOTS : slot;
+                const unsigned char *pb = s_x + slot * ROW_SLOT + kx * ROW_COPY + b_off;
+                u32x4 bv[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
-                    constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
+                for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t], 0, 0, 0);
-                }
+                for (int k = 0; k < 6; ++k)
+                    acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t9], 0, 0, 0);
             }
-            barrier_lds();
-            base = base == 4 ? 0 : base + 2;
         }
+        barrier_lds();
+        base = base == 4 ? 0 : base + 2;
+        if (++j == nrows) { j = -2; base = 2; }
     }
     float *out = a.partial + (((long)slice * a.ntiles + tile) * 9) * (T_CO * T_CI);
 #pragma unroll
@@ -393,6 +412,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
     const int nrows = y_hi - y_lo;
     // iteration j = -1 .. nrows - 1: the compute waves multiply output row y_lo + j out of buffer j & 1 while the loaders stage row
     // y_lo + j + 1 (its input row and its dY row) into the other one
+    const int T = a.nseg * (nrows + 1), T_pad = (T + PF - 1) / PF * PF;
     if (wid >= 4) {
         // ------------------------------------------------------------------------------------------------ loaders
         // entry (ch, kh) = 8 output pixels from x0 = 16 seg + 8 kh; fl[i] = input column c0 - 4 + i, c0 = 2 x0; copy kx holds
@@ -400,9 +420,11 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
         const int lt = tid - 256, lw = wid - 4;
         const int ch = lt & 63, kh = lw & 1;
         const bool odd_role = lw < 2;
-        float4 vr[6], vd[2];
-        bool okq[6], okd;
-        auto issue = [&](int seg, int j) {
+        float4 vr[PF][6], vd[PF][2];
+        bool okq[PF][6], okdq[PF][2];
+        int i_seg = 0, i_j = -1, s_j = -1;
+        auto issue = [&](float4 (&vr)[6], float4 (&vd)[2], bool (&okq)[6], bool (&okdq)[2]) __attribute__((always_inline)) {
+            const int seg = min(i_seg, a.nseg - 1), j = i_j;
             const int x0 = seg * PX + 8 * kh, c0 = 2 * x0;
             const int row = 2 * (y_lo + j + 1) + ky - 3;
             const bool rok = row >= 0 && row < a.H;
@@ -415,14 +437,18 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
             }
             if (!odd_role) {
                 const int orow = y_lo + j + 1;
-                okd = orow < y_hi;
+                const bool okd = orow < y_hi;
                 const float *pd = dyn + (long)ch * oplane + (long)min(orow, OH - 1) * OW;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) vd[q] = *reinterpret_cast<const float4 *>(pd + min(x0 + 4 * q, OW - 4));
+                for (int q = 0; q < 2; ++q) {
+                    okdq[q] = okd && x0 + 4 * q < OW;
+                    vd[q] = *reinterpret_cast<const float4 *>(pd + min(x0 + 4 * q, OW - 4));
+                }
             }
+            if (++i_j == nrows) { i_j = -1; ++i_seg; }
         };
-        auto stage = [&](int seg, int j) {
-            const int x0 = seg * PX + 8 * kh;
+        auto stage = [&](const float4 (&vr)[6], const float4 (&vd)[2], const bool (&okq)[6], const bool (&okdq)[2]) __attribute__((always_inline)) {
+            const int j = s_j;
             const int ps = 2 * T_CI * ENTRY;
             unsigned char *xd = s_x + ((j + 1) & 1) * K7_ROW + (kh * T_CI + ch) * ENTRY;
             float fl[24];
@@ -459,17 +485,19 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
                 float f[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const bool ok = okd && x0 + 4 * q < OW;
-                    f[4 * q] = ok ? vd[q].x : 0.f; f[4 * q + 1] = ok ? vd[q].y : 0.f; f[4 * q + 2] = ok ? vd[q].z : 0.f; f[4 * q + 3] = ok ? vd[q].w : 0.f;
+                    f[4 * q] = okdq[q] ? vd[q].x : 0.f; f[4 * q + 1] = okdq[q] ? vd[q].y : 0.f; f[4 * q + 2] = okdq[q] ? vd[q].z : 0.f; f[4 * q + 3] = okdq[q] ? vd[q].w : 0.f;
                 }
                 emit8(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
             }
+            if (++s_j == nrows) s_j = -1;
         };
-        for (int seg = 0; seg < a.nseg; ++seg) {
-            issue(seg, -1);
-            for (int j = -1; j < nrows; ++j) {
-                stage(seg, j);
-                if (j + 1 < nrows) issue(seg, j + 1);
+#pragma unroll
+        for (int d = 0; d < PF; ++d) issue(vr[d], vd[d], okq[d], okdq[d]);
+        for (int t = 0; t < T_pad; t += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                stage(vr[d], vd[d], okq[d], okdq[d]);
+                issue(vr[d], vd[d], okq[d], okdq[d]);
                 barrier_lds();
             }
         }
@@ -484,27 +512,27 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int a_off = (kgrp * T_CO + 32 * h + l31) * ENTRY, b_off = (kgrp * T_CI + 32 * g + l31) * ENTRY;
-    for (int seg = 0; seg < a.nseg; ++seg) {
-        for (int j = -1; j < nrows; ++j) {
-            if (j >= 0) {
-                u32x4 av[3];
-                const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
+    int j = -1;
+    for (int t = 0; t < T_pad; ++t) {
+        if (j >= 0 && t < T) {
+            u32x4 av[3];
+            const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const unsigned char *pb = s_x + (j & 1) * K7_ROW + kx * ROW_COPY + b_off;
-                    u32x4 bv[3];
+            for (int kx = 0; kx < 7; ++kx) {
+                const unsigned char *pb = s_x + (j & 1) * K7_ROW + kx * ROW_COPY + b_off;
+                u32x4 bv[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
-                    constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
+                for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[kx], 0, 0, 0);
-                }
+                for (int k = 0; k < 6; ++k)
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[kx], 0, 0, 0);
             }
-            barrier_lds();
         }
+        barrier_lds();
+        if (++j == nrows) j = -1;
     }
     float *out = a.partial + (((long)slice * a.ntiles + tile) * 49 + ky * 7) * (T_CO * T_CI);
 #pragma unroll
