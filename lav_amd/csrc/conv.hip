@@ -845,7 +845,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     const DirectPlan &d = ch.dp;
     if (ch.kind == 2) {   // split kernel: info[0] = -1, then MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows
         info[0] = -1; info[1] = ch.sp.MP; info[2] = ch.sp.MC; info[3] = ch.sp.WPX; info[4] = ch.sp.tw; info[5] = (int)ch.sp.lds;
-        info[6] = ch.sp.ksplit; info[7] = ch.sp.tap_group + 100 * ch.sp.tp; info[8] = ch.sp.th;   // (tap group + 100 in tap-pair mode)
+        info[6] = ch.sp.sk_w ? -ch.sp.sk_w : ch.sp.ksplit; info[7] = ch.sp.tap_group + 100 * ch.sp.tp; info[8] = ch.sp.th;   // (tap group + 100 in tap-pair mode; split-K < 0: stream-K over that many workgroups)
         return LAV_OK;
     }
     if (ch.kind == 1) {   // direct path: info[0] = 0, info[1] = waves per workgroup
@@ -1063,7 +1063,8 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     const Choice ch = decide(*c, p, cost, raw);
     if (ch.kind == 1) a.ksplit = ch.dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
-    return a.ksplit > 1 ? (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float) : 0;
+    const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);   // stream-K: head and tail parts of the cut tiles
+    return (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
 }
 
 extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
@@ -1093,8 +1094,9 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     const bool direct = ch.kind == 1;
     if (direct) a.ksplit = dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
-    if (a.ksplit > 1) {
-        const size_t need = (size_t)a.ksplit * c->batch * c->cout * p.OH * p.OW * sizeof(float);
+    const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);
+    if (slabs) {
+        const size_t need = (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
         if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, need);
         a.partial = static_cast<float *>(workspace);
     } else {

@@ -120,38 +120,37 @@ struct SplitOps {
 // couts before - LDS-read bound, no faster than the fp32 kernel.  Same packed weights: lane (h, cout) of a fragment fetches
 // its 16 bytes from tap 2p + h, channel half (chunk & 1) of the ordinary layout; the odd tap out (49 = 24 pairs + 1) is
 // zeroed on its way into LDS.  A chunk is 8 channels, a step one tap pair.
-template <int MP, int MC, int WPX, int NT, int G, bool TP = false>
-__global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
+// The work of one workgroup on one tile: pixel tile `by`, cout tile `bx`, class `cls`, image `n`, chunks [chunk_lo, chunk_hi) of the K
+// loop; part < 0: the tile's whole K range, epilogue applied and written to y; part >= 0: raw partial sums into slab `part` of
+// a.partial.  SK (stream-K, k_conv_split_sk): the function is called for one segment after the other - every role ends on one more
+// LDS barrier, so that the loaders enter the next segment while the compute waves write this one out.
+template <int MP, int MC, int WPX, int NT, int G, bool TP, bool SK>
+__device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *smem_raw, const int bx, const int by, const int cls, const int n, const int batch,
+                                           const int chunk_lo, const int chunk_hi, const int part, const long wg) {
     constexpr int WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
     constexpr int CH = TP ? 8 : 16;                            // channels per chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ks = blockIdx.z % a.ksplit;
-    const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
     if (a.n_valid && n >= *a.n_valid) return;   // workgroup-uniform
     const int ntaps_real = a.cls_ntaps[cls];
     const int ntaps = TP ? (ntaps_real + 1) >> 1 : ntaps_real;   // steps per chunk (TP: tap pairs)
-    const int nchunks_k = TP ? 2 * a.nchunks : a.nchunks;       // chunks of the K loop
     int qy0, qx0, q0 = 0;
     if (a.tw) {
-        const int tx = blockIdx.y % a.tiles_x, ty = blockIdx.y / a.tiles_x;
+        const int tx = by % a.tiles_x, ty = by / a.tiles_x;
         qy0 = ty * a.th; qx0 = tx * a.tw;
     } else {
-        q0 = blockIdx.y * PIXW; qy0 = q0 / a.QW; qx0 = 0;
+        q0 = by * PIXW; qy0 = q0 / a.QW; qx0 = 0;
     }
     const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls], in_ox = qx0 * a.in_s + a.cls_in_ox[cls];
     const int plane = a.plane;
     const int ibuf_bytes = (TP ? 3 : 6) * plane * 16;         // [3 pieces][2 k halves][plane] x 16 B (TP: no k-half dimension)
     constexpr int WSLOT = NBLK * 3 * 1024;                    // one tap's weights of the tile: [cout block][piece][lane] x 16 B
     unsigned char *s_in = smem_raw, *s_w = smem_raw + 2 * ibuf_bytes;
-    const int chunk_lo = ks * nchunks_k / a.ksplit, chunk_hi = (ks + 1) * nchunks_k / a.ksplit;
     const int nchunk = chunk_hi - chunk_lo, nsteps = nchunk * ntaps;   // a step = one tap of one 16-channel chunk
     constexpr int WFM = 4 / G;                                 // groups of G taps the weight waves keep in flight in registers
     const int ngroups = (nsteps + G - 1) / G;                 // a group = the G taps between two barriers
     const int ngroups_pad = (ngroups + WFM - 1) / WFM * WFM;  // barriers every role executes (the weight waves' loop is unrolled by WFM)
     const int *toff = a.toff + cls * a.taps_per_class;
-    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
     if (wid == 4 || wid == 5) {
         // ------------------------------------------------------------------------------ weight waves (2 x 64 threads)
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             int pc = lw + 2 * k;
             if (pc >= NBLK * 3) pc = lw;
             const int b = pc / 3, pl = pc - b * 3;
-            const int blk = min((int)blockIdx.x * NBLK + b, a.nblk_total - 1);
+            const int blk = min(bx * NBLK + b, a.nblk_total - 1);
             rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * 3 + pl) * 1024) + lane * 16;
             if constexpr (TP) rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * 3 + pl) * 1024) + l31 * 16 + half * (unsigned)(a.nchunks * 3072);
             doff[k] = pc * 1024 + lane * 16;
@@ -236,6 +235,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
             }
         }
         if (a.trace && tid == 256) a.trace[wg * 8 + 7] = waited;
+        if constexpr (SK) lds_barrier();
         return;
     }
     if (wid >= 6) {
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         }
         for (int k = ngroups; k < ngroups_pad; ++k) lds_barrier();
         if (a.trace && tid == 384) { a.trace[wg * 8 + 5] = conv; a.trace[wg * 8 + 6] = waited; }
+        if constexpr (SK) lds_barrier();
         return;
     }
     // -------------------------------------------------------------------------------------- compute waves
@@ -440,15 +441,15 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
         }
         for (; bars < ngroups_pad; ++bars) lds_barrier();
     }
+    if constexpr (SK) lds_barrier();   // the LDS of this segment is free: the loaders go on to the next one
     if (a.trace && tid == 0) { a.trace[wg * 8 + 2] = clock64(); a.trace[wg * 8 + 4] = waited; }
 
     // -------------------------------------------------------------------------------------- epilogue (as k_conv)
-    const int cb = (blockIdx.x * NBLK + wc * MC) * 32;
+    const int cb = (bx * NBLK + wc * MC) * 32;
     const int out_oy = a.cls_out_oy[cls], out_ox = a.cls_out_ox[cls];
-    if (a.ksplit > 1) {
+    if (part >= 0) {
         const long plane_o = (long)a.OH * a.OW;
-        const int batch = gridDim.z / (a.ksplit * a.nclasses);
-        float *pbase = a.partial + ((long)ks * batch + n) * a.cout * plane_o;
+        float *pbase = a.partial + ((long)part * batch + n) * a.cout * plane_o;
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
@@ -508,6 +509,79 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     }
 }
 
+template <int MP, int MC, int WPX, int NT, int G, bool TP = false>
+__global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int ks = blockIdx.z % a.ksplit;
+    const int cls = (blockIdx.z / a.ksplit) % a.nclasses, n = blockIdx.z / (a.ksplit * a.nclasses);
+    const int nchunks_k = TP ? 2 * a.nchunks : a.nchunks;
+    const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    split_body<MP, MC, WPX, NT, G, TP, false>(a, smem_raw, blockIdx.x, blockIdx.y, cls, n, gridDim.z / (a.ksplit * a.nclasses), ks * nchunks_k / a.ksplit,
+                                              (ks + 1) * nchunks_k / a.ksplit, a.ksplit > 1 ? ks : -1, wg);
+}
+
+// Stream-K launch of a single-image, single-class layer (round 5).  The head convolution's 400 tiles ran as two rounds of a 256-CU
+// chip with the second round 56 % full (0.78 of the tile time wasted).  Here W persistent workgroups (one per CU) share
+// the layer's U = tiles x chunks units of K work evenly: workgroup i takes units [i U / W, (i + 1) U / W) of the linear order (tile,
+// chunk), i.e. the tail of one tile, whole tiles, and the head of another.  With U / W >= chunks per tile a tile is cut at most once:
+// its head part (chunks [0, c)) goes to slab 0 of a.partial, its tail part to slab 1, and k_conv_sk_fixup adds the two in that order
+// and applies the epilogue - fixed cuts, fixed order: bit-reproducible.  Whole tiles take the ordinary epilogue.
+template <int MP, int MC, int WPX, int NT, int G>
+__global__ __launch_bounds__(512) void k_conv_split_sk(SplitArgs a, int nbx, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nck = a.nchunks;
+    const long U = (long)ntiles * nck;
+    const int W = gridDim.x, npx = ntiles / nbx;
+    // The tiles are ordered cout tile first (tile = bx * npx + by), and the workgroups of one XCD (workgroup b is dispatched to XCD b % 8)
+    // take neighbouring ranges of that order: an XCD's L2 then streams the weights of ONE cout tile (2.6 MB of the head convolution's
+    // 5.3 MB; both do not fit its 4 MB - the first version, workgroup b on range b, was slower than whole tiles).
+    int j = blockIdx.x;
+    if (8 % nbx == 0 && W % 8 == 0) {
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        j = (x % nbx) * (W / nbx) + (x / nbx) * (W / 8) + slot;
+    }
+    long u = (long)j * U / W;
+    const long u1 = (long)(j + 1) * U / W;
+    while (u < u1) {
+        const int tile = (int)(u / nck), c_lo = (int)(u - (long)tile * nck);
+        const int c_hi = (int)(u1 - u < (long)(nck - c_lo) ? c_lo + (u1 - u) : nck);
+        const int part = c_lo == 0 && c_hi == nck ? -1 : (c_lo == 0 ? 0 : 1);
+        split_body<MP, MC, WPX, NT, G, false, true>(a, smem_raw, tile / npx, tile % npx, 0, 0, 1, c_lo, c_hi, part, 0);
+        u += c_hi - c_lo;
+    }
+}
+
+struct SkFixupArgs {
+    const float *partial, *bias, *scale, *shift, *res;
+    const int *n_valid;
+    float *y;
+    int cout, out_c_total, out_c_offset, OH, OW;
+    int tw, th, tiles_x, couts_per_tile, nbx, nck, ntiles, W;
+    int relu_pre, relu_post, sigmoid;
+};
+// y = epilogue(slab 0 + slab 1) for the outputs of the tiles that k_conv_split_sk cut (the same arithmetic as k_conv_reduce)
+__global__ __launch_bounds__(256) void k_conv_sk_fixup(SkFixupArgs a) {
+    const long plane_o = (long)a.OH * a.OW, total = (long)a.cout * plane_o;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    if (a.n_valid && *a.n_valid < 1) return;
+    const int co = (int)(e / plane_o);
+    const int pix = (int)(e - (long)co * plane_o), oy = pix / a.OW, ox = pix - oy * a.OW;
+    const int tile = (co / a.couts_per_tile) * (a.ntiles / a.nbx) + (oy / a.th) * a.tiles_x + ox / a.tw;
+    const long U = (long)a.ntiles * a.nck, lo = (long)tile * a.nck;
+    const long i0 = lo * a.W / U + 1, b = i0 * U / a.W;   // the first workgroup boundary past the tile's first unit
+    if (!(i0 < a.W && b > lo && b < lo + a.nck)) return;  // the tile was not cut
+    float v = a.partial[e] + a.partial[total + e];
+    if (a.bias) v += a.bias[co];
+    if (a.relu_pre) v = v > 0.f ? v : 0.f;
+    if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+    const long idx = ((long)a.out_c_offset + co) * plane_o + pix;
+    if (a.res) v += a.res[idx];
+    if (a.relu_post) v = v > 0.f ? v : 0.f;
+    if (a.sigmoid && co >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
+    a.y[idx] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // bytes of the split packed weights of one plan
 inline size_t split_weight_bytes(const Plan &p) {
@@ -562,6 +636,7 @@ struct SplitPlan {
     size_t lds;
     double cost;
     int tp;   // tap-pair mode (k_conv_split<..., TP = true>)
+    int sk_w; // > 0: stream-K launch with this many persistent workgroups (k_conv_split_sk)
 };
 
 // Tile shape, tile geometry, tap group and split-K factor of the split kernel, by estimated time (us).
@@ -649,6 +724,21 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
             }
         }
     }
+    // Stream-K (k_conv_split_sk) where whole-tile rounds waste a large part of the chip: a single image, one class, the 2x2/w2 G = 2
+    // kernel (the head convolution: 400 tiles on 256 CUs = two rounds, the second 56 % full), at least one tile's worth of K per
+    // workgroup (a tile is then cut at most once).  OPT-IN (LAV_SPLIT_SK=1, read at every plan): measured no faster than whole tiles -
+    // 282 vs 281 us on the head convolution, with and without the XCD-aware order - because the chip is POWER bound under this kernel
+    // (tools/clock_probe.py: 1330 W of the 1400 W socket limit at 2.11 GHz; the half-empty second round of whole tiles simply runs at a
+    // higher clock), so evening out the work buys nothing.  Kept for parts / clocks where it is not (profiles/r05_clock_power.txt).
+    const char *sk_env = getenv("LAV_SPLIT_SK");
+    const bool sk_on = sk_env && atoi(sk_env) != 0;
+    if (sk_on && best.ok && !best.tp && best.MP == 2 && best.MC == 2 && best.WPX == 2 && best.tap_group == 2 && best.ksplit == 1 && best.tw > 0 &&
+        c.batch == 1 && p.nclasses == 1 && ncu == 256 && !(c.target_cus >= 16 && c.target_cus < 256)) {
+        const int NBLK = (4 / best.WPX) * best.MC;
+        const long wgs = (long)best.tiles * ((c.cout + NBLK * 32 - 1) / (NBLK * 32));
+        const long rounds = (wgs + ncu - 1) / ncu;
+        if (wgs > ncu && rounds * ncu * 100 >= wgs * 115 && rounds <= 4) best.sk_w = (int)ncu;
+    }
     return best;
 }
 
@@ -720,6 +810,29 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
     dim3 grid((c.cout + NBLK * 32 - 1) / (NBLK * 32), sp.tiles, c.batch * p.nclasses * sp.ksplit);
     const int tok = timer_begin("conv2d", st);
     int rc = LAV_EINVAL;
+    if (sp.sk_w) {
+        const size_t lds_sk = sp.lds;
+        const int nbx = (int)grid.x, ntiles = (int)(grid.x * grid.y);
+        const bool small = s.plane <= SPLIT_LOADERS * 2;
+        static bool attr = false;
+        if (!attr) {
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_sk<2, 2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_sk<2, 2, 2, SPLIT_NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        if (small) hipLaunchKernelGGL((k_conv_split_sk<2, 2, 2, 2, 2>), dim3(sp.sk_w), dim3(512), lds_sk, st, s, nbx, ntiles);
+        else hipLaunchKernelGGL((k_conv_split_sk<2, 2, 2, SPLIT_NT, 2>), dim3(sp.sk_w), dim3(512), lds_sk, st, s, nbx, ntiles);
+        SkFixupArgs f;
+        f.partial = a.partial; f.bias = a.bias; f.scale = a.scale; f.shift = a.shift; f.res = a.res; f.n_valid = a.n_valid; f.y = a.y;
+        f.cout = a.cout; f.out_c_total = a.out_c_total; f.out_c_offset = a.out_c_offset; f.OH = a.OH; f.OW = a.OW;
+        f.tw = sp.tw; f.th = sp.th; f.tiles_x = sp.tiles_x; f.couts_per_tile = NBLK * 32; f.nbx = nbx; f.nck = s.nchunks; f.ntiles = ntiles; f.W = sp.sk_w;
+        f.relu_pre = a.relu_pre; f.relu_post = a.relu_post; f.sigmoid = a.sigmoid;
+        const long total = (long)a.cout * p.OH * p.OW;
+        hipLaunchKernelGGL(k_conv_sk_fixup, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f);
+        timer_end(tok, st);
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
+    }
     if (sp.tp) {
         if (sp.MP == 1 && sp.MC == 2 && sp.WPX == 4 && sp.tap_group == 4) rc = launch_split_g<1, 2, 4, SPLIT_NT_TP, 4, true>(s, grid, sp.lds, st);
         else if (sp.MP == 2 && sp.MC == 2 && sp.WPX == 4 && sp.tap_group == 1) rc = launch_split_g<2, 2, 4, SPLIT_NT_TP, 1, true>(s, grid, sp.lds, st);

@@ -475,7 +475,7 @@ class ConvLayer:
             if residual.shape != out.shape:
                 raise RuntimeError("residual shape mismatch")
         lib = _lib.load()
-        key = (B, h, w, _os.environ.get("LAV_CONV_SPLIT"))   # lav_conv2d re-reads the plan knob per call: the cached size follows it
+        key = (B, h, w, _os.environ.get("LAV_CONV_SPLIT"), _os.environ.get("LAV_SPLIT_SK"))   # lav_conv2d re-reads the plan knobs per call: the cached size follows them
         nbytes = self._ws_bytes.get(key)
         if nbytes is None:
             nbytes = self._ws_bytes[key] = lib.lav_conv_workspace_bytes(C.byref(d))

@@ -107,6 +107,51 @@ def test_split_k_epilogue_matches_unsplit():
     assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what="split-K epilogue")
 
 
+def test_stream_k_head_convolution(monkeypatch):
+    """LAV_SPLIT_SK=1 (opt-in: no faster on this power-bound chip, profiles/r05_clock_power.txt): the head convolution's plan (384 ->
+    256, 3x3, one 160 x 160 image: 400 tiles on 256 CUs) runs as a stream-K launch - persistent
+    workgroups share the K work evenly, a cut tile's two parts go through slabs and k_conv_sk_fixup (conv_split.hpp).  Against float64:
+    the error bar of the split kernel (2e-6 of sum |w||x|); every epilogue piece through both the direct and the fix-up path; the
+    untouched channels of a wider output stay untouched; two launches give the same bits (fixed cuts, fixed order)."""
+    import ctypes as C
+    from lav_amd import _lib
+    from lav_amd._lib import Conv
+    lib = _lib.load()
+    info = (C.c_int * 9)()
+    d = Conv(1, 384, 0, 384, 160, 160, 256, 3, 3, 1, 1, 1, 1, 1, 0, 0, 256, 0, 0, 0, 0)
+    assert lib.lav_conv_tile_info(C.byref(d), info) == 0 and info[6] == 1, "whole tiles by default"
+    monkeypatch.setenv("LAV_SPLIT_SK", "1")
+    assert lib.lav_conv_tile_info(C.byref(d), info) == 0
+    assert info[0] == -1 and info[6] == -256, f"the head convolution is expected on the stream-K launch, plan {list(info)}"
+    B, cin, cout, H, W = 1, 384, 256, 160, 160
+    x = rnd((B, cin, H, W), 41)
+    w = rnd((cout, cin, 3, 3), 42, scale=1.0 / np.sqrt(cin * 9))
+    bias = rnd((cout,), 43)
+    bn = (rnd((cout,), 44, 0.1), rnd((cout,), 45).abs() + 0.5, rnd((cout,), 46).abs() + 0.5, rnd((cout,), 47, 0.1))
+    res = rnd((B, cout, H, W), 48)
+    xd, wd = x.to(DEV).double(), w.to(DEV).double()
+    conv64 = F.conv2d(xd, wd, None, 1, 1)
+    mag = F.conv2d(xd.abs(), wd.abs(), None, 1, 1)
+    # plain convolution: the arithmetic
+    y = ConvLayer(w, padding=1, device=DEV)(x.to(DEV))
+    err = ((y.double() - conv64).abs() / mag).max().item()
+    assert err < 2e-6, f"max |y - ref| / sum|w||x| = {err:.3e}"
+    # epilogue through both paths, into a channel window
+    ref = F.relu(F.batch_norm(conv64 + bias.to(DEV).double()[None, :, None, None], bn[0].to(DEV).double(), bn[1].to(DEV).double(), bn[2].to(DEV).double(),
+                              bn[3].to(DEV).double(), False, 0., 1e-5) + res.to(DEV).double()).float()
+    layer = ConvLayer(w, padding=1, bias=bias, bn=bn, relu_post=True, device=DEV)
+    outs = []
+    for _ in range(2):
+        outs.append(layer(x.to(DEV), residual=res.to(DEV)).clone())
+    assert torch.equal(outs[0], outs[1]), "stream-K results must be bit-reproducible"
+    assert_close(outs[0].cpu().numpy(), ref.cpu().numpy(), atol=3e-5, rtol=1e-5, what="stream-K epilogue")
+    sig = ConvLayer(w, padding=1, bias=bias, sigmoid=True, out_c_total=cout + 24, out_c_offset=8, device=DEV)
+    out = torch.full((B, cout + 24, H, W), 7.0, device=DEV)
+    sig(x.to(DEV), out=out)
+    assert (out[:, :8] == 7).all() and (out[:, 8 + cout:] == 7).all(), "channels outside the window were touched"
+    assert_close(out[:, 8:8 + cout].cpu().numpy(), torch.sigmoid(conv64 + bias.to(DEV).double()[None, :, None, None]).float().cpu().numpy(), atol=1e-5, what="stream-K sigmoid window")
+
+
 def test_crop_rotate_matches_torch_grid_sample():
     from lav_amd import ops
     from lav_amd.planner_common import crop_feature_torch
