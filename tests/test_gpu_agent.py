@@ -110,18 +110,19 @@ def test_agent_vs_reference_agent_golden(golden, tmp_path, hip_graphs):
     for i in range(ticks):
         ctl = a.run_step(synth.agent_inputs(i, sc, n_points=npts), i * 0.05)
         want = g["controls"][i]
-        # throttle is the speed PID on the waypoints' spacing (gain 5 on a difference of waypoint norms): 5e-3 covers waypoints
-        # that agree to 1e-4 m; the brake decision (pred_bra > 0.1, plan_collide, PID brake) must be the reference's on every tick
-        assert abs(ctl.steer - want[0]) < 1e-3 and abs(ctl.throttle - want[1]) < 5e-3 and ctl.brake == want[2], (i, ctl, want)
+        # throttle is the speed PID on the waypoints' spacing (gain 5 on a difference of waypoint norms).  Round 5: the bars
+        # sit near what is measured (tools/agent_dev.py, profiles/r05_agent_dev.txt: steer 5.2e-7, throttle 7.3e-6 at most over the
+        # 24 ticks) instead of at what waypoints agreeing to 1e-4 m would allow (1e-3 / 5e-3 before); the brake decision
+        # (pred_bra > 0.1, plan_collide, PID brake) must be the reference's on every tick
+        assert abs(ctl.steer - want[0]) < 1e-4 and abs(ctl.throttle - want[1]) < 5e-4 and ctl.brake == want[2], (i, ctl, want)
         if i == 0:
             continue
         out = a.last_outputs
         # pose handed to the stacking = the reference's EKF state before the tick
         pose = a.pipeline.poses[-1] if hip_graphs else (a.pipeline.locs[-1], a.pipeline.oris[-1])
-        # (the EKF integrates the PREVIOUS ticks' steer - held to 1e-3 above - through the bicycle model: a steer difference d
-        # moves the pose by about speed * 0.05 s * d / 2 per tick, so 1e-4 m here is the steer bar's own consequence; measured
-        # 1.6e-5 m with the crop stems on the split-operand kernel, < 1e-6 while they ran on the fp32 kernel)
-        np.testing.assert_allclose(np.r_[pose[0], pose[1]], g["poses"][i], rtol=0, atol=1e-4)
+        # (the EKF integrates the PREVIOUS ticks' steer through the bicycle model: a steer difference d moves the pose by about
+        # speed * 0.05 s * d / 2 per tick; measured 5.4e-7 m at most over the 24 ticks, bar 1e-5 - round 4 had 1e-4)
+        np.testing.assert_allclose(np.r_[pose[0], pose[1]], g["poses"][i], rtol=0, atol=1e-5)
         if hip_graphs:
             np.testing.assert_allclose(a.pipeline.b_nxp.cpu().numpy(), g["nxps"][i], rtol=1e-5, atol=1e-4)
         assert abs(float(out["pred_bra"]) - g["pred_bra"][i]) < 1e-5
