@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from collections import deque
 
 import numpy as np
@@ -183,6 +184,8 @@ class GraphedFramePipeline(FramePipeline):
             trunk._drop()
         self.graphs, self.outs = {}, {}
         self.frame_no = 0
+        self._h2d_stage = {}          # device staging tensors of host inputs, by (input, shape, strides)
+        self.host_trace = [] if os.environ.get("LAV_FRAME_HOST_TRACE") else None   # (label, perf_counter) stamps of step()
         self.overflow_ticks = 0       # ticks larger than the static buffers (each grew them and re-captured the graphs)
         self.forced_others = None     # set_forced_others: (actors, count, n) on the device
         self.decode_mismatches = 0    # frames on which the device and host detection decodes disagreed (host result used)
@@ -285,6 +288,11 @@ class GraphedFramePipeline(FramePipeline):
         with ops.batch_limit(self.d_n):
             return self._g_others(15)
 
+    def _stamp(self, label):
+        """Host-side time stamps of one step (LAV_FRAME_HOST_TRACE=1, tools/host_tail_probe.py): where the host spends the frame."""
+        if self.host_trace is not None:
+            self.host_trace.append((label, time.perf_counter()))
+
     def _replay(self, key, fn, stream, *args, _skip=False):
         """Replay graph `key` on the current stream; first use: one eager run on the capture stream (builds the
         convolution engines and the per-stream workspaces), then the capture.  Every graph has a PRIVATE memory pool:
@@ -353,9 +361,24 @@ class GraphedFramePipeline(FramePipeline):
             self.b_prev.copy_(self.b_tick)
             self.prev_lidar = True
             return None
+        self._stamp("enter")
         # the tick's LiDAR rows, camera tensors and next waypoint into the graphs' static buffers: one launch (tensors that are
         # not float32 / contiguous / device resident take Tensor.copy_ inside copy_many)
         pairs = [(self.b_tick[:n], lidar[:n]), (self.b_all_rgbs, all_rgbs), (self.b_rgbs, rgbs), (self.b_tel, tel_rgbs), (self.b_nxp, nxps)]
+        # HOST tensors (the sensor path of a real drive) travel as they lie in memory - strides kept - into device staging tensors
+        # (asynchronously when they are pinned), and the layout change happens on the GPU with the rest of copy_many.  Copied straight
+        # into the static buffers, a channels-last camera tensor is permuted by torch ON THE CPU first: 37 ms of host time per frame
+        # (tools/upload_probe.py: 39.8 frames/s against 402 this way and 431 with resident inputs).
+        for k, (b, t) in enumerate(pairs):
+            if isinstance(t, torch.Tensor) and not t.is_cuda and t.dtype == torch.float32:
+                key = (k, tuple(t.shape), tuple(t.stride()))
+                st = self._h2d_stage.get(key)
+                if st is None:
+                    if len(self._h2d_stage) > 64:
+                        self._h2d_stage.clear()
+                    st = self._h2d_stage[key] = torch.empty_like(t, device=self.device)   # (preserve_format: dense layouts keep their strides)
+                st.copy_(t, non_blocking=t.is_pinned())
+                pairs[k] = (b, st)
         if all(isinstance(t, torch.Tensor) and t.is_cuda and t.shape == b.shape for b, t in pairs):
             ops.copy_many(pairs)
         else:
@@ -370,7 +393,9 @@ class GraphedFramePipeline(FramePipeline):
         cmd_value = int(cmd_value)
         main = torch.cuda.current_stream()
         self.ev_in.record(main)                                        # inputs are in their static buffers
+        self._stamp("inputs enqueued")
         o_lidar = self._replay("lidar", self._g_lidar, self.s_cap)
+        self._stamp("lidar graph launched")
         self.s_bra.wait_event(self.ev_in)
         with torch.cuda.stream(self.s_bra):
             o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
@@ -380,6 +405,7 @@ class GraphedFramePipeline(FramePipeline):
             o_ego = self._replay(("ego", cmd_value), self._g_ego, self.s_ego, cmd_value,
                                  _skip="ego" in _DIAG_SKIP and ("ego", cmd_value) in self.graphs)
         o_heads = self._replay("heads", self._g_heads, self.s_cap)
+        self._stamp("brake, ego, heads graphs launched")
         self.frame_no += 1
         up = self.infer_model.uniplanner
         if self.device_others:
@@ -391,7 +417,9 @@ class GraphedFramePipeline(FramePipeline):
             ob = self._replay("others_cap", self._g_others_cap, self.s_cap)
             main.wait_stream(self.s_ego)      # also keeps the next frame's input copies behind this frame's readers
             main.wait_stream(self.s_bra)
+            self._stamp("others graph launched")
             self.ev_det.synchronize()
+            self._stamp("heads done on the GPU (event)")
             if not np.isfinite(self.hn_det).all():   # the peak rows are on the host every frame: their check costs no launch
                 self.nonfinite_det_frames += 1
             det, locs, oris = self.infer_model.det_decode_fast(self.hn_det)
@@ -417,6 +445,7 @@ class GraphedFramePipeline(FramePipeline):
             else:   # the reference returns CPU zeros (model_inference.py:167-168)
                 other_cast = torch.zeros((0, up.num_cmds, up.num_plan, 2))
                 other_cmds = torch.zeros((0, up.num_cmds))
+            self._stamp("decoded, return")
             return dict(ego_embd=o_ego["ego_embd"], ego_plan_locs=o_ego["ego_plan_locs"], ego_cast_locs=o_ego["ego_cast_locs"],
                         other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=o_heads["pred_bev"],
                         det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])

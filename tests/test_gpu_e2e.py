@@ -159,6 +159,36 @@ def test_graphed_frame_pipeline_matches_eager(models):
         assert_close(b["pred_bev"].cpu().numpy(), a["pred_bev"].cpu().numpy(), atol=1e-5, what=f"frame {i} pred_bev")
 
 
+def test_host_sensor_tensors_give_the_resident_inputs_frame(models):
+    """step() handed HOST tensors (the sensor path of a real drive: pinned channels-last camera tensors, a pageable contiguous LiDAR
+    tick) stages them to the device with their strides kept and lets copy_many change the layout there (round 5: copied straight into
+    the static buffers, torch permuted the camera tensors on the CPU - 37 ms per frame).  Same frames, same outputs, bit for bit."""
+    from lav_amd.frame import GraphedFramePipeline
+    from lav_amd.rgb import RGBBrakePredictionModel, RGBSegmentationModel
+    lm, up = models
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval().to(DEV)
+    bra = RGBBrakePredictionModel([4, 6, 7, 10]); bra.load_state_dict(synth.seeded_state_dict(bra, prefix="bra.")); bra.eval().to(DEV)
+    cams, tel = synth.rgb_frames()
+    rgbs = [c[..., :3][..., ::-1] for c in cams]
+    # channels-last in memory, as bench.py's synthetic_inputs builds them (transpose + astype keeps the strides)
+    h_all = torch.from_numpy(np.stack(rgbs, 0).transpose(0, 3, 1, 2).astype(np.float32)).pin_memory()
+    h_wide = torch.from_numpy(np.concatenate(rgbs, axis=1)[None].transpose(0, 3, 1, 2).astype(np.float32)).pin_memory()
+    h_tel = torch.from_numpy(tel[..., :3][..., ::-1][:-96][None].transpose(0, 3, 1, 2).astype(np.float32)).pin_memory()
+    assert not h_all.is_contiguous() and h_all.is_pinned()
+    h_nxp = torch.tensor([1.0, -9.0])
+    outs = []
+    for host in (False, True):
+        pipe = GraphedFramePipeline(lm, up, seg, bra, 1.5, 2.4, device=DEV, points_per_tick=8192)
+        o = None
+        for i in range(18):
+            tick = torch.from_numpy(synth.lidar_sweep(8192 if i % 3 else 7000, name=f"h{i}"))
+            args = (tick, h_all, h_wide, h_tel) if host else (tick.to(DEV), h_all.to(DEV), h_wide.to(DEV), h_tel.to(DEV))
+            o = pipe.step(*args, np.array([0.3 * i, 0.05 * i]), 0.02 * i, h_nxp if host else h_nxp.to(DEV), 3)
+        outs.append({k: o[k].clone() for k in ("ego_plan_locs", "ego_cast_locs", "other_cast_locs", "pred_bra", "pred_bev")})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_forced_others_hook_runs_the_others_branch_on_the_given_poses(models):
     """set_forced_others (frame time at a fixed number of other vehicles): the others branch's outputs are those of the
     given poses - crop_feature + embedder + cast on this frame's feature map - whatever the heads detect; n = 0 gives the
