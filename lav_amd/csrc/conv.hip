@@ -446,6 +446,7 @@ int build_plan(const lav_conv &c, Plan &p) {
 }
 
 #include "conv_split.hpp"
+#include "conv_smallcin.hpp"
 
 // Tile shape + staging geometry.  Cost model (units: MFMA time of one k-step): a CU runs ceil(nwg/256) workgroups
 // back to back on its matrix pipes, each costing MP*MC MFMAs per k-step plus ~0.5 of LDS staging / operand fetch.
@@ -821,11 +822,12 @@ Choice decide(const lav_conv &c, const Plan &p, double tile_cost, double tile_ra
             if (ch.sp.ok && (mode == 2 || (ch.sp.cost < other && !deep_stem))) ch.kind = 2;
         }
     }
+    if (smallcin_applies(c)) ch.kind = 3;   // camera stems: K = 3 x taps on packed fp32 FMAs (conv_smallcin.hpp)
     static const bool dbg = getenv("LAV_CONV_PLAN_DEBUG") != nullptr;
     if (dbg)
         fprintf(stderr, "[conv plan] B%d %d->%d k%dx%d s%d %dx%d%s: tiled %.1f us, direct %.1f us, split %.1f us -> %s\n", c.batch, c.cin, c.cout, c.kh, c.kw,
                 c.stride, c.h, c.w, c.transposed ? " T" : "", tile_raw, ch.dp.ok ? ch.dp.cost : -1.0, ch.sp.ok ? ch.sp.cost : -1.0,
-                ch.kind == 2 ? "split" : ch.kind == 1 ? "direct" : "tiled");
+                ch.kind == 3 ? "small-cin" : ch.kind == 2 ? "split" : ch.kind == 1 ? "direct" : "tiled");
     return ch;
 }
 }  // namespace
@@ -843,6 +845,11 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     if (rc) return rc;
     const Choice ch = decide(*c, p, cost, raw);
     const DirectPlan &d = ch.dp;
+    if (ch.kind == 3) {   // small-cin vector kernel: info[0] = -2, tile width, tile rows, workgroups; LDS; no split-K
+        info[0] = -2; info[1] = SC_TW; info[2] = SC_TH; info[3] = ((p.OW + SC_TW - 1) / SC_TW) * ((p.OH + SC_TH - 1) / SC_TH) * c->batch; info[4] = 0;
+        info[5] = 0; info[6] = 1; info[7] = 1; info[8] = 1;
+        return LAV_OK;
+    }
     if (ch.kind == 2) {   // split kernel: info[0] = -1, then MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows
         info[0] = -1; info[1] = ch.sp.MP; info[2] = ch.sp.MC; info[3] = ch.sp.WPX; info[4] = ch.sp.tw; info[5] = (int)ch.sp.lds;
         info[6] = ch.sp.sk_w ? -ch.sp.sk_w : ch.sp.ksplit; info[7] = ch.sp.tap_group + 100 * ch.sp.tp; info[8] = ch.sp.th;   // (tap group + 100 in tap-pair mode; split-K < 0: stream-K over that many workgroups)
@@ -1063,6 +1070,7 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     const Choice ch = decide(*c, p, cost, raw);
     if (ch.kind == 1) a.ksplit = ch.dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
+    if (ch.kind == 3) return 0;
     const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);   // stream-K: head and tail parts of the cut tiles
     return (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
 }
@@ -1092,6 +1100,10 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     const Choice ch = decide(*c, p, cost, raw);
     const DirectPlan &dp = ch.dp;
     const bool direct = ch.kind == 1;
+    if (ch.kind == 3) {
+        a.pad_value = c->pad_value;
+        return launch_smallcin(*c, p, a, static_cast<hipStream_t>(stream));
+    }
     if (direct) a.ksplit = dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);

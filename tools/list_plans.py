@@ -57,6 +57,10 @@ for name, conv, shp in todo:
     s = conv.stride[0]
     QH, QW = (shp[2], shp[3]) if tr else (oh.value, ow.value)
     ncls = s * s if tr else 1
+    if MP == -2:  # small-cin vector kernel: info = {-2, tile width, tile rows, workgroups, ...}
+        print(f"{name:10s} {'T' if tr else 'C'} {cin:4d}->{cout:4d} k{conv.kernel_size[0]}x{conv.kernel_size[1]} s{s} d{conv.dilation[0]},{conv.dilation[1]} "
+              f"in {shp[0]}x{shp[2]}x{shp[3]:<4d} small-cin (packed fp32 FMA) tile {MCt}x{rb} wgs={Wst:5d} rounds={-(-Wst // 256)}")
+        continue
     if MP == -1:  # split-operand kernel (bf16x6): info = {-1, MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows}
         mp, mc, wpx, tw, th = MCt, rb, Wst, ROWS, cps
         pixw = wpx * mp * 32
