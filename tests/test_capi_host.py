@@ -258,10 +258,13 @@ def test_direct_plan_is_chosen_where_it_was_measured_faster():
         assert waves in (1, 2, 4, 8, 16) and mc in (1, 2) and cin % (8 * waves * ks) == 0
         assert i[5] == waves * mc * 32 * 33 * 4 <= 160 * 1024
         assert mc == 1 or shp[2] >= 64
-    tiled = [(1, 384, 64, 7, 2, 3, 96, 96), (7, 384, 64, 7, 2, 3, 96, 96), (1, 384, 256, 3, 1, 1, 160, 160), (1, 3, 64, 7, 2, 3, 288, 768),
-             (1, 13, 48, 3, 1, 1, 20, 33)]
+    tiled = [(1, 384, 64, 7, 2, 3, 96, 96), (7, 384, 64, 7, 2, 3, 96, 96), (1, 384, 256, 3, 1, 1, 160, 160), (1, 13, 48, 3, 1, 1, 20, 33)]
     for shp in tiled:
         assert plan(*shp)[0] >= 1, f"{shp}: expected a tiled plan"
+    # the camera stems (3 input channels, stride 2) run on packed fp32 FMAs (round 5, conv_smallcin.hpp): plan {-2, tile 32 x 8, workgroups}
+    for shp, wgs in (((1, 3, 64, 7, 2, 3, 288, 768), 216), ((1, 3, 64, 7, 2, 3, 192, 480), 96), ((3, 3, 13, 3, 2, 1, 288, 256), 216)):
+        i = plan(*shp)
+        assert i[:4] == [-2, 32, 8, wgs], f"{shp}: expected the small-cin kernel, got {i}"
     # transposed convolutions run on the direct kernel too (one launch, output-parity classes in grid.z)
     i = plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)
     assert i[0] == 0 and i[2] == 2
