@@ -42,7 +42,7 @@ def probe(label, pts, reps=50):
     k, p = read("pointnet_scatter"), read("pillar_prep")
     lib.lav_profile_enable(0)
     nb = 4 * (len(pts) * 11 + 64 * 320 * 320)
-    print(f"ZERO={os.environ.get('LAV_PILLAR_ZERO', 'rows'):4s} {label:28s} n={len(pts):7d} kernel {k:6.1f} us ({nb / k / 1e3:6.0f} GB/s, {nb / k / 8e3 * 100:4.1f}%)  prep {p:6.1f} us  stage {k + p:6.1f} us ({nb / (k + p) / 8e3 * 100:4.1f}%)", flush=True)
+    print(f"ZERO={os.environ.get('LAV_PILLAR_ZERO', 'rows'):4s} {label:28s} n={len(pts):7d} kernel {k:6.1f} us ({nb / k / 1e3:6.0f} GB/s, {nb / k / 8e6 * 100:4.1f}% of 8 TB/s)  prep {p:6.1f} us  stage {k + p:6.1f} us ({nb / (k + p) / 8e6 * 100:4.1f}%)", flush=True)
 
 
 def ev_time(fn, reps=50):
