@@ -846,7 +846,8 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     const Choice ch = decide(*c, p, cost, raw);
     const DirectPlan &d = ch.dp;
     if (ch.kind == 3) {   // small-cin vector kernel: info[0] = -2, tile width, tile rows, workgroups; LDS; no split-K
-        info[0] = -2; info[1] = SC_TW; info[2] = SC_TH; info[3] = ((p.OW + SC_TW - 1) / SC_TW) * ((p.OH + SC_TH - 1) / SC_TH) * c->batch; info[4] = 0;
+        const int th = smallcin_tile_rows(*c);
+        info[0] = -2; info[1] = SC_TW; info[2] = th; info[3] = ((p.OW + SC_TW - 1) / SC_TW) * ((p.OH + th - 1) / th) * c->batch; info[4] = 0;
         info[5] = 0; info[6] = 1; info[7] = 1; info[8] = 1;
         return LAV_OK;
     }

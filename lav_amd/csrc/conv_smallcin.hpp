@@ -27,10 +27,11 @@ struct SmallCinArgs {
     float pad_value;
 };
 
-constexpr int SC_TW = 32, SC_TH = 8;   // output pixels of a tile; thread (tx, ty4) owns rows ty4 and ty4 + 4
+constexpr int SC_TW = 32;   // output columns of a tile; rows: PPT x 4 (a thread owns PPT pixels: rows ty and, PPT = 2, ty + 4)
 
-template <int CIN, int K, int S, int COUT, int CS>
+template <int CIN, int K, int S, int COUT, int CS, int PPT>
 __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
+    constexpr int SC_TH = 4 * PPT;
     constexpr int PW = (SC_TW - 1) * S + K, PH = (SC_TH - 1) * S + K;      // patch
     constexpr int PWS = PW | 1;                                            // odd row stride: the stride-2 column reads of a wave spread over the banks
     constexpr int NT = K * K;
@@ -94,9 +95,9 @@ __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
         s_ep[2 * COUT + tid] = a.scale ? a.shift[cc] : 0.f;
     }
     __syncthreads();
-    sc_v2f acc[2][CH / 2];
+    sc_v2f acc[PPT][CH / 2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PPT; ++p)
 #pragma unroll
         for (int q = 0; q < CH / 2; ++q) acc[p][q] = sc_v2f{0.f, 0.f};
     const float *in0 = s_in + (ty * S) * PWS + tx * S;            // pixel (ty, tx); the second pixel sits 4 S rows further down
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
             const float *wrow = s_w + ((ky * K) * CIN + ci) * COUT + c_lo;
             float xa[K], xb[K];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) { xa[kx] = r0[kx]; xb[kx] = r1[kx]; }
+            for (int kx = 0; kx < K; ++kx) { xa[kx] = r0[kx]; xb[kx] = PPT == 2 ? r1[kx] : 0.f; }
 #pragma unroll
             for (int q = 0; q < CQ; ++q) wbuf[0][q] = reinterpret_cast<const float4 *>(wrow)[q];
 #pragma unroll
@@ -131,8 +132,10 @@ __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
                     const int o = 2 * (h * CQ + q);
                     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[0][o]) : "v"(x0), "v"(wa));
                     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[0][o + 1]) : "v"(x0), "v"(wb));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[1][o]) : "v"(x1), "v"(wa));
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[1][o + 1]) : "v"(x1), "v"(wb));
+                    if constexpr (PPT == 2) {
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[1][o]) : "v"(x1), "v"(wa));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[1][o + 1]) : "v"(x1), "v"(wb));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -141,10 +144,10 @@ __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
     // epilogue (as k_conv_direct): a wave's 32 lanes of one row write 128 contiguous bytes per channel
     const long plane_o = (long)a.OH * a.OW;
     const int ox = ox0 + tx;
-    bool pok[2];
-    long pix[2];
+    bool pok[PPT];
+    long pix[PPT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < PPT; ++p) {
         const int oy = oy0 + ty + 4 * p;
         pok[p] = oy < a.OH && ox < a.OW;
         pix[p] = (long)min(oy, a.OH - 1) * a.OW + min(ox, a.OW - 1);
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int cl = 4 * c4 + j, co = c_lo + cl;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < PPT; ++p) {
                 if (co >= a.cout || !pok[p]) continue;
                 float v = acc[p][cl >> 1][cl & 1] + bb[j];
                 if (a.relu_pre) v = v > 0.f ? v : 0.f;
@@ -177,20 +180,26 @@ __global__ __launch_bounds__(128 * CS) void k_conv_smallcin(SmallCinArgs a) {
 inline bool smallcin_applies(const lav_conv &c) {
     const char *e = getenv("LAV_CONV_SMALLCIN");
     if (e && atoi(e) == 0) return false;
-    if (c.transposed || c.cin != 3 || c.dil_h != 1 || c.dil_w != 1 || c.kh != c.kw || c.stride != 2) return false;
+    if (c.transposed || c.dil_h != 1 || c.dil_w != 1 || c.kh != c.kw || c.stride != 2) return false;
+    // (ERFNet's second downsampler, 16 -> 48 with K = 144, was tried on an instance <16, 3, 2, 48, 4, 1> of this kernel: 33.3 us against 25.4 us
+    // on the split kernel - the 37 KB patch per 4 x 32 tile costs more than the matrix kernel's prologue; not kept.)
+    if (c.cin != 3) return false;
     return (c.kh == 7 && c.cout <= 64 && c.cout > 16) || (c.kh == 3 && c.cout <= 16);
 }
 
-template <int CIN, int K, int S, int COUT, int CS>
+inline int smallcin_tile_rows(const lav_conv &) { return 8; }   // 4 x pixels per thread (PPT) of the instance that takes the layer
+
+template <int CIN, int K, int S, int COUT, int CS, int PPT>
 int launch_smallcin_t(const SmallCinArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int SC_TH = 4 * PPT;
     constexpr int PW = (SC_TW - 1) * S + K, PH = (SC_TH - 1) * S + K, PWS = PW | 1;
     constexpr size_t lds = (size_t)(K * K * CIN * COUT + CIN * PH * PWS + 3 * COUT) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_smallcin<CIN, K, S, COUT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_smallcin<CIN, K, S, COUT, CS, PPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_smallcin<CIN, K, S, COUT, CS>), grid, dim3(128 * CS), lds, st, a);
+    hipLaunchKernelGGL((k_conv_smallcin<CIN, K, S, COUT, CS, PPT>), grid, dim3(128 * CS), lds, st, a);
     return LAV_OK;
 }
 
@@ -200,13 +209,14 @@ inline int launch_smallcin(const lav_conv &c, const Plan &p, const ConvArgs &ca,
     a.in_c_total = c.in_c_total; a.in_c_offset = c.in_c_offset; a.H = c.h; a.W = c.w;
     a.cout = c.cout; a.out_c_total = c.out_c_total; a.out_c_offset = c.out_c_offset; a.OH = p.OH; a.OW = p.OW;
     a.cin_pad = p.cin_pad; a.ntaps = c.kh * c.kw; a.pad_h = c.pad_h; a.pad_w = c.pad_w;
-    a.tiles_x = (p.OW + SC_TW - 1) / SC_TW; a.tiles_y = (p.OH + SC_TH - 1) / SC_TH;
+    const int th = smallcin_tile_rows(c);
+    a.tiles_x = (p.OW + SC_TW - 1) / SC_TW; a.tiles_y = (p.OH + th - 1) / th;
     a.relu_pre = c.relu_pre; a.relu_post = c.relu_post; a.sigmoid = c.sigmoid; a.pad_value = c.pad_value;
     const dim3 grid(a.tiles_x, a.tiles_y, c.batch);
     const int tok = timer_begin("conv2d", st);
     int rc;
-    if (c.kh == 7) rc = launch_smallcin_t<3, 7, 2, 64, 4>(a, grid, st);
-    else rc = launch_smallcin_t<3, 3, 2, 16, 2>(a, grid, st);
+    if (c.kh == 7) rc = launch_smallcin_t<3, 7, 2, 64, 4, 2>(a, grid, st);
+    else rc = launch_smallcin_t<3, 3, 2, 16, 2, 2>(a, grid, st);
     timer_end(tok, st);
     if (rc) return rc;
     LAV_LAUNCH_CHECK();

@@ -262,9 +262,9 @@ def test_direct_plan_is_chosen_where_it_was_measured_faster():
     for shp in tiled:
         assert plan(*shp)[0] >= 1, f"{shp}: expected a tiled plan"
     # the camera stems (3 input channels, stride 2) run on packed fp32 FMAs (round 5, conv_smallcin.hpp): plan {-2, tile 32 x 8, workgroups}
-    for shp, wgs in (((1, 3, 64, 7, 2, 3, 288, 768), 216), ((1, 3, 64, 7, 2, 3, 192, 480), 96), ((3, 3, 13, 3, 2, 1, 288, 256), 216)):
+    for shp, th, wgs in (((1, 3, 64, 7, 2, 3, 288, 768), 8, 216), ((1, 3, 64, 7, 2, 3, 192, 480), 8, 96), ((3, 3, 13, 3, 2, 1, 288, 256), 8, 216)):
         i = plan(*shp)
-        assert i[:4] == [-2, 32, 8, wgs], f"{shp}: expected the small-cin kernel, got {i}"
+        assert i[:4] == [-2, 32, th, wgs], f"{shp}: expected the small-cin kernel, got {i}"
     # transposed convolutions run on the direct kernel too (one launch, output-parity classes in grid.z)
     i = plan(1, 128, 128, 4, 2, 1, 80, 80, tr=True)
     assert i[0] == 0 and i[2] == 2

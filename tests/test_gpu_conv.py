@@ -107,8 +107,9 @@ def test_split_k_epilogue_matches_unsplit():
     assert_close(y.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5, what="split-K epilogue")
 
 
-@pytest.mark.parametrize("k,cout,B,H,W", [(7, 64, 1, 288, 768), (7, 64, 2, 50, 70), (3, 13, 3, 288, 256), (3, 13, 2, 37, 45), (7, 40, 1, 20, 24), (3, 16, 1, 16, 64)])
-def test_small_cin_vector_kernel(k, cout, B, H, W):
+@pytest.mark.parametrize("cin,k,cout,B,H,W", [(3, 7, 64, 1, 288, 768), (3, 7, 64, 2, 50, 70), (3, 3, 13, 3, 288, 256), (3, 3, 13, 2, 37, 45), (3, 7, 40, 1, 20, 24),
+                                              (3, 3, 16, 1, 16, 64)])
+def test_small_cin_vector_kernel(cin, k, cout, B, H, W):
     """The camera stems (3 input channels, stride 2: brake net 7x7 -> 64, ERFNet 3x3 -> 13) on k_conv_smallcin (packed fp32 FMAs, round 5):
     an fp32 FMA chain per output - held to 2e-6 of sum |w||x| against float64 - ragged tiles, a folded-normalisation pad value, every
     epilogue piece, channel windows on both sides, and the layers' real sizes; the plan says which kernel ran."""
@@ -117,23 +118,23 @@ def test_small_cin_vector_kernel(k, cout, B, H, W):
     from lav_amd._lib import Conv
     lib = _lib.load()
     info = (C.c_int * 9)()
-    d = Conv(B, 3, 0, 3, H, W, cout, k, k, 2, k // 2, k // 2, 1, 1, 0, 0, cout, 0, 0, 0, 0)
+    d = Conv(B, cin, 0, cin, H, W, cout, k, k, 2, k // 2, k // 2, 1, 1, 0, 0, cout, 0, 0, 0, 0)
     assert lib.lav_conv_tile_info(C.byref(d), info) == 0 and info[0] == -2, f"expected the small-cin kernel, plan {list(info)}"
-    x = rnd((B, 5, H, W), 51)
-    w = rnd((cout, 3, k, k), 52, scale=1.0 / np.sqrt(3 * k * k))
+    x = rnd((B, cin + 2, H, W), 51)
+    w = rnd((cout, cin, k, k), 52, scale=1.0 / np.sqrt(cin * k * k))
     bias = rnd((cout,), 53)
     bn = (rnd((cout,), 54, 0.1), rnd((cout,), 55).abs() + 0.5, rnd((cout,), 56).abs() + 0.5, rnd((cout,), 57, 0.1))
-    xin = x[:, 1:4]
+    xin = x[:, 1:1 + cin]
     ref64 = F.conv2d(xin.double(), w.double(), None, 2, k // 2)
     mag = F.conv2d(xin.double().abs(), w.double().abs(), None, 2, k // 2)
-    y = ConvLayer(w, stride=2, padding=k // 2, in_c_total=5, in_c_offset=1, device=DEV)(x.to(DEV)).cpu()
+    y = ConvLayer(w, stride=2, padding=k // 2, in_c_total=cin + 2, in_c_offset=1, device=DEV)(x.to(DEV)).cpu()
     err = ((y.double() - ref64).abs() / mag.clamp_min(1e-30)).max().item()
     assert err < 2e-6, f"max |y - ref| / sum|w||x| = {err:.3e}"
     # conv -> + bias -> relu -> bn into a channel window, out-of-image taps reading a pad value (ERFNet's folded input normalisation)
     pv = 0.37
     xp = F.pad(xin, (k // 2,) * 4, value=pv)
     ref = F.batch_norm(F.relu(F.conv2d(xp, w, bias, 2, 0)), bn[0], bn[1], bn[2], bn[3], False, 0., 1e-3)
-    layer = ConvLayer(w, stride=2, padding=k // 2, bias=bias, bn=bn, bn_eps=1e-3, relu_pre=True, in_c_total=5, in_c_offset=1, out_c_total=cout + 5,
+    layer = ConvLayer(w, stride=2, padding=k // 2, bias=bias, bn=bn, bn_eps=1e-3, relu_pre=True, in_c_total=cin + 2, in_c_offset=1, out_c_total=cout + 5,
                       out_c_offset=2, pad_value=pv, device=DEV)
     out = torch.full((B, cout + 5, ref.shape[2], ref.shape[3]), 7.0, device=DEV)
     layer(x.to(DEV), out=out)
