@@ -498,8 +498,10 @@ int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_p
  * leave the CU.  residual[i] != 0: pair i adds the INPUT of pair i-1 (the block's input) before its ReLU; the run starts at a
  * block boundary.  out[i]: output buffer of pair i ([batch][channels][h][w] each, all distinct; out[npairs-1] is the result).
  * batch * h must not exceed the CU count (every row's workgroup waits for its neighbours'); bf16x6 precision only.  Waits are
- * bounded: a workgroup that gives up voids the launch's result and raises a sticky counter - lav_conv1d_pair_chain_status copies
- * {workgroups that gave up, launches} since the workspace was zero-filled (it SYNCHRONISES `stream`; 0 = every result was valid).
+ * bounded: a workgroup that gives up raises the launch's abort word (its peers poll it and stop waiting too), fills ITS row of
+ * out[npairs-1] with NaN - a voided launch cannot be mistaken for a result: every row of the output is either the complete result or
+ * NaN (round 5) - and raises a sticky counter: lav_conv1d_pair_chain_status copies {workgroups that gave up, launches}
+ * since the workspace was zero-filled (it SYNCHRONISES `stream`; 0 = every result was valid).
  * workspace: lav_conv1d_pair_chain_workspace_bytes, ZERO before its first use, private to the stream.
  */
 size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h);
