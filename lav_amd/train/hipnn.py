@@ -122,7 +122,7 @@ def conv_relu_bn(seq, x):
         raise RuntimeError("expected [conv, relu, bn] triples")
     for j in range(0, len(mods), 3):
         c = mods[j]
-        y = conv_module(c, x) if isinstance(c, torch.nn.Conv2d) else c(x)    # (transposed convolutions: torch / MIOpen)
+        y = conv_module(c, x) if isinstance(c, torch.nn.Conv2d) else (conv_transpose_module(c, x) if isinstance(c, torch.nn.ConvTranspose2d) else c(x))
         x = bn_act(mods[j + 2], y, relu_pre=True)
     return x
 
@@ -131,11 +131,14 @@ def conv_relu_bn(seq, x):
 # Round 5: the training graph's 3x3 / 7x7 convolutions on liblav_amd's own kernels.
 #   forward        lav_conv2d (split-operand bf16x6 / fp32 plans, the inference kernels) over the LIVE parameter: the packed weights are
 #                  re-gathered on the device before the launch (lav_conv_repack through the layer's index map: one small launch)
-#   data gradient  the same kernel on the adjoint problem - a transposed convolution with the same weight tensor (stride 1 only: the
-#                  stride-2 adjoints lose against MIOpen, profiles/r03_train_conv_probe.txt, and stay there)
-#   weight gradient lav_conv_wgrad (bf16x6 matrix-core kernel, csrc/conv_wgrad.hip) for stride-1 3x3 layers on 16-pixel aligned rows -
-#                  the BEV backbone and the fused heads convolution, where the step spends its convolution time -, torch / MIOpen for
-#                  the rest (LAV_TRAIN_WGRAD=torch: everywhere)
+#   data gradient  the same kernel on the adjoint problem - a transposed convolution with the same weight tensor (strides 1 and 2,
+#                  profiles/r05_dgrad_probe.txt)
+#   weight gradient lav_conv_wgrad (bf16x6 matrix-core kernels, csrc/conv_wgrad.hip) for the 3x3 layers of stride 1 / 2 and the 7x7
+#                  stride-2 stems on maps from 40 x 40 - the BEV backbone, the fused heads convolution, the crops' stems: where the
+#                  step spends its convolution time -, torch / MIOpen for the rest (LAV_TRAIN_WGRAD=torch: everywhere)
+#   transposed     nn.ConvTranspose2d (the backbone's up-convolutions): torch / MIOpen by default; LAV_TRAIN_CONVT=hip: forward on
+#                  lav_conv2d's transposed plan, data gradient = the ordinary convolution with the same weight tensor on lav_conv2d,
+#                  weight gradient torch (correct, 1 ms per step slower: not the default)
 # LAV_TRAIN_CONV=torch routes everything back to torch.nn.functional (A/B timing, the CPU tests).
 _CONV_ENGINES = {}
 
@@ -228,6 +231,44 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding=(0, 0), di
             or os.environ.get("LAV_TRAIN_CONV", "hip") == "torch"):
         return F.conv2d(x, w, None, stride, tuple(padding), tuple(dilation))
     return _Conv2d.apply(x, w, int(stride), tuple(padding), tuple(dilation))
+
+
+class _ConvT2d(torch.autograd.Function):
+    """F.conv_transpose2d(x, w, None, stride, padding, output_padding) - w [cin][cout][k][k] as nn.ConvTranspose2d holds it."""
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, output_padding):
+        x = x.contiguous()
+        y = _conv_engine("fwdT", w, stride, padding, (1, 1), True, output_padding)(x)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, output_padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, output_padding = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # the adjoint of a transposed convolution is the ordinary convolution with the same tensor read as [out = cin][in = cout][k][k]
+            dx = _conv_engine("dgradT", w, stride, padding, (1, 1), False, 0)(dy)
+            if dx.shape != x.shape:   # (an output_padding larger than the stride's slack cannot occur for nn.ConvTranspose2d)
+                raise RuntimeError(f"transposed-convolution data gradient {tuple(dx.shape)} != input {tuple(x.shape)}")
+        if ctx.needs_input_grad[1]:
+            _, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], list(padding), [1, 1], True, [output_padding, output_padding], 1,
+                                                           [False, True, False])
+        return dx, dw, None, None, None
+
+
+def conv_transpose_module(conv: torch.nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
+    """nn.ConvTranspose2d forward in train mode on liblav_amd (kernel >= 2, no bias / groups / dilation; the rest: the module itself).
+    OPT-IN (LAV_TRAIN_CONVT=hip): measured 1 ms per train_full step SLOWER than MIOpen's Winograd solvers on the backbone's three
+    up-convolutions (129.3 / 128.2 vs 130.0 / 129.5 ms, interleaved) - the default stays torch; tests/test_gpu_train.py holds it to torch."""
+    if (conv.bias is not None or conv.groups != 1 or conv.stride[0] != conv.stride[1] or tuple(conv.dilation) != (1, 1) or conv.kernel_size[0] < 2
+            or conv.output_padding[0] != conv.output_padding[1] or not x.is_cuda or x.dtype != torch.float32 or not torch.is_grad_enabled()
+            or os.environ.get("LAV_TRAIN_CONV", "hip") == "torch" or os.environ.get("LAV_TRAIN_CONVT", "torch") != "hip"):
+        return conv(x)
+    return _ConvT2d.apply(x, conv.weight, int(conv.stride[0]), tuple(conv.padding), int(conv.output_padding[0]))
 
 
 def conv_module(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:

@@ -596,3 +596,29 @@ def test_training_convolution_function_vs_torch(B, cin, cout, k, s, H, W):
             assert (got.detach().cpu().double() - want.detach()).abs().max().item() < tol, (name, rep)
         with torch.no_grad():
             w.mul_(0.5).add_(0.01)
+
+
+@pytest.mark.parametrize("B,cin,cout,k,s,p,op,H,W", [(2, 128, 128, 4, 2, 1, 0, 20, 24), (2, 128, 64, 4, 4, 0, 0, 10, 12), (3, 64, 128, 3, 2, 1, 1, 16, 16)])
+def test_training_transposed_convolution_function_vs_torch(B, cin, cout, k, s, p, op, H, W, monkeypatch):
+    """lav_amd.train.hipnn.conv_transpose_module with LAV_TRAIN_CONVT=hip (opt-in: 1 ms per step slower than MIOpen on the backbone's
+    up-convolutions): forward on lav_conv2d's transposed plan over
+    the live parameter, data gradient = the ordinary convolution with the same tensor, weight gradient torch - against torch's own
+    ConvTranspose2d and its autograd in float64 (1e-4 of the largest reference value); a changed weight is seen by the next call."""
+    from lav_amd.train.hipnn import _ConvT2d, conv_transpose_module
+    monkeypatch.setenv("LAV_TRAIN_CONVT", "hip")
+    torch.manual_seed(B + cin + k)
+    m = torch.nn.ConvTranspose2d(cin, cout, k, s, p, op, bias=False).to(DEV)
+    x = torch.randn((B, cin, H, W), device=DEV, requires_grad=True)
+    for rep in range(2):
+        y = conv_transpose_module(m, x)
+        assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith(_ConvT2d.__name__), "the liblav_amd function must be the one that ran"
+        dy = torch.randn_like(y)
+        gx, gw = torch.autograd.grad(y, (x, m.weight), dy)
+        xr, wr = x.detach().cpu().double().requires_grad_(True), m.weight.detach().cpu().double().requires_grad_(True)
+        yr = torch.nn.functional.conv_transpose2d(xr, wr, None, s, p, op)
+        gxr, gwr = torch.autograd.grad(yr, (xr, wr), dy.cpu().double())
+        for name, got, want in (("y", y, yr), ("dx", gx, gxr), ("dw", gw, gwr)):
+            tol = 1e-4 * want.abs().max().item()
+            assert (got.detach().cpu().double() - want.detach()).abs().max().item() < tol, (name, rep)
+        with torch.no_grad():
+            m.weight.mul_(0.5).add_(0.01)
