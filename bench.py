@@ -31,7 +31,8 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (same guide); the split convolution kernels run on these pipes
 DTYPE = ("f32 (convolution contractions: fp32 operands split exactly into three bf16 pieces, the six leading partial products on the "
-         "bf16 matrix cores, f32 accumulate - error of an fp32 dot product, DESIGN 4.3; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
+         "bf16 matrix cores, f32 accumulate - error of an fp32 dot product, DESIGN 4.3; the head convolution: two scaled fp16 pieces, three "
+         "products, same error level, LAV_HEADS_PRECISION=bf16x6 restores; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
 
 
 def build_pipeline(device, eager=False):
@@ -441,13 +442,17 @@ def main():
             del am
         except Exception:  # noqa: BLE001 - a calibration line, never a reason to lose the bench
             vend = None
-        if info[0] == -1:   # split kernel: six bf16 MFMA products per fp32 product
-            executed = 6.0 * flops
-            return dict(bound="mfma", kernel="k_conv_split<2,2> heads 384->256 3x3 @160x160 (bf16x6 split operands)",
+        if info[0] == -1:   # split kernel: six bf16 MFMA products per fp32 product - or, LAV_CONV_F16X3 (round 5: what the frame pipelines
+            # ask for on this layer), three fp16 ones, with the launch that measures the activation scale inside the timed pair
+            f16 = info[7] >= 200
+            executed = (3.0 if f16 else 6.0) * flops
+            return dict(bound="mfma", kernel=("k_absmax_parts + k_conv_split_f16<2,2> heads 384->256 3x3 @160x160 (f16x3: two fp16 pieces per operand, three products)"
+                                              if f16 else "k_conv_split<2,2> heads 384->256 3x3 @160x160 (bf16x6 split operands)"),
+                        executed_per_algorithmic=3 if f16 else 6,
                         vendor_gemm_tflops=None if vend is None else round(vend, 1),
                         vendor_gemm="torch bf16 8192^3 matmul (hipBLASLt), 10 launches after 3 warm-ups, same process: the sustained bf16 rate of this box (power bound)",
                         frac_of_vendor_gemm=None if vend is None else round(executed / sec / 1e12 / vend, 4),
-                        achieved=round(executed / sec / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s (bf16 MFMA flops executed: 6 x 2MNK)",
+                        achieved=round(executed / sec / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s (16-bit MFMA flops executed: executed_per_algorithmic x 2MNK)",
                         frac=round(executed / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, algorithmic_flops=flops,
                         fp32_equivalent_tflops=round(flops / sec / 1e12, 1),
                         vs_fp32_mfma_peak=round(flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 3), avg_kernel_us=round(sec * 1e6, 1), launches=reps)

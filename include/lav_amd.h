@@ -256,6 +256,11 @@ typedef struct lav_conv {
 } lav_conv;
 #define LAV_CONV_F32 1
 #define LAV_CONV_BF16X6 2
+#define LAV_CONV_F16X3 3   /* round 5: as BF16X6, and where the plan is the 2x2 whole-K split kernel of a stride-1 layer (the head
+                              convolution) each operand is TWO fp16 pieces scaled by a power of two taken from the tensor's largest
+                              finite magnitude (measured by a first launch), three products: half the matrix instructions at 22 bits
+                              per operand - the error of the dot product stays at the level of its fp32 accumulation; lav_conv_repack
+                              does not support it (such layers are packed on the host) */
 
 /* output spatial size of the convolution */
 int lav_conv_out_hw(const lav_conv *c, int *oh, int *ow);

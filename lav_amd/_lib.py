@@ -36,7 +36,7 @@ class Conv(C.Structure):
         "dil_h", "dil_w", "transposed", "out_pad", "out_c_total", "out_c_offset", "relu_pre", "relu_post", "sigmoid", "target_cus")] + [("pad_value", C.c_float), ("precision", C.c_int)]
 
 
-CONV_F32, CONV_BF16X6 = 1, 2     # lav_conv.precision (0 = library default: LAV_CONV_PRECISION, bf16x6)
+CONV_F32, CONV_BF16X6, CONV_F16X3 = 1, 2, 3     # lav_conv.precision (0 = library default: LAV_CONV_PRECISION, bf16x6)
 
 
 # name -> (restype, argtypes); every symbol declared in include/lav_amd.h

@@ -788,13 +788,15 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
 // precision of a layer: LAV_CONV_F32 (exact fp32 MFMA kernels only) or LAV_CONV_BF16X6 (the split kernel where its plan
 // wins); 0 in the descriptor = LAV_CONV_PRECISION (f32 | bf16x6), default bf16x6
 int resolve_precision(const lav_conv &c) {
-    if (c.precision == LAV_CONV_F32 || c.precision == LAV_CONV_BF16X6) return c.precision;
+    if (c.precision == LAV_CONV_F32 || c.precision == LAV_CONV_BF16X6 || c.precision == LAV_CONV_F16X3) return c.precision;
     static const int dflt = [] {
         const char *e = getenv("LAV_CONV_PRECISION");
         return e && (!strcmp(e, "f32") || !strcmp(e, "fp32")) ? LAV_CONV_F32 : LAV_CONV_BF16X6;
     }();
     return dflt;
 }
+
+inline bool has_split_packing(int prec) { return prec == LAV_CONV_BF16X6 || prec == LAV_CONV_F16X3; }   // (F16X3 layers carry the bf16 pieces too: their fall-back)
 
 // which kernel runs a layer: 0 tiled fp32, 1 direct fp32, 2 split bf16x6
 struct Choice {
@@ -808,7 +810,7 @@ Choice decide(const lav_conv &c, const Plan &p, double tile_cost, double tile_ra
     ch.dp = choose_direct(c, p);
     ch.sp.ok = false;
     ch.kind = ch.dp.ok && ch.dp.cost < tile_cost ? 1 : 0;
-    if (resolve_precision(c) == LAV_CONV_BF16X6) {
+    if (has_split_packing(resolve_precision(c))) {
         const char *e = getenv("LAV_CONV_SPLIT");   // 0 never / 1 by cost / 2 whenever the split kernel can take the layer
         const int mode = e ? atoi(e) : 1;
         if (mode) {
@@ -822,6 +824,11 @@ Choice decide(const lav_conv &c, const Plan &p, double tile_cost, double tile_ra
             if (ch.sp.ok && (mode == 2 || (ch.sp.cost < other && !deep_stem))) ch.kind = 2;
         }
     }
+    // LAV_CONV_F16X3: where the split plan is the 2x2/w2 G = 2 whole-K kernel the mode is built for (the head convolution); any other
+    // layer of that precision runs as bf16x6
+    ch.sp.f16 = ch.kind == 2 && resolve_precision(c) == LAV_CONV_F16X3 && f16x3_layer(c, p) && !ch.sp.tp && ch.sp.MP == 2 && ch.sp.MC == 2 && ch.sp.WPX == 2 &&
+                        ch.sp.tap_group == 2 && ch.sp.ksplit == 1 && !ch.sp.sk_w && c.pad_value == 0.f
+                    ? 1 : 0;
     if (smallcin_applies(c)) ch.kind = 3;   // camera stems: K = 3 x taps on packed fp32 FMAs (conv_smallcin.hpp)
     static const bool dbg = getenv("LAV_CONV_PLAN_DEBUG") != nullptr;
     if (dbg)
@@ -853,7 +860,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
     }
     if (ch.kind == 2) {   // split kernel: info[0] = -1, then MP, MC, pixel waves, tile width (0 = linearised), LDS, split-K, tap group, tile rows
         info[0] = -1; info[1] = ch.sp.MP; info[2] = ch.sp.MC; info[3] = ch.sp.WPX; info[4] = ch.sp.tw; info[5] = (int)ch.sp.lds;
-        info[6] = ch.sp.sk_w ? -ch.sp.sk_w : ch.sp.ksplit; info[7] = ch.sp.tap_group + 100 * ch.sp.tp; info[8] = ch.sp.th;   // (tap group + 100 in tap-pair mode; split-K < 0: stream-K over that many workgroups)
+        info[6] = ch.sp.sk_w ? -ch.sp.sk_w : ch.sp.ksplit; info[7] = ch.sp.tap_group + 100 * ch.sp.tp + 200 * ch.sp.f16; info[8] = ch.sp.th;   // (tap group + 100 in tap-pair mode; split-K < 0: stream-K over that many workgroups)
         return LAV_OK;
     }
     if (ch.kind == 1) {   // direct path: info[0] = 0, info[1] = waves per workgroup
@@ -937,7 +944,10 @@ extern "C" size_t lav_conv_packed_weight_floats(const lav_conv *c) {
     Plan p;
     if (build_plan(*c, p)) return 0;
     // the fp32 packing, followed (16-byte aligned) by the three-piece bf16 packing of the split kernel
-    return resolve_precision(*c) == LAV_CONV_BF16X6 ? (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 4 : p.wfloats;
+    const int prec = resolve_precision(*c);
+    size_t n = has_split_packing(prec) ? (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 4 : p.wfloats;
+    if (prec == LAV_CONV_F16X3 && f16x3_layer(*c, p)) n += split_weight_bytes_f16(p) / 4 + 4;   // the fp16 pieces + their scale (16 bytes)
+    return n;
 }
 
 extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_packed) {
@@ -961,8 +971,10 @@ extern "C" int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, f
                 }
         });
     }
-    if (resolve_precision(*c) == LAV_CONV_BF16X6)
+    if (has_split_packing(resolve_precision(*c)))
         split_pack_weights(*c, p, h_weight, reinterpret_cast<unsigned char *>(h_packed + (p.wfloats + 3) / 4 * 4));
+    if (resolve_precision(*c) == LAV_CONV_F16X3 && f16x3_layer(*c, p))
+        split_pack_weights_f16(*c, p, h_weight, reinterpret_cast<unsigned char *>(h_packed + (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 4));
     return LAV_OK;
 }
 
@@ -975,7 +987,7 @@ extern "C" size_t lav_conv_pack_map_ints(const lav_conv *c) {
     if (!c) return 0;
     Plan p;
     if (build_plan(*c, p)) return 0;
-    if (resolve_precision(*c) != LAV_CONV_BF16X6) return p.wfloats;
+    if (!has_split_packing(resolve_precision(*c))) return p.wfloats;
     return (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 6;   // one entry per fp32 slot, then one per bf16 triple
 }
 
@@ -990,7 +1002,7 @@ extern "C" int lav_conv_pack_map(const lav_conv *c, int *h_map) {
     for (size_t i = 0; i < nw; ++i) iota[i] = (float)(i + 1);
     rc = lav_conv_pack_weights(c, iota.data(), packed.data());
     if (rc) return rc;
-    const bool split = resolve_precision(*c) == LAV_CONV_BF16X6;
+    const bool split = has_split_packing(resolve_precision(*c));
     const size_t nf = split ? (p.wfloats + 3) / 4 * 4 : p.wfloats;
     for (size_t i = 0; i < nf; ++i) h_map[i] = i < p.wfloats ? (int)packed[i] - 1 : -1;
     if (split) {
@@ -1042,7 +1054,10 @@ extern "C" int lav_conv_repack(const lav_conv *c, const float *d_weight, const i
     Plan p;
     int rc = build_plan(*c, p);
     if (rc) return rc;
-    const bool split = resolve_precision(*c) == LAV_CONV_BF16X6;
+    // (LAV_CONV_F16X3: the fp16 section needs the weights' largest magnitude first - such layers are re-packed on the host,
+    //  lav_amd/ops.py:ConvLayer.refresh; the frame's layers never change)
+    LAV_REQUIRE(resolve_precision(*c) != LAV_CONV_F16X3, "lav_conv_repack: LAV_CONV_F16X3 layers are packed on the host");
+    const bool split = has_split_packing(resolve_precision(*c));
     const long nf = split ? (long)((p.wfloats + 3) / 4 * 4) : (long)p.wfloats, ntrip = split ? (long)(split_weight_bytes(p) / 6) : 0;
     hipLaunchKernelGGL(k_conv_repack, dim3((unsigned)((nf + ntrip + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_weight, d_map, nf,
                        ntrip, d_packed);
@@ -1072,6 +1087,7 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     if (ch.kind == 1) a.ksplit = ch.dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     if (ch.kind == 3) return 0;
+    if (ch.kind == 2 && ch.sp.f16) return (size_t)F16_PARTS * sizeof(float);
     const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);   // stream-K: head and tail parts of the cut tiles
     return (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
 }
@@ -1108,7 +1124,10 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     if (direct) a.ksplit = dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);
-    if (slabs) {
+    if (ch.kind == 2 && ch.sp.f16) {
+        if (!workspace || workspace_bytes < F16_PARTS * sizeof(float)) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (fp16 scale)", workspace_bytes, F16_PARTS * sizeof(float));
+        a.partial = static_cast<float *>(workspace);
+    } else if (slabs) {
         const size_t need = (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
         if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, need);
         a.partial = static_cast<float *>(workspace);
@@ -1131,7 +1150,10 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         for (size_t t = 0; t < p.taps[cl].size(); ++t) a.toff[cl * p.taps_per_class + t] = p.taps[cl][t].dy * a.Wst + p.taps[cl][t].dx;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ch.kind == 2) return launch_split(*c, p, ch.sp, a, reinterpret_cast<const unsigned char *>(w_packed + (p.wfloats + 3) / 4 * 4), st);
+    if (ch.kind == 2) {
+        const unsigned char *w_split = reinterpret_cast<const unsigned char *>(w_packed + (p.wfloats + 3) / 4 * 4);
+        return launch_split(*c, p, ch.sp, a, w_split, st, ch.sp.f16 ? w_split + split_weight_bytes(p) : nullptr);
+    }
     if (direct) {
         DirectArgs d;
         d.x = x; d.w = w_packed; d.bias = bias; d.scale = scale; d.shift = shift; d.res = residual; d.y = y; d.partial = a.partial;

@@ -50,6 +50,9 @@ struct SplitArgs {
     int cls_ntaps[MAX_CLASSES], cls_in_oy[MAX_CLASSES], cls_in_ox[MAX_CLASSES], cls_out_oy[MAX_CLASSES], cls_out_ox[MAX_CLASSES];
     long cls_woff[MAX_CLASSES];      // byte offset of the class's weights
     int toff[MAX_TAPS];              // class c, tap t -> entry offset dy*Wst + (dx % in_s)*Wsub + dx / in_s
+    // LAV_CONV_F16X3: per-workgroup maxima of |x| over the finite inputs (k_absmax_parts), the packed weights' scale (device)
+    const float *f16_parts, *f16_wscale;
+    int f16_nparts;
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -87,6 +90,19 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &q0, un
     const float s0 = r0 - __uint_as_float(q1 << 16), s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
     q2 = __builtin_bit_cast(unsigned, __builtin_convertvector(split_f32x2{s0, s1}, split_bf16x2));
 }
+// Round 5, LAV_CONV_F16X3: two values -> two fp16 pieces each, u = h0 + h1 + O(2^-22 |u|) (round to nearest; |u| <= 32768 by the caller's
+// power-of-two scale, so nothing overflows; what is below fp16's subnormal quantum 2^-24 - 2^-39 of the tensor's largest value - is lost).
+// With a . b ~ a0 b0 + a0 b1 + a1 b0 that is THREE v_mfma_f32_32x32x16_f16 per 16 k-steps instead of six bf16 ones, at 22 instead of
+// 24 bits per operand: the error of the dot product stays at the level of its fp32 accumulation (tests/test_gpu_conv.py).
+typedef _Float16 split_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h_pair(float u0, float u1, unsigned &q0, unsigned &q1) {
+    const split_f16x2 h0 = __builtin_convertvector(split_f32x2{u0, u1}, split_f16x2);
+    const split_f32x2 f0 = __builtin_convertvector(h0, split_f32x2);
+    const split_f16x2 h1 = __builtin_convertvector(split_f32x2{u0 - f0[0], u1 - f0[1]}, split_f16x2);
+    q0 = __builtin_bit_cast(unsigned, h0);
+    q1 = __builtin_bit_cast(unsigned, h1);
+}
 // {hi half of odd, hi half of even} -> one dword of two bf16 (even in the low half)
 __device__ __forceinline__ unsigned pack_hi(unsigned even, unsigned odd) { return __builtin_amdgcn_perm(odd, even, 0x07060302u); }
 
@@ -104,9 +120,9 @@ struct SplitInterleave<NR, NM, NR> {
     static __device__ __forceinline__ void run() {}
 };
 
-template <int MP, int MC>
+template <int MP, int MC, int NPC = 3>
 struct SplitOps {
-    u32x4 a[MC][3], b[MP][3];
+    u32x4 a[MC][NPC], b[MP][NPC];
 };
 
 // NT: staged positions per activation-loader thread (plane <= 192 * NT); every loader thread issues all 16 * NT loads
@@ -124,14 +140,30 @@ struct SplitOps {
 // loop; part < 0: the tile's whole K range, epilogue applied and written to y; part >= 0: raw partial sums into slab `part` of
 // a.partial.  SK (stream-K, k_conv_split_sk): the function is called for one segment after the other - every role ends on one more
 // LDS barrier, so that the loaders enter the next segment while the compute waves write this one out.
-template <int MP, int MC, int WPX, int NT, int G, bool TP, bool SK>
+template <int MP, int MC, int WPX, int NT, int G, bool TP, bool SK, bool F16 = false>
 __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *smem_raw, const int bx, const int by, const int cls, const int n, const int batch,
                                            const int chunk_lo, const int chunk_hi, const int part, const long wg) {
     constexpr int WCO = 4 / WPX, NBLK = WCO * MC, PIXW = WPX * MP * 32;
     constexpr int CH = TP ? 8 : 16;                            // channels per chunk
+    constexpr int NPC = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;      // pieces per operand, partial products per k-block
+    static_assert(!(F16 && TP), "the fp16 two-piece mode is built for the ordinary 16-channel chunks");
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.n_valid && n >= *a.n_valid) return;   // workgroup-uniform
+    // F16: scale of the activations = the power of two that puts the tensor's largest finite |x| into [16384, 32768); every wave
+    // reduces the absmax launch's per-workgroup maxima itself (a few hundred floats from L2: no LDS, no barrier)
+    float inv_sx = 1.f, out_scale = 1.f;
+    if constexpr (F16) {
+        float m = 0.f;
+        for (int i = lane; i < a.f16_nparts; i += 64) m = fmaxf(m, a.f16_parts[i]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        int e = 0;
+        (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1): m / 2^(e - 15) in [16384, 32768)
+        const float sx = ldexpf(1.f, m > 0.f ? e - 15 : 0);
+        inv_sx = 1.f / sx;                         // (a power of two: exact)
+        out_scale = sx * *a.f16_wscale;
+    }
     const int ntaps_real = a.cls_ntaps[cls];
     const int ntaps = TP ? (ntaps_real + 1) >> 1 : ntaps_real;   // steps per chunk (TP: tap pairs)
     int qy0, qx0, q0 = 0;
@@ -143,8 +175,8 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
     }
     const int iy_base = qy0 * a.in_s + a.cls_in_oy[cls], in_ox = qx0 * a.in_s + a.cls_in_ox[cls];
     const int plane = a.plane;
-    const int ibuf_bytes = (TP ? 3 : 6) * plane * 16;         // [3 pieces][2 k halves][plane] x 16 B (TP: no k-half dimension)
-    constexpr int WSLOT = NBLK * 3 * 1024;                    // one tap's weights of the tile: [cout block][piece][lane] x 16 B
+    const int ibuf_bytes = (TP ? 3 : 2 * NPC) * plane * 16;   // [pieces][2 k halves][plane] x 16 B (TP: no k-half dimension)
+    constexpr int WSLOT = NBLK * NPC * 1024;                  // one tap's weights of the tile: [cout block][piece][lane] x 16 B
     unsigned char *s_in = smem_raw, *s_w = smem_raw + 2 * ibuf_bytes;
     const int nchunk = chunk_hi - chunk_lo, nsteps = nchunk * ntaps;   // a step = one tap of one 16-channel chunk
     constexpr int WFM = 4 / G;                                 // groups of G taps the weight waves keep in flight in registers
@@ -159,7 +191,7 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
         // LDS DMA (global_load_lds) saturates at ~25 GB/s per CU on this part; a 128-cout tile needs 12 KB per ~0.35 us of
         // matrix work.  WF steps of requests are in flight in registers (the compiler counts vmcnt for them), so the LDS
         // ring is just two slots: step i+2 is written while the compute waves fetch step i+1 and multiply step i.
-        constexpr int NPW = (NBLK * 3 + 1) / 2;
+        constexpr int NPW = (NBLK * NPC + 1) / 2;
         const int lw = wid - 4;
         const unsigned char *wcls = a.w + a.cls_woff[cls];
         // Everything below is unconditional straight-line code per step (a dead piece of an odd piece count repeats the
@@ -171,10 +203,10 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
 #pragma unroll
         for (int k = 0; k < NPW; ++k) {
             int pc = lw + 2 * k;
-            if (pc >= NBLK * 3) pc = lw;
-            const int b = pc / 3, pl = pc - b * 3;
+            if (pc >= NBLK * NPC) pc = lw;
+            const int b = pc / NPC, pl = pc - b * NPC;
             const int blk = min(bx * NBLK + b, a.nblk_total - 1);
-            rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * 3 + pl) * 1024) + lane * 16;
+            rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * NPC + pl) * 1024) + lane * 16;
             if constexpr (TP) rel[k] = (unsigned)((blk * ntaps_real * a.nchunks * 3 + pl) * 1024) + l31 * 16 + half * (unsigned)(a.nchunks * 3072);
             doff[k] = pc * 1024 + lane * 16;
         }
@@ -184,7 +216,7 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
         auto request = [&](u32x4 (&dst)[NPW]) {
             const int cch = min(r_chunk, chunk_hi - 1);
             const unsigned char *base = TP ? wcls + ((long)(2 * r_t) * a.nchunks + (cch >> 1)) * 3072 + (cch & 1) * 512
-                                           : wcls + ((long)r_t * a.nchunks + cch) * 3072;
+                                           : wcls + ((long)r_t * a.nchunks + cch) * (NPC * 1024);
             // TP, odd tap count: the last pair's second tap does not exist - its lanes re-read the first (zeroed at the deposit)
             const unsigned back = TP && (ntaps_real & 1) && r_t == ntaps - 1 ? tap_hop : 0u;
 #pragma unroll
@@ -273,7 +305,7 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
             for (int i = 0; i < NT; ++i) {
                 const int pos = lt + SPLIT_LOADERS * i;
                 const bool ok = goff[i] >= 0;
-                u32x4 q[3][KH];
+                u32x4 q[NPC][KH];
 #pragma unroll
                 for (int h = 0; h < KH; ++h)
 #pragma unroll
@@ -281,13 +313,19 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
                         const int c0 = 8 * h + 2 * e;
                         const float x0 = c0 < nc ? (ok ? v[i][c0] : a.pad_value) : 0.f;
                         const float x1 = c0 + 1 < nc ? (ok ? v[i][c0 + 1] : a.pad_value) : 0.f;
-                        unsigned p0, p1, p2;
-                        split3_pair(x0, x1, p0, p1, p2);
-                        q[0][h][e] = p0; q[1][h][e] = p1; q[2][h][e] = p2;
+                        if constexpr (F16) {
+                            unsigned p0, p1;
+                            split2h_pair(x0 * inv_sx, x1 * inv_sx, p0, p1);
+                            q[0][h][e] = p0; q[1][h][e] = p1;
+                        } else {
+                            unsigned p0, p1, p2;
+                            split3_pair(x0, x1, p0, p1, p2);
+                            q[0][h][e] = p0; q[1][h][e] = p1; q[NPC - 1][h][e] = p2;
+                        }
                     }
                 if (pos < plane) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NPC; ++pl)
 #pragma unroll
                         for (int h = 0; h < KH; ++h) *reinterpret_cast<u32x4 *>(dst + ((pl * KH + h) * plane + pos) * 16) = q[pl][h];
                 }
@@ -364,27 +402,33 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
             for (int r = 0; r < 16; ++r) acc[mc][mp][r] = 0.f;
 
     const int pstride = (TP ? 1 : 2) * plane * 16;   // bytes between the pieces of the input buffer
-    auto load_ops = [&](SplitOps<MP, MC> &o, const unsigned char *bin, const unsigned char *bw, int to) {
+    auto load_ops = [&](SplitOps<MP, MC, NPC> &o, const unsigned char *bin, const unsigned char *bw, int to) {
 #pragma unroll
         for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) o.a[mc][pl] = *reinterpret_cast<const u32x4 *>(bw + (mc * 3 + pl) * 1024);
+            for (int pl = 0; pl < NPC; ++pl) o.a[mc][pl] = *reinterpret_cast<const u32x4 *>(bw + (mc * NPC + pl) * 1024);
 #pragma unroll
         for (int mp = 0; mp < MP; ++mp)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) o.b[mp][pl] = *reinterpret_cast<const u32x4 *>(bin + pl * pstride + base[mp] + to * 16);
+            for (int pl = 0; pl < NPC; ++pl) o.b[mp][pl] = *reinterpret_cast<const u32x4 *>(bin + pl * pstride + base[mp] + to * 16);
     };
-    auto mma = [&](const SplitOps<MP, MC> &o) {
+    auto mma = [&](const SplitOps<MP, MC, NPC> &o) {
         // smallest terms first; consecutive instructions go to different accumulators
         constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};   // fp16 pieces: a1 b0, a0 b1, a0 b0
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < NPROD; ++k)
 #pragma unroll
             for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
-                for (int mp = 0; mp < MP; ++mp)
-                    acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.a[mc][PA[k]]), __builtin_bit_cast(bf16x8, o.b[mp][PB[k]]),
-                                                                          acc[mc][mp], 0, 0, 0);
+                for (int mp = 0; mp < MP; ++mp) {
+                    if constexpr (F16)
+                        acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, o.a[mc][HA[k]]), __builtin_bit_cast(f16x8, o.b[mp][HB[k]]),
+                                                                             acc[mc][mp], 0, 0, 0);
+                    else
+                        acc[mc][mp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.a[mc][PA[k]]), __builtin_bit_cast(bf16x8, o.b[mp][PB[k]]),
+                                                                              acc[mc][mp], 0, 0, 0);
+                }
     };
     // tap offsets: lane t of one VGPR holds tap t's offset, fetched with v_readlane (a scalar load per tap would share
     // lgkmcnt with the LDS reads and drain the operand pipeline at every tap)
@@ -404,13 +448,13 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
     {
         // operands of the NEXT tap: tap f_t of chunk parity f_par, weight slot f_slot of the 3G-slot ring
         int f_t = 0, f_par = 0, f_slot = 0;
-        const unsigned char *bw_lane = s_w + (wc * MC * 3 * 64 + lane) * 16;
-        auto fetch = [&](SplitOps<MP, MC> &o) {
+        const unsigned char *bw_lane = s_w + (wc * MC * NPC * 64 + lane) * 16;
+        auto fetch = [&](SplitOps<MP, MC, NPC> &o) {
             load_ops(o, s_in + f_par * ibuf_bytes, bw_lane + f_slot * WSLOT, tap_off(f_t));
             if (++f_t == ntaps) { f_t = 0; f_par ^= 1; }
             if (++f_slot == 3 * G) f_slot = 0;
         };
-        SplitOps<MP, MC> o0, o1;
+        SplitOps<MP, MC, NPC> o0, o1;
         if (nsteps > 0) fetch(o0);
         // U taps per iteration (static register sets, a barrier after every G-th).  The operand fetch is unconditional - past
         // the last tap it reads stale LDS that nobody uses - so that fetch and matrix instructions share one basic block, and
@@ -423,11 +467,11 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
             for (int j = 0; j < U; j += 2) {
                 fetch(o1);
                 mma(o0);
-                SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
+                SplitInterleave<0, NPROD * MP * MC, NPC * (MP + MC)>::run();
                 if ((j + 1) % G == 0) { SPLIT_TIMED(lds_barrier(), waited); ++bars; }
                 fetch(o0);
                 mma(o1);
-                SplitInterleave<0, 6 * MP * MC, 3 * (MP + MC)>::run();
+                SplitInterleave<0, NPROD * MP * MC, NPC * (MP + MC)>::run();
                 if ((j + 2) % G == 0) { SPLIT_TIMED(lds_barrier(), waited); ++bars; }
             }
         }
@@ -497,7 +541,9 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[mc][mp][r] + bv[r];
+                float v;
+                if constexpr (F16) v = fmaf(acc[mc][mp][r], out_scale, bv[r]);   // the accumulators are in units of (activation scale x weight scale)
+                else v = acc[mc][mp][r] + bv[r];
                 if (a.relu_pre) v = v > 0.f ? v : 0.f;
                 v = fmaf(v, sv[r], tv[r]);
                 v += has_res ? rv[r] : 0.f;
@@ -518,6 +564,45 @@ __global__ __launch_bounds__(512) void k_conv_split(SplitArgs a) {
     const long wg = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     split_body<MP, MC, WPX, NT, G, TP, false>(a, smem_raw, blockIdx.x, blockIdx.y, cls, n, gridDim.z / (a.ksplit * a.nclasses), ks * nchunks_k / a.ksplit,
                                               (ks + 1) * nchunks_k / a.ksplit, a.ksplit > 1 ? ks : -1, wg);
+}
+
+// LAV_CONV_F16X3 (round 5): the same kernel on two fp16 pieces per operand and three products (split_body<..., F16 = true>), for
+// stride-1 single-class layers on the 2x2/w2 G = 2 tile - the head convolution.  k_absmax_parts runs first: workgroup g writes the
+// largest FINITE |x| of its share of the layer's input channels to parts[g] (no atomics, nothing to zero); Inf / NaN inputs do not
+// enter the scale and propagate through the data path as they are.
+constexpr int F16_PARTS = 512;
+__global__ __launch_bounds__(256) void k_absmax_parts(const float *__restrict__ x, int batch, int in_c_total, int in_c_offset, int cin, long plane,
+                                                      float *__restrict__ parts) {
+    __shared__ float s_m[4];
+    const long per_img = (long)cin * plane, total = (long)batch * per_img;
+    float m = 0.f;
+    if ((plane & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const long total4 = total >> 2, per4 = per_img >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+            const long n = i / per4, r = i - n * per4;
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((long)n * in_c_total + in_c_offset) * plane + 4 * r);
+            const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+            m = fmaxf(m, a0 <= 3.4028235e38f ? a0 : 0.f); m = fmaxf(m, a1 <= 3.4028235e38f ? a1 : 0.f);
+            m = fmaxf(m, a2 <= 3.4028235e38f ? a2 : 0.f); m = fmaxf(m, a3 <= 3.4028235e38f ? a3 : 0.f);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const long n = i / per_img, r = i - n * per_img;
+            const float a0 = fabsf(x[((long)n * in_c_total + in_c_offset) * plane + r]);
+            m = fmaxf(m, a0 <= 3.4028235e38f ? a0 : 0.f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
+template <int MP, int MC, int WPX, int NT, int G>
+__global__ __launch_bounds__(512) void k_conv_split_f16(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    split_body<MP, MC, WPX, NT, G, false, false, true>(a, smem_raw, blockIdx.x, blockIdx.y, 0, blockIdx.z, gridDim.z, 0, a.nchunks, -1, 0);
 }
 
 // Stream-K launch of a single-image, single-class layer (round 5).  The head convolution's 400 tiles ran as two rounds of a 256-CU
@@ -590,6 +675,43 @@ inline size_t split_weight_bytes(const Plan &p) {
     return taps * (size_t)(p.cout_pad / 32) * (p.cin_pad / 16) * 3 * 1024;
 }
 
+// LAV_CONV_F16X3 packing: [cout block][tap][chunk][piece 2][lane = khalf*32 + cout%32][8 channels] fp16 of w / s_w, then the scale s_w
+// (a power of two that puts the largest |w| into [16384, 32768)) as one float at a 16-byte aligned offset
+inline size_t split_weight_bytes_f16(const Plan &p) {
+    size_t taps = 0;
+    for (auto &t : p.taps) taps += t.size();
+    return taps * (size_t)(p.cout_pad / 32) * (p.cin_pad / 16) * 2 * 1024;
+}
+inline bool f16x3_layer(const lav_conv &c, const Plan &p) {   // the layers the mode is built for: stride-1 single-class 3x3-like convolutions with whole chunks
+    return !c.transposed && p.nclasses == 1 && c.stride == 1 && c.cin % 16 == 0 && c.cin >= 64 && c.cout >= 128;
+}
+inline void split_pack_weights_f16(const lav_conv &c, const Plan &p, const float *h_weight, unsigned char *out) {
+    const int nblk = p.cout_pad / 32, nchunks = p.cin_pad / 16;
+    const size_t nw = (size_t)c.cout * c.cin * c.kh * c.kw;
+    float m = 0.f;
+    for (size_t i = 0; i < nw; ++i) { const float v = fabsf(h_weight[i]); if (v <= 3.4028235e38f && v > m) m = v; }
+    int e = 0;
+    (void)frexpf(m, &e);
+    const float sw = ldexpf(1.f, m > 0.f ? e - 15 : 0), inv = 1.f / sw;
+    _Float16 *o = reinterpret_cast<_Float16 *>(out);
+    const auto &t = p.taps[0];
+    parallel_for(nblk, [&](int blk) {
+        for (size_t ti = 0; ti < t.size(); ++ti)
+            for (int ch = 0; ch < nchunks; ++ch)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int el = 0; el < 8; ++el) {
+                        const int co = blk * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + el;
+                        float w = 0.f;
+                        if (co < c.cout && ci < c.cin) w = h_weight[(((size_t)co * c.cin + ci) * c.kh + t[ti].ky) * c.kw + t[ti].kx] * inv;
+                        const _Float16 h0 = (_Float16)w, h1 = (_Float16)(w - (float)h0);
+                        const size_t frag = ((((size_t)blk * t.size() + ti) * nchunks + ch) * 2) * 512;
+                        o[frag + lane * 8 + el] = h0;
+                        o[frag + 512 + lane * 8 + el] = h1;
+                    }
+    });
+    memcpy(out + split_weight_bytes_f16(p), &sw, sizeof(float));
+}
+
 inline unsigned short bf16_round(float x, float &rest) {
     unsigned u;
     memcpy(&u, &x, 4);
@@ -637,6 +759,7 @@ struct SplitPlan {
     double cost;
     int tp;   // tap-pair mode (k_conv_split<..., TP = true>)
     int sk_w; // > 0: stream-K launch with this many persistent workgroups (k_conv_split_sk)
+    int f16;  // LAV_CONV_F16X3 applies: two fp16 pieces per operand, three products (k_conv_split_f16)
 };
 
 // Tile shape, tile geometry, tap group and split-K factor of the split kernel, by estimated time (us).
@@ -770,7 +893,8 @@ int launch_split_t(const SplitArgs &sa, dim3 grid, size_t lds, hipStream_t st) {
 }
 
 // `a`: the epilogue / output description already filled in by lav_conv2d (pointers, sizes, flags, partial slab)
-inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, const ConvArgs &a, const unsigned char *w_split, hipStream_t st) {
+inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, const ConvArgs &a, const unsigned char *w_split, hipStream_t st,
+                        const unsigned char *w_f16 = nullptr) {
     SplitArgs s;
     s.x = a.x; s.w = w_split; s.bias = a.bias; s.scale = a.scale; s.shift = a.shift; s.res = a.res; s.n_valid = a.n_valid;
     s.y = a.y; s.partial = a.partial;
@@ -798,6 +922,7 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
             s.toff[cl * p.taps_per_class + t] = dy * sp.Wst + (dx % p.in_s) * sp.Wsub + dx / p.in_s;
         }
     s.trace = nullptr;
+    s.f16_parts = nullptr; s.f16_wscale = nullptr; s.f16_nparts = 0;
     const int NBLK = (4 / sp.WPX) * sp.MC;
     static const bool want_trace = getenv("LAV_SPLIT_TRACE") != nullptr;
     static long long *d_trace = nullptr;
@@ -810,6 +935,28 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
     dim3 grid((c.cout + NBLK * 32 - 1) / (NBLK * 32), sp.tiles, c.batch * p.nclasses * sp.ksplit);
     const int tok = timer_begin("conv2d", st);
     int rc = LAV_EINVAL;
+    if (sp.f16) {
+        // a.partial = the layer's workspace: F16_PARTS floats of per-workgroup maxima; w_f16: the fp16 section of the packed weights
+        s.w = w_f16; s.f16_parts = a.partial; s.f16_nparts = F16_PARTS;
+        s.f16_wscale = reinterpret_cast<const float *>(w_f16 + split_weight_bytes_f16(p));
+        s.partial = nullptr;
+        s.cls_woff[0] = 0;
+        hipLaunchKernelGGL(k_absmax_parts, dim3(F16_PARTS), dim3(256), 0, st, a.x, c.batch, a.in_c_total, a.in_c_offset, a.cin, (long)a.H * a.W, a.partial);
+        const bool small = s.plane <= SPLIT_LOADERS * 2;
+        static bool attr = false;
+        if (!attr) {
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_f16<2, 2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_f16<2, 2, 2, SPLIT_NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        const size_t lds16 = (size_t)2 * 4 * sp.plane * 16 + (size_t)3 * sp.tap_group * NBLK * 2 * 1024;
+        const dim3 g16(grid.x, grid.y, c.batch);
+        if (small) hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, 2, 2>), g16, dim3(512), lds16, st, s);
+        else hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, SPLIT_NT, 2>), g16, dim3(512), lds16, st, s);
+        timer_end(tok, st);
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
+    }
     if (sp.sk_w) {
         const size_t lds_sk = sp.lds;
         const int nbx = (int)grid.x, ntiles = (int)(grid.x * grid.y);

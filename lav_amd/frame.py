@@ -46,6 +46,14 @@ class FramePipeline:
     def __init__(self, lidar_model, uniplanner, seg_model, bra_model, camera_x=1.5, camera_z=2.4, num_frame_stack=2,
                  device=torch.device("cuda"), compact_ego_box: bool = False):
         self.device = device
+        # Round 5: the frame's head convolution (384 -> 256, the largest kernel of the tick and power bound) on LAV_CONV_F16X3 - two fp16
+        # pieces per operand, three products instead of six (conv_split.hpp).  Asked for HERE, by the inference pipelines: a LiDARModel
+        # that a trainer owns keeps bf16x6 (its engines are re-packed on the device after every step, which the fp16 packing does not
+        # support).  LAV_HEADS_PRECISION=bf16x6 switches it off.
+        want = 0 if os.environ.get("LAV_HEADS_PRECISION", "f16x3") != "f16x3" else 3
+        if getattr(lidar_model, "heads_precision", 0) != want and hasattr(lidar_model, "_drop"):
+            lidar_model.heads_precision = want
+            lidar_model._drop()
         self.infer_model = InferModel(lidar_model, uniplanner, camera_x, camera_z, device=device)
         self.seg_model, self.bra_model = seg_model, bra_model
         self.num_frame_stack = num_frame_stack

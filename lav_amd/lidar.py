@@ -234,7 +234,8 @@ class LiDARModel(_Engine):
             cts = [h.net[3] for h in hs]
             outs = [ct.weight.shape[1] for ct in cts]
             eng[names] = dict(outs=outs,
-                              conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=device),
+                              conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=device,
+                                             precision=getattr(self, "heads_precision", 0)),   # (the frame pipelines ask for LAV_CONV_F16X3)
                               deconv=GroupedDeconv(cts, sigmoid_from=sum(outs[:-1]) if sig[-1] else -1, device=device))
             eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use
             object.__setattr__(self, "_eng", eng)

@@ -406,6 +406,8 @@ class ConvLayer:
         dev = self.w.device
         probe = Conv.from_buffer_copy(self.desc)
         probe.h, probe.w = 64, 64
+        if self.desc.precision == _lib.CONV_F16X3:
+            self._map = False    # the fp16 pieces need the weights' largest magnitude first: packed on the host (the frame's layers never change)
         if dev.type == "cuda" and w.device == dev and self._map is not False:
             if self._map is None:
                 n = lib.lav_conv_pack_map_ints(C.byref(probe))

@@ -463,3 +463,44 @@ def test_library_holds_no_packed_fp32_with_op_sel(tmp_path):
             if re.search(r"\bv_pk_\w+_f32\b", line) and re.search(r"op_sel:\[[01,]*1", line):
                 bad.append(line.split("//")[0].strip())
     assert not bad, f"{len(bad)} packed fp32 instructions with an op_sel bit in liblav_amd.so, e.g. {bad[:3]}"
+
+
+def test_f16x3_plan_and_packing():
+    """LAV_CONV_F16X3 (round 5, host side): the head convolution's plan carries the fp16 flag and a workspace for the absmax launch's
+    per-workgroup maxima; other layers of that precision plan as bf16x6; the packed buffer holds, behind the fp32 and bf16 sections, two
+    fp16 pieces per weight of w / s_w with s_w the power of two that puts the largest |w| into [16384, 32768): h0 + h1 reproduces every
+    weight to 2^-21 of its magnitude + 2^-24 s_w (= 2^-39 of the largest weight: fp16's subnormal quantum)."""
+    import ctypes as C
+    import numpy as np
+    from lav_amd import _lib
+    from lav_amd._lib import Conv
+    lib = _lib.load()
+    info = (C.c_int * 9)()
+    head = lambda prec: Conv(1, 384, 0, 384, 160, 160, 256, 3, 3, 1, 1, 1, 1, 1, 0, 0, 256, 0, 0, 0, 0, 0, 0.0, prec)
+    d2, d3 = head(_lib.CONV_BF16X6), head(_lib.CONV_F16X3)
+    assert lib.lav_conv_tile_info(C.byref(d3), info) == 0 and info[0] == -1 and info[7] == 202, list(info)
+    assert lib.lav_conv_tile_info(C.byref(d2), info) == 0 and info[7] == 2
+    assert lib.lav_conv_workspace_bytes(C.byref(d3)) == 2048 and lib.lav_conv_workspace_bytes(C.byref(d2)) == 0
+    small = Conv(1, 64, 0, 64, 160, 160, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, 64, 0, 0, 0, 0, 0, 0.0, _lib.CONV_F16X3)
+    assert lib.lav_conv_tile_info(C.byref(small), info) == 0 and info[7] < 200, "a 64-channel layer of that precision runs as bf16x6"
+    assert lib.lav_conv_packed_weight_floats(C.byref(small)) == lib.lav_conv_packed_weight_floats(
+        C.byref(Conv(1, 64, 0, 64, 160, 160, 64, 3, 3, 1, 1, 1, 1, 1, 0, 0, 64, 0, 0, 0, 0, 0, 0.0, _lib.CONV_BF16X6)))
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((256, 384, 3, 3)) * np.exp(rng.uniform(-5, 2, (256, 384, 3, 3))) / 60).astype(np.float32)
+    n2, n3 = lib.lav_conv_packed_weight_floats(C.byref(d2)), lib.lav_conv_packed_weight_floats(C.byref(d3))
+    nb16 = 9 * 8 * 24 * 2 * 1024
+    assert n3 == n2 + nb16 // 4 + 4
+    p2, p3 = np.zeros(n2, np.float32), np.zeros(n3, np.float32)
+    assert lib.lav_conv_pack_weights(C.byref(d2), w.ctypes.data, p2.ctypes.data) == 0
+    assert lib.lav_conv_pack_weights(C.byref(d3), w.ctypes.data, p3.ctypes.data) == 0
+    assert np.array_equal(p2.view(np.uint32), p3[:n2].view(np.uint32)), "the fp32 and bf16 sections are the bf16x6 layer's"
+    sec = p3[n2:].view(np.uint8)
+    sw = float(sec[nb16:nb16 + 4].view(np.float32)[0])
+    assert sw == 2.0 ** round(np.log2(sw)) and 16384 <= np.abs(w).max() / sw < 32768
+    h = sec[:nb16].view(np.float16).astype(np.float64).reshape(8, 9, 24, 2, 64, 8)    # cout block, tap, chunk, piece, lane, channel
+    rec = (h[:, :, :, 0] + h[:, :, :, 1]) * sw
+    blk, tap, ch, lane, el = np.meshgrid(np.arange(8), np.arange(9), np.arange(24), np.arange(64), np.arange(8), indexing="ij")
+    ref = w[blk * 32 + (lane & 31), ch * 16 + 8 * (lane >> 5) + el, tap // 3, tap % 3].astype(np.float64)
+    # h0 carries 11 bits of w / s_w, h1 11 more of what is left - down to fp16's subnormal quantum 2^-24 (in units of s_w)
+    assert (np.abs(rec - ref) <= np.abs(ref) * 2.0 ** -21 + sw * 2.0 ** -24).all()
+    assert lib.lav_conv_repack(C.byref(d3), None, None, None, None) != 0        # (null arguments are refused first; the mode is host-packed)

@@ -143,6 +143,54 @@ def test_small_cin_vector_kernel(cin, k, cout, B, H, W):
     assert (out[:, :2] == 7).all() and (out[:, 2 + cout:] == 7).all(), "channels outside the window were touched"
 
 
+def test_f16x3_head_convolution():
+    """LAV_CONV_F16X3 (round 5): the head convolution's plan on two fp16 pieces per operand and three products, the activation scale taken
+    from the tensor's largest finite magnitude by a first launch.  Against float64 on inputs that span five decades: the error bar of the
+    bf16x6 kernel (2e-6 of sum |w||x|); the epilogue; an all-zero input; an Inf that must stay local; same bits on a second launch."""
+    import ctypes as C
+    from lav_amd import _lib
+    from lav_amd._lib import Conv
+    lib = _lib.load()
+    info = (C.c_int * 9)()
+    d = Conv(1, 384, 0, 384, 160, 160, 256, 3, 3, 1, 1, 1, 1, 1, 0, 0, 256, 0, 0, 0, 0, 0, 0.0, _lib.CONV_F16X3)
+    assert lib.lav_conv_tile_info(C.byref(d), info) == 0 and info[0] == -1 and info[7] >= 200, f"expected the fp16 three-product plan, got {list(info)}"
+    B, cin, cout, H, W = 1, 384, 256, 160, 160
+    g = np.random.Generator(np.random.PCG64(61))
+    x = torch.from_numpy((g.standard_normal((B, cin, H, W)) * np.exp(g.uniform(-8.0, 3.0, (B, cin, H, W)))).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((cout, cin, 3, 3)) * np.exp(g.uniform(-4.0, 1.0, (cout, cin, 3, 3))) / np.sqrt(cin * 9)).astype(np.float32))
+    bias = rnd((cout,), 63)
+    bn = (rnd((cout,), 64, 0.1), rnd((cout,), 65).abs() + 0.5, rnd((cout,), 66).abs() + 0.5, rnd((cout,), 67, 0.1))
+    xd, wd = x.to(DEV).double(), w.to(DEV).double()
+    conv64 = F.conv2d(xd, wd, None, 1, 1)
+    mag = F.conv2d(xd.abs(), wd.abs(), None, 1, 1)
+    plain = ConvLayer(w, padding=1, precision=_lib.CONV_F16X3, device=DEV)
+    y = plain(x.to(DEV))
+    err = ((y.double() - conv64).abs() / mag).max().item()
+    assert err < 2e-6, f"max |y - ref| / sum|w||x| = {err:.3e}"
+    y6 = ConvLayer(w, padding=1, device=DEV)(x.to(DEV))
+    err6 = ((y6.double() - conv64).abs() / mag).max().item()
+    print(f"head convolution, five decades of input magnitude: f16x3 {err:.2e}, bf16x6 {err6:.2e} of sum|w||x|")
+    assert torch.equal(y, plain(x.to(DEV))), "bit-reproducible"
+    ref = F.batch_norm(F.relu(conv64 + bias.to(DEV).double()[None, :, None, None]), bn[0].to(DEV).double(), bn[1].to(DEV).double(), bn[2].to(DEV).double(),
+                       bn[3].to(DEV).double(), False, 0., 1e-3).float()
+    layer = ConvLayer(w, padding=1, bias=bias, bn=bn, bn_eps=1e-3, relu_pre=True, out_c_total=cout + 8, out_c_offset=8, precision=_lib.CONV_F16X3, device=DEV)
+    out = torch.full((B, cout + 8, H, W), 7.0, device=DEV)
+    layer(x.to(DEV), out=out)
+    assert (out[:, :8] == 7).all()
+    # (the inputs span five decades: the bar stays relative to sum |w||x|, carried through the BatchNorm scale)
+    gain = (bn[2].abs() / torch.sqrt(bn[1] + 1e-3)).to(DEV).double()[None, :, None, None]
+    excess = ((out[:, 8:].double() - ref.double()).abs() - (2e-6 * mag * gain + 1e-5 * ref.double().abs() + 1e-6)).max().item()
+    assert excess <= 0, f"f16x3 epilogue: beyond 2e-6 of sum|w||x| (through the BatchNorm gain) by {excess:.3e}"
+    z = layer(torch.zeros((B, cin, H, W), device=DEV))
+    zr = F.batch_norm(F.relu(bias.to(DEV)[None, :, None, None].expand(B, cout, H, W)), bn[0].to(DEV), bn[1].to(DEV), bn[2].to(DEV), bn[3].to(DEV), False, 0., 1e-3)
+    assert_close(z[:, 8:].cpu().numpy(), zr.cpu().numpy(), atol=1e-6, what="all-zero input")
+    xi = x.clone(); xi[0, 5, 80, 80] = float("inf")
+    yi = plain(xi.to(DEV))
+    assert not torch.isfinite(yi[0, :, 79:82, 79:82]).all(), "an Inf input must reach the outputs that read it"
+    far = torch.ones((H, W), dtype=torch.bool); far[78:83, 78:83] = False
+    assert torch.equal(yi[0][:, far], y[0][:, far]), "an Inf input must not change the scale: every other output keeps its bits"
+
+
 def test_stream_k_head_convolution(monkeypatch):
     """LAV_SPLIT_SK=1 (opt-in: no faster on this power-bound chip, profiles/r05_clock_power.txt): the head convolution's plan (384 ->
     256, 3x3, one 160 x 160 image: 400 tiles on 256 CUs) runs as a stream-K launch - persistent

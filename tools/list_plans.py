@@ -69,7 +69,7 @@ for name, conv, shp in todo:
         nwg = tiles * (-(-cout // (32 * nblk))) * shp[0] * ncls * max(ks, 1)
         sk = f" stream-K: {nwg} tiles over {-ks} persistent workgroups" if ks < 0 else ""
         print(f"{name:10s} {'T' if tr else 'C'} {cin:4d}->{cout:4d} k{conv.kernel_size[0]}x{conv.kernel_size[1]} s{s} d{conv.dilation[0]},{conv.dilation[1]} "
-              f"in {shp[0]}x{shp[2]}x{shp[3]:<4d} split {mp}x{mc}/w{wpx} tile {tw}x{th} G={tg % 100}{' tap pairs' if tg >= 100 else ''} lds={lds // 1024:3d}K ks={max(ks, 1):2d} wgs={nwg:5d} rounds={-(-nwg // 256)}{sk} "
+              f"in {shp[0]}x{shp[2]}x{shp[3]:<4d} split {mp}x{mc}/w{wpx} tile {tw}x{th} G={tg % 100}{' tap pairs' if 100 <= tg < 200 else ''}{' f16x3' if tg >= 200 else ''} lds={lds // 1024:3d}K ks={max(ks, 1):2d} wgs={nwg:5d} rounds={-(-nwg // 256)}{sk} "
               f"pix-util={QH * QW / max(tiles * pixw, 1):.2f}")
         continue
     if MP == 0:   # direct kernel: info = {0, waves, cout blocks per workgroup, -, -, LDS, split-K, ...}
