@@ -947,12 +947,24 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
         if (!attr) {
             LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_f16<2, 2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_f16<2, 2, 2, SPLIT_NT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_f16<2, 2, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_split_f16<2, 2, 2, SPLIT_NT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
-        const size_t lds16 = (size_t)2 * 4 * sp.plane * 16 + (size_t)3 * sp.tap_group * NBLK * 2 * 1024;
+        // taps per barrier: a tap is 12 matrix instructions here (24 with bf16 pieces), so the barrier's share doubles at G = 2; with two
+        // pieces a ring of 3 x 4 taps of weights fits beside the activation buffers (LAV_F16_TAP_GROUP=2 restores)
+        static const int g_env = [] { const char *e = getenv("LAV_F16_TAP_GROUP"); return e ? atoi(e) : 4; }();
+        const int G16 = (g_env == 4 && 2 * 4 <= p.taps_per_class + 1 && (size_t)2 * 4 * sp.plane * 16 + (size_t)3 * 4 * NBLK * 2 * 1024 <= 160 * 1024) ? 4 : 2;
+        s.tap_group = G16; s.wring = 3 * G16;
+        const size_t lds16 = (size_t)2 * 4 * sp.plane * 16 + (size_t)3 * G16 * NBLK * 2 * 1024;
         const dim3 g16(grid.x, grid.y, c.batch);
-        if (small) hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, 2, 2>), g16, dim3(512), lds16, st, s);
-        else hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, SPLIT_NT, 2>), g16, dim3(512), lds16, st, s);
+        if (G16 == 4) {
+            if (small) hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, 2, 4>), g16, dim3(512), lds16, st, s);
+            else hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, SPLIT_NT, 4>), g16, dim3(512), lds16, st, s);
+        } else {
+            if (small) hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, 2, 2>), g16, dim3(512), lds16, st, s);
+            else hipLaunchKernelGGL((k_conv_split_f16<2, 2, 2, SPLIT_NT, 2>), g16, dim3(512), lds16, st, s);
+        }
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
         return LAV_OK;
