@@ -125,6 +125,14 @@ def train_bench(args):
     step and logs every 100th), 100 = only on the steps that are logged.  Convolutions and Linear layers run on torch autograd
     (MIOpen / rocBLAS); BatchNorm + ReLU (+ residual), the pillar front end, scatter-max, the crops and the GRU recurrences are
     liblav_amd kernels."""
+    # MIOpen's on-disk user database can hold solver choices that another process made under other rules (a test session in torch's
+    # deterministic mode leaves the naive weight-gradient kernel for these very shapes: 634 instead of 128 ms per step, round 5): the
+    # training bench searches for itself, in a directory of its own (the search runs inside the warm-up steps)
+    if "MIOPEN_USER_DB_PATH" not in os.environ:
+        import tempfile
+        _d = tempfile.mkdtemp(prefix="lav_bench_miopen_")
+        os.environ["MIOPEN_USER_DB_PATH"] = _d
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _d)
     from lav_amd.train import TrainConfig
     from lav_amd.train.run import train_loop
     what = "lidar" if args.mode == "train_full" else "bev"

@@ -50,7 +50,8 @@ class FramePipeline:
         # pieces per operand, three products instead of six (conv_split.hpp).  Asked for HERE, by the inference pipelines: a LiDARModel
         # that a trainer owns keeps bf16x6 (its engines are re-packed on the device after every step, which the fp16 packing does not
         # support).  LAV_HEADS_PRECISION=bf16x6 switches it off.
-        want = 0 if os.environ.get("LAV_HEADS_PRECISION", "f16x3") != "f16x3" else 3
+        exact = os.environ.get("LAV_CONV_PRECISION", "") in ("f32", "fp32")       # (the exact-fp32 frame keeps every layer on the fp32 kernels)
+        want = 0 if exact or os.environ.get("LAV_HEADS_PRECISION", "f16x3") != "f16x3" else 3
         if getattr(lidar_model, "heads_precision", 0) != want and hasattr(lidar_model, "_drop"):
             lidar_model.heads_precision = want
             lidar_model._drop()
