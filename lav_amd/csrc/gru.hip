@@ -390,8 +390,9 @@ __global__ __launch_bounds__(256) void k_plan_poison(const int *__restrict__ sta
 // of the state and the four quarters meet in LDS - a quarter of the polling traffic per workgroup (the chip's other streams pay
 // for every poll: MI355X guide, "polling-cost"), two loads instead of eight per lane and poll round.
 // -DLAV_PLAN_LDS_SYNC=1: every LDS access of the persistent kernel one at a time, instruction + wait in one asm block - the build that
-// is immune to matrix + LDS heavy neighbours on its CUs whatever they claim (common.hpp; +60 us per plan).  Default 0: the frame is
-// protected by the aggressors' LDS claims instead.
+// was immune to matrix + LDS heavy neighbours on its CUs in round 4 (+60 us per plan).  Round 5 found the real cause of those wrong
+// results - packed fp32 instructions with an op_sel bit, not LDS (common.hpp) - removed them from the library and moved the
+// frame to k_plan_wave, which has no LDS at all; this kernel and the switch stay as the known victim for tools/coresidency.py.
 #ifndef LAV_PLAN_LDS_SYNC
 #define LAV_PLAN_LDS_SYNC 0
 #endif
@@ -974,12 +975,12 @@ int plan_launch(bool allow_persistent, const float *embd, const float *nxp, cons
         // instructions and LDS traffic (the stem kernel, or the synthetic neighbour of tools/probes/lds_hog.hip); the hidden state
         // exchanged between the workgroups was always right (instrumented), the damage was inside a workgroup: (1) a ds_write2_b64
         // whose data registers hipcc overwrote with the next instructions (common.hpp: lds_store_fence - with that alone a neighbour
-        // that only issues matrix instructions is harmless), (2) something that committing the LDS stores (lds_commit / lds_keep) does
-        // NOT cure and that needs the neighbour's LDS traffic - not understood.  What makes the frame safe is that the aggressors
-        // cannot become neighbours any more: every split-operand convolution workgroup claims the CU's whole LDS
-        // (conv_split.hpp: launch_split_g), so no kernel that uses LDS - this one does - shares a CU with it; beside that stem kernel both
-        // variants are bit-identical to the step path in 300 of 300 launches.  tests/test_gpu_paint_gru.py runs that comparison, and
-        // bench.py re-computes the plans of frames after its timed ones on the step path (`plan_vs_step_path_max_abs`).
+        // that only issues matrix instructions is harmless), (2) something that committing the LDS stores (lds_commit / lds_keep) did
+        // NOT cure - round 5: packed fp32 instructions with an op_sel bit on their second source, which hipcc's SLP vectoriser had put into
+        // this kernel's reductions, go wrong in lanes 48-63 beside such neighbours (common.hpp; the library is built without them and
+        // tests/test_capi_host.py scans the ISA).  Round 4 kept the aggressors away with LDS claims (now an opt-in, LAV_LDS_EXCLUSIVE=1).
+        // tests/test_gpu_paint_gru.py compares every implementation with the step path, and bench.py re-computes the plans of frames
+        // after its timed ones on the step path (`plan_vs_step_path_max_abs`).
         // Default: k_plan_wave (round 5, no LDS at all).  LAV_PLAN_IMPL=lds: rounds 2-4's four-wave kernel (quarter poll, LAV_PLAN_POLL=all:
         // every wave polls everything) - kept as the known victim of tools/coresidency.py, not used by the frame.
         static const char *poll_env = getenv("LAV_PLAN_POLL");
