@@ -504,3 +504,13 @@ def test_f16x3_plan_and_packing():
     # h0 carries 11 bits of w / s_w, h1 11 more of what is left - down to fp16's subnormal quantum 2^-24 (in units of s_w)
     assert (np.abs(rec - ref) <= np.abs(ref) * 2.0 ** -21 + sw * 2.0 ** -24).all()
     assert lib.lav_conv_repack(C.byref(d3), None, None, None, None) != 0        # (null arguments are refused first; the mode is host-packed)
+
+
+def test_the_test_session_keeps_miopen_databases_to_itself():
+    """tests/conftest.py: a GPU test session must not leave its (deterministic-mode) solver choices in MIOpen's default user database -
+    the next process on the box inherits them (round 5: train_full at 634 instead of 128 ms per step, profiles/r05_miopen_db_poisoning.txt)."""
+    import os
+    import tempfile
+    d = os.environ.get("MIOPEN_USER_DB_PATH")
+    assert d and os.path.isdir(d) and os.path.realpath(d) != os.path.realpath(os.path.expanduser("~/.config/miopen"))
+    assert os.path.realpath(d).startswith(os.path.realpath(tempfile.gettempdir())) or "MIOPEN_USER_DB_PATH" in os.environ
