@@ -129,8 +129,13 @@ def train_bench(args):
     # deterministic mode leaves the naive weight-gradient kernel for these very shapes: 634 instead of 128 ms per step, round 5): the
     # training bench searches for itself, in a directory of its own (the search runs inside the warm-up steps)
     if "MIOPEN_USER_DB_PATH" not in os.environ:
-        import tempfile
-        _d = tempfile.mkdtemp(prefix="lav_bench_miopen_")
+        _d = os.path.join(os.path.expanduser("~"), ".cache", "lav_amd", "miopen_bench")   # (stable: nothing piles up under /tmp)
+        try:
+            os.makedirs(_d, exist_ok=True)
+        except OSError:
+            import tempfile
+            _d = os.path.join(tempfile.gettempdir(), "lav_amd_miopen_bench")
+            os.makedirs(_d, exist_ok=True)
         os.environ["MIOPEN_USER_DB_PATH"] = _d
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _d)
     from lav_amd.train import TrainConfig

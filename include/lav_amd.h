@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 24
+#define LAV_ABI_VERSION 25
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -256,11 +256,13 @@ typedef struct lav_conv {
 } lav_conv;
 #define LAV_CONV_F32 1
 #define LAV_CONV_BF16X6 2
-#define LAV_CONV_F16X3 3   /* round 5: as BF16X6, and where the plan is the 2x2 whole-K split kernel of a stride-1 layer (the head
-                              convolution) each operand is TWO fp16 pieces scaled by a power of two taken from the tensor's largest
-                              finite magnitude (measured by a first launch), three products: half the matrix instructions at 22 bits
-                              per operand - the error of the dot product stays at the level of its fp32 accumulation; lav_conv_repack
-                              does not support it (such layers are packed on the host) */
+#define LAV_CONV_F16X3 3   /* as BF16X6, and wherever the plan is the split kernel (round 5: the head convolution's plan only; round 6:
+                              every split plan - any stride, tile, split-K, tap pairs, the classes of a transposed convolution) each
+                              operand is TWO fp16 pieces scaled by a power of two taken from the tensor's largest finite magnitude,
+                              three products: half the matrix instructions at 22 bits per operand - the error of the dot product
+                              stays at the level of its fp32 accumulation.  The activations' magnitude comes from the launches that
+                              wrote them (lav_conv2d_amax below) or, without that, from one measuring launch in front of the
+                              convolution.  lav_conv_repack does not support it (such layers are packed on the host) */
 
 /* output spatial size of the convolution */
 int lav_conv_out_hw(const lav_conv *c, int *oh, int *ow);
@@ -293,6 +295,19 @@ size_t lav_conv_workspace_bytes(const lav_conv *c);
 int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
                const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
                void *stream);
+/* lav_conv2d with the scale hand-off of LAV_CONV_F16X3 (round 6; replaces nothing in the reference - its cuDNN layers compute in
+ * fp32 - it is what lets a CHAIN of layers, team_code_v2/models/lidar.py:110-143, lav/models/resnet.py:41-85, run on fp16 pieces
+ * without a pass over the activations per layer).  amax_out (device, lav_conv_amax_count(c) floats, or NULL): the launch leaves
+ * the largest finite |y| of each of its workgroups there (from its epilogue; from the split-K reduce pass; for the few plans with
+ * neither, measured by one more launch) - rows beyond lav_batch_limit contribute 0, nothing needs zeroing.  amax_in / amax_in_count
+ * (device, or NULL / 0): such maxima of the tensor(s) x was assembled from - any values whose maximum bounds max |x| (e.g. the
+ * maxima of a tensor that x is a max-pooling, a crop or a bilinear resampling of); a LAV_CONV_F16X3 layer on the split kernel takes
+ * its power-of-two scale from them instead of measuring x (other layers ignore them).  A bound that is too small would overflow
+ * fp16 (Inf / NaN in y); one that is 2^k too large costs k of the 22 operand bits. */
+int lav_conv_amax_count(const lav_conv *c);
+int lav_conv2d_amax(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
+                    const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
+                    const float *amax_in, int amax_in_count, float *amax_out, void *stream);
 
 /* Grouped ConvTranspose2d with few output channels (memory bound, vector-ALU kernel): group g maps input channels
  * [g*cin/groups, (g+1)*cin/groups) to cout_per_group[g] (1..8) output channels; y is [batch][sum cout][oh][ow] with the

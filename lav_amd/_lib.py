@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 MAX_CAM = 4
 
 
@@ -74,6 +74,8 @@ SIGNATURES = {
     "lav_conv_tile_info": (_I, [C.POINTER(Conv), C.POINTER(_I)]),
     "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_conv_amax_count": (_I, [C.POINTER(Conv)]),
+    "lav_conv2d_amax": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P, _P]),
     "lav_deconv_grouped": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "lav_crop_rotate": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),
     "lav_crop_rotate_indexed": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _I, _F, _I, _F, _F, _P, _P]),

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "conv_f16.hpp"
 
 namespace {
 using namespace lav;
@@ -357,26 +358,43 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 #undef CONV_STAMP
 }
 
-// Split-K second pass: y = epilogue( sum_ks partial[ks] ), fixed summation order (deterministic).
-__global__ __launch_bounds__(256) void k_conv_reduce(ConvArgs a, int batch) {
+// Split-K second pass: y = epilogue( sum_ks partial[ks] ), fixed summation order (deterministic).  amax_out (round 6, LAV_CONV_F16X3's
+// scale hand-off): block b leaves the largest finite |y| it wrote in amax_out[b] (0 for blocks beyond lav_batch_limit).
+__device__ __forceinline__ float reduce_finite_abs(float v) {
+    const float a = fabsf(v);
+    return a <= 3.4028235e38f ? a : 0.f;
+}
+__global__ __launch_bounds__(256) void k_conv_reduce(ConvArgs a, int batch, float *__restrict__ amax_out) {
     const long plane_o = (long)a.OH * a.OW;
     const long total = (long)batch * a.cout * plane_o;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int n = (int)(e / (a.cout * plane_o));
-    if (a.n_valid && n >= *a.n_valid) return;   // lav_batch_limit: rows the first pass skipped hold no partial sums
-    const int co = (int)((e / plane_o) % a.cout);
-    const long pix = e % plane_o;
-    float v = 0.f;
-    for (int ks = 0; ks < a.ksplit; ++ks) v += a.partial[(long)ks * total + e];
-    if (a.bias) v += a.bias[co];
-    if (a.relu_pre) v = v > 0.f ? v : 0.f;
-    if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
-    const long idx = ((long)n * a.out_c_total + a.out_c_offset + co) * plane_o + pix;
-    if (a.res) v += a.res[idx];
-    if (a.relu_post) v = v > 0.f ? v : 0.f;
-    if (a.sigmoid && co >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
-    a.y[idx] = v;
+    const int n = (int)(min(e, total - 1) / (a.cout * plane_o));
+    // lav_batch_limit: rows the first pass skipped hold no partial sums
+    const bool live = e < total && !(a.n_valid && n >= *a.n_valid);
+    float m = 0.f;
+    if (live) {
+        const int co = (int)((e / plane_o) % a.cout);
+        const long pix = e % plane_o;
+        float v = 0.f;
+        for (int ks = 0; ks < a.ksplit; ++ks) v += a.partial[(long)ks * total + e];
+        if (a.bias) v += a.bias[co];
+        if (a.relu_pre) v = v > 0.f ? v : 0.f;
+        if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+        const long idx = ((long)n * a.out_c_total + a.out_c_offset + co) * plane_o + pix;
+        if (a.res) v += a.res[idx];
+        if (a.relu_post) v = v > 0.f ? v : 0.f;
+        if (a.sigmoid && co >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
+        a.y[idx] = v;
+        m = reduce_finite_abs(v);
+    }
+    if (amax_out) {   // (kernel-uniform)
+        __shared__ float s_m[4];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) amax_out[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host plan
@@ -596,6 +614,7 @@ struct DirectArgs {
     int ksplit;
     int relu_pre, relu_post, sigmoid;
     float pad_value;
+    float *amax_out;   // whole-K launches: the workgroup's largest finite |y| -> amax_out[linear workgroup] (null: not wanted)
 };
 
 // DEPTH = load batches in flight per wave: every weight byte is used once, so the stream runs at (bytes in flight) /
@@ -610,7 +629,11 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
     const int ks = blockIdx.z % a.ksplit, cls = blockIdx.z / a.ksplit;
     const int plane_o = a.OH * a.OW, plane_q = a.QH * a.QW;
     const int nty = a.cls_nty[cls], ntx = a.cls_ntx[cls];
-    if (a.n_valid && (int)(blockIdx.x * 32) / plane_q >= *a.n_valid) return;   // workgroup-uniform
+    const long wg_lin = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (a.n_valid && (int)(blockIdx.x * 32) / plane_q >= *a.n_valid) {   // workgroup-uniform
+        if (a.amax_out && a.ksplit == 1 && tid == 0) a.amax_out[wg_lin] = 0.f;
+        return;
+    }
     const int m = blockIdx.x * 32 + l31;
     const bool mvalid = m < a.M;
     const int mcl = min(m, a.M - 1);
@@ -707,6 +730,7 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
     __syncthreads();
     // (A ticket / last-arriver reduction inside this kernel was measured slower than the second launch: 15.1 vs 13.6 us on
     // the 512-channel 3x3 layer - the write-through stores, the atomic round trip and the acquire cost as much as a launch.)
+    float wmax = 0.f;
     for (int e = tid; e < MC * 1024; e += blockDim.x) {
         const int i = e >> 5, col = e & 31;
         const int co = cb + i, mm = blockIdx.x * 32 + col;
@@ -729,6 +753,19 @@ __global__ __launch_bounds__(MC == 1 ? 1024 : 512) void k_conv_direct(DirectArgs
         if (a.relu_post) v = v > 0.f ? v : 0.f;
         if (a.sigmoid && co >= a.sigmoid - 1) v = 1.f / (1.f + expf(-v));
         a.y[idx] = v;
+        wmax = fmaxf(wmax, reduce_finite_abs(v));
+    }
+    if (a.amax_out && a.ksplit == 1) {   // (kernel-uniform) the partial tiles in s_red are consumed: its first floats carry the waves' maxima
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+        __syncthreads();
+        if (lane == 0) s_red[wid] = wmax;
+        __syncthreads();
+        if (tid == 0) {
+            float mm = 0.f;
+            for (int w = 0; w < nw; ++w) mm = fmaxf(mm, s_red[w]);
+            a.amax_out[wg_lin] = mm;
+        }
     }
 }
 
@@ -824,11 +861,9 @@ Choice decide(const lav_conv &c, const Plan &p, double tile_cost, double tile_ra
             if (ch.sp.ok && (mode == 2 || (ch.sp.cost < other && !deep_stem))) ch.kind = 2;
         }
     }
-    // LAV_CONV_F16X3: where the split plan is the 2x2/w2 G = 2 whole-K kernel the mode is built for (the head convolution); any other
-    // layer of that precision runs as bf16x6
-    ch.sp.f16 = ch.kind == 2 && resolve_precision(c) == LAV_CONV_F16X3 && f16x3_layer(c, p) && !ch.sp.tp && ch.sp.MP == 2 && ch.sp.MC == 2 && ch.sp.WPX == 2 &&
-                        ch.sp.tap_group == 2 && ch.sp.ksplit == 1 && !ch.sp.sk_w && c.pad_value == 0.f
-                    ? 1 : 0;
+    // LAV_CONV_F16X3: wherever the split kernel runs the layer (round 5: the head convolution's plan only); on the fp32 kernels the
+    // precision means nothing
+    ch.sp.f16 = ch.kind == 2 && resolve_precision(c) == LAV_CONV_F16X3 && f16x3_layer(c, p) && !ch.sp.sk_w ? 1 : 0;
     if (smallcin_applies(c)) ch.kind = 3;   // camera stems: K = 3 x taps on packed fp32 FMAs (conv_smallcin.hpp)
     static const bool dbg = getenv("LAV_CONV_PLAN_DEBUG") != nullptr;
     if (dbg)
@@ -875,7 +910,7 @@ extern "C" int lav_conv_tile_info(const lav_conv *c, int *info) {
 
 namespace {
 template <int MP, int MC>
-int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t st) {
+int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t st, float *amax_out = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv<MP, MC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -899,6 +934,10 @@ int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t 
             ConvArgs at = a;
             at.trace = d_trace;
             hipLaunchKernelGGL((k_conv<MP, MC, true>), grid, dim3(256), lds, st, at);
+            if (a.ksplit > 1) {
+                const long total = (long)batch * a.cout * p.OH * p.OW;
+                hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, batch, amax_out);
+            }
             if (++runs % 10 == 0) {
                 std::vector<unsigned long long> h(nwg * 8);
                 if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -921,7 +960,7 @@ int launch(const ConvArgs &a, const Plan &p, int batch, size_t lds, hipStream_t 
     hipLaunchKernelGGL((k_conv<MP, MC>), grid, dim3(256), lds, st, a);
     if (a.ksplit > 1) {
         const long total = (long)batch * a.cout * p.OH * p.OW;
-        hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, batch);
+        hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, batch, amax_out);
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
@@ -1087,15 +1126,55 @@ extern "C" size_t lav_conv_workspace_bytes(const lav_conv *c) {
     if (ch.kind == 1) a.ksplit = ch.dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     if (ch.kind == 3) return 0;
-    if (ch.kind == 2 && ch.sp.f16) return (size_t)F16_PARTS * sizeof(float);
     const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);   // stream-K: head and tail parts of the cut tiles
-    return (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
+    // LAV_CONV_F16X3: F16_PARTS floats behind the slabs for the launch that measures x when no producer maxima are handed in
+    return (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float) + (ch.kind == 2 && ch.sp.f16 ? (size_t)F16_PARTS * sizeof(float) : 0);
+}
+
+namespace {
+// How many floats a launch of this plan leaves in amax_out, and whether its own kernels write them (else lav_conv2d measures y with
+// one more launch: F16_PARTS floats).  Whole-K split / direct launches: one per workgroup; split-K: one per block of k_conv_reduce.
+struct AmaxPlan { int count; bool in_kernel; };
+AmaxPlan amax_plan(const lav_conv &c, const Plan &p, const Choice &ch, int tiled_ksplit) {
+    const long reduce_blocks = ((long)c.batch * c.cout * p.OH * p.OW + 255) / 256;
+    long n = 0;
+    if (ch.kind == 2 && !ch.sp.sk_w) {
+        const int NBLK = (4 / ch.sp.WPX) * ch.sp.MC;
+        n = ch.sp.ksplit > 1 ? reduce_blocks : (long)((c.cout + NBLK * 32 - 1) / (NBLK * 32)) * ch.sp.tiles * c.batch * p.nclasses;
+    } else if (ch.kind == 1) {
+        n = ch.dp.ksplit > 1 ? reduce_blocks : (long)((c.batch * p.QH * p.QW + 31) / 32) * ((c.cout + 32 * ch.dp.mc - 1) / (32 * ch.dp.mc)) * p.nclasses;
+    } else if (ch.kind == 0 && tiled_ksplit > 1) {
+        n = reduce_blocks;
+    }
+    if (n < 1 || n > AMAX_MAX) return AmaxPlan{F16_PARTS, false};
+    return AmaxPlan{(int)n, true};
+}
+}  // namespace
+
+extern "C" int lav_conv_amax_count(const lav_conv *c) {
+    if (!c) return 0;
+    Plan p;
+    if (build_plan(*c, p)) return 0;
+    ConvArgs a;
+    int MP, MC;
+    size_t lds;
+    double cost = 0, raw = 0;
+    if (choose_tile(*c, p, a, MP, MC, lds, &cost, &raw)) return 0;
+    const Choice ch = decide(*c, p, cost, raw);
+    return amax_plan(*c, p, ch, a.ksplit).count;
 }
 
 extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
                           const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
                           void *stream) {
+    return lav_conv2d_amax(c, x, w_packed, bias, scale, shift, residual, y, workspace, workspace_bytes, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int lav_conv2d_amax(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
+                               const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
+                               const float *amax_in, int amax_in_count, float *amax_out, void *stream) {
     LAV_REQUIRE(c && x && w_packed && y, "lav_conv2d: null argument");
+    LAV_REQUIRE(!amax_in || amax_in_count >= 1, "lav_conv2d_amax: amax_in without a count");
     LAV_REQUIRE((scale == nullptr) == (shift == nullptr), "lav_conv2d: scale and shift go together");
     Plan p;
     int rc = build_plan(*c, p);
@@ -1117,23 +1196,34 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     const Choice ch = decide(*c, p, cost, raw);
     const DirectPlan &dp = ch.dp;
     const bool direct = ch.kind == 1;
-    if (ch.kind == 3) {
-        a.pad_value = c->pad_value;
-        return launch_smallcin(*c, p, a, static_cast<hipStream_t>(stream));
-    }
     if (direct) a.ksplit = dp.ksplit;
     if (ch.kind == 2) a.ksplit = ch.sp.ksplit;
     const int slabs = ch.kind == 2 && ch.sp.sk_w ? 2 : (a.ksplit > 1 ? a.ksplit : 0);
-    if (ch.kind == 2 && ch.sp.f16) {
-        if (!workspace || workspace_bytes < F16_PARTS * sizeof(float)) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (fp16 scale)", workspace_bytes, F16_PARTS * sizeof(float));
-        a.partial = static_cast<float *>(workspace);
-    } else if (slabs) {
-        const size_t need = (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
-        if (!workspace || workspace_bytes < need) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, need);
+    const size_t slab_bytes = (size_t)slabs * c->batch * c->cout * p.OH * p.OW * sizeof(float);
+    AmaxIO io{amax_in, amax_in_count, nullptr, nullptr};
+    if (ch.kind == 2 && ch.sp.f16 && !amax_in) {   // the launch that measures x writes behind the slabs
+        if (!workspace || workspace_bytes < slab_bytes + F16_PARTS * sizeof(float))
+            return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (fp16 scale)", workspace_bytes, slab_bytes + F16_PARTS * sizeof(float));
+        io.scratch = reinterpret_cast<float *>(static_cast<char *>(workspace) + slab_bytes);
+    }
+    if (slabs) {
+        if (!workspace || workspace_bytes < slab_bytes) return fail(LAV_EWORKSPACE, "lav_conv2d: workspace %zu < %zu bytes (split-K)", workspace_bytes, slab_bytes);
         a.partial = static_cast<float *>(workspace);
     } else {
         a.partial = nullptr;
     }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the maxima of |y| for the next layer's fp16 scale: from this launch's own epilogue / reduce pass where the plan has one, else
+    // measured behind it (ap.count floats either way: lav_conv_amax_count)
+    const AmaxPlan ap = amax_plan(*c, p, ch, a.ksplit);
+    io.out = amax_out && ap.in_kernel ? amax_out : nullptr;
+    auto measure_y = [&]() -> int {
+        if (!amax_out || ap.in_kernel) return LAV_OK;
+        const int rcm = launch_absmax_parts(y, c->batch, c->out_c_total, c->out_c_offset, c->cout, (long)p.OH * p.OW, amax_out, lav::batch_limit(), st);
+        if (rcm) return rcm;
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
+    };
     {
         a.pad_value = c->pad_value;
         a.trace = nullptr;
@@ -1149,10 +1239,14 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
     for (int cl = 0; cl < p.nclasses; ++cl)
         for (size_t t = 0; t < p.taps[cl].size(); ++t) a.toff[cl * p.taps_per_class + t] = p.taps[cl][t].dy * a.Wst + p.taps[cl][t].dx;
 
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ch.kind == 3) {
+        rc = launch_smallcin(*c, p, a, st);
+        return rc ? rc : measure_y();
+    }
     if (ch.kind == 2) {
         const unsigned char *w_split = reinterpret_cast<const unsigned char *>(w_packed + (p.wfloats + 3) / 4 * 4);
-        return launch_split(*c, p, ch.sp, a, w_split, st, ch.sp.f16 ? w_split + split_weight_bytes(p) : nullptr);
+        rc = launch_split(*c, p, ch.sp, a, w_split, st, ch.sp.f16 ? w_split + split_weight_bytes(p) : nullptr, io);
+        return rc ? rc : measure_y();
     }
     if (direct) {
         DirectArgs d;
@@ -1180,6 +1274,7 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         }
         d.M = c->batch * p.QH * p.QW; d.cw = dp.cw; d.cks = dp.cw * dp.waves; d.ksplit = dp.ksplit;
         d.relu_pre = c->relu_pre; d.relu_post = c->relu_post; d.sigmoid = c->sigmoid; d.pad_value = c->pad_value;
+        d.amax_out = io.out;
         const int tok = timer_begin("conv2d", st);
         dim3 grid((d.M + 31) / 32, (c->cout + 32 * dp.mc - 1) / (32 * dp.mc), dp.ksplit * p.nclasses);
         const dim3 block(64 * dp.waves);
@@ -1198,13 +1293,14 @@ extern "C" int lav_conv2d(const lav_conv *c, const float *x, const float *w_pack
         }
         if (dp.ksplit > 1) {
             const long total = (long)c->batch * c->cout * p.OH * p.OW;
-            hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, c->batch);
+            hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, c->batch, io.out);
         }
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
-        return LAV_OK;
+        return measure_y();
     }
-    if (MP == 2 && MC == 2) return launch<2, 2>(a, p, c->batch, lds, st);
-    if (MP == 1 && MC == 2) return launch<1, 2>(a, p, c->batch, lds, st);
-    return launch<1, 1>(a, p, c->batch, lds, st);
+    if (MP == 2 && MC == 2) rc = launch<2, 2>(a, p, c->batch, lds, st, io.out);
+    else if (MP == 1 && MC == 2) rc = launch<1, 2>(a, p, c->batch, lds, st, io.out);
+    else rc = launch<1, 1>(a, p, c->batch, lds, st, io.out);
+    return rc ? rc : measure_y();
 }

@@ -42,20 +42,29 @@ def move_lidar_points(xyz: torch.Tensor, dloc, ori0: float, ori1: float) -> torc
                         xyz[:, 2]], dim=1)
 
 
+def _at_frame_precision(fn):
+    """Run a pipeline method with the pipeline's inference precision in force (ops.precision): the eval engines it touches are the
+    ones packed for that precision - cached per precision on their modules, nothing is written onto a model somebody else owns."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with ops.precision(self.precision):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class FramePipeline:
     def __init__(self, lidar_model, uniplanner, seg_model, bra_model, camera_x=1.5, camera_z=2.4, num_frame_stack=2,
                  device=torch.device("cuda"), compact_ego_box: bool = False):
         self.device = device
-        # Round 5: the frame's head convolution (384 -> 256, the largest kernel of the tick and power bound) on LAV_CONV_F16X3 - two fp16
-        # pieces per operand, three products instead of six (conv_split.hpp).  Asked for HERE, by the inference pipelines: a LiDARModel
-        # that a trainer owns keeps bf16x6 (its engines are re-packed on the device after every step, which the fp16 packing does not
-        # support).  LAV_HEADS_PRECISION=bf16x6 switches it off.
-        exact = os.environ.get("LAV_CONV_PRECISION", "") in ("f32", "fp32")       # (the exact-fp32 frame keeps every layer on the fp32 kernels)
-        want = 0 if exact or os.environ.get("LAV_HEADS_PRECISION", "f16x3") != "f16x3" else 3
-        if getattr(lidar_model, "heads_precision", 0) != want and hasattr(lidar_model, "_drop"):
-            lidar_model.heads_precision = want
-            lidar_model._drop()
-        self.infer_model = InferModel(lidar_model, uniplanner, camera_x, camera_z, device=device)
+        # Round 5 put the frame's head convolution on LAV_CONV_F16X3 (two fp16 pieces per operand, three products instead of six,
+        # conv_split.hpp) by writing a flag onto the LiDARModel; round 6 runs EVERY split-kernel layer of the frame that way (the scale
+        # handed from layer to layer, lav_conv2d_amax) and asks for it through ops.precision around the pipeline's own calls: the
+        # engines are cached per precision on their modules, a model that a trainer owns keeps its default engines (ADVICE r5).
+        # LAV_INFER_PRECISION=bf16x6 (or round 5's LAV_HEADS_PRECISION=bf16x6) switches the mode off; LAV_CONV_PRECISION=f32 too.
+        self.precision = ops.frame_precision()
+        self.infer_model = InferModel(lidar_model, uniplanner, camera_x, camera_z, device=device, precision=self.precision)
         self.seg_model, self.bra_model = seg_model, bra_model
         self.num_frame_stack = num_frame_stack
         self.num_frame_keep = (num_frame_stack + 1) * GAP
@@ -97,6 +106,7 @@ class FramePipeline:
         return torch.cat(parts)
 
     @torch.no_grad()
+    @_at_frame_precision
     def step(self, lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value):
         """One frame.  lidar (n,4) f32, all_rgbs (3,3,288,256) f32, rgbs (1,3,288,768) f32, tel_rgbs (1,3,192,480)
         f32 - all resident in HBM; loc (2,) / ori host floats (EKF pose); nxps (2,) HBM; cmd_value int."""
@@ -277,7 +287,7 @@ class GraphedFramePipeline(FramePipeline):
 
     def _g_ego(self, cmd_value):
         up, features = self.infer_model.uniplanner, self.b_features
-        ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], up.pixels_per_meter / 2, up.crop_size)
+        ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], up.pixels_per_meter / 2, up.crop_size, amax=ops.amax_of(features))
         ego_embd, ego_cast, _ = up.embed_cast(ego_crop)
         ego_plan = up.plan(ego_embd, self.b_nxp[None], cast_locs=ego_cast, pixels_per_meter=up.pixels_per_meter,
                            crop_size=up.crop_size * 2, cmd=int(cmd_value))[0, -1, 0]
@@ -288,7 +298,7 @@ class GraphedFramePipeline(FramePipeline):
         up = self.infer_model.uniplanner
         feats = self.b_features
         locs, oris = self.b_locs[:n], self.b_oris[:n]
-        crops = up.crop_feature(feats.expand(n, -1, -1, -1), locs, oris, up.pixels_per_meter / 2, up.crop_size)
+        crops = up.crop_feature(feats.expand(n, -1, -1, -1), locs, oris, up.pixels_per_meter / 2, up.crop_size, amax=ops.amax_of(feats))
         _, cast, cmds = up.embed_cast(crops, oris=oris, locs=locs, want_cmds=True)   # pool, cast GRUs, command scores, ego frame
         return dict(other_cast_locs=cast, other_cast_cmds=cmds)
 
@@ -350,6 +360,7 @@ class GraphedFramePipeline(FramePipeline):
         self.d_pose.copy_(self.h_pose, non_blocking=True)
 
     @torch.no_grad()
+    @_at_frame_precision
     def step(self, lidar, all_rgbs, rgbs, tel_rgbs, loc, ori, nxps, cmd_value):
         n = int(lidar.shape[0])
         if n > self.P:
@@ -480,6 +491,7 @@ class GraphedFramePipeline(FramePipeline):
                     det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])
 
     @torch.no_grad()
+    @_at_frame_precision
     def recover_plan(self, out, cmd_value):
         """Called by the consumer of step()'s result when `ego_plan_locs` holds NaN: if the persistent plan kernel gave up
         (its 64 workgroups were not co-resident beside the other streams' work - status word of its workspace), warn and
@@ -497,6 +509,7 @@ class GraphedFramePipeline(FramePipeline):
         return plan
 
     @torch.no_grad()
+    @_at_frame_precision
     def plan_deviation(self, out, cmd_value) -> float:
         """max |graph's persistent plan - the same plan recomputed on the step-per-launch path| of a frame `step` returned (the two
         paths are bit-identical: tests/test_gpu_paint_gru.py).  A finite but wrong plan is invisible to the health counters - round
@@ -528,6 +541,7 @@ class GraphedFramePipeline(FramePipeline):
                     last_plan_launch=diag)
 
     @torch.no_grad()
+    @_at_frame_precision
     def precapture(self, cmds=range(6), max_others=15):
         """Capture every graph a drive will need up front - the frame graphs, one ego graph per command value, one others
         graph per vehicle count up to `max_others` - so that no 20 Hz tick pays a capture (hundreds of ms) the first time a

@@ -12,7 +12,9 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
-from .ops import ConvLayer, GroupedDeconv
+from . import _lib
+from . import ops
+from .ops import Amax, ConvLayer, GroupedDeconv
 from .point_pillar import PointPillarNet
 
 _NORM = dict(eps=1e-3, momentum=0.01)
@@ -113,15 +115,19 @@ class ConvBackbone(_Engine):
         self._drop()
 
     def _engine(self, device):
-        eng = self._fresh(device)
-        if eng is not None:
-            return eng
+        """The packed layers for the calling thread's inference precision (ops.infer_precision: the frame pipelines ask for
+        LAV_CONV_F16X3, a trainer's log inference gets the default) - one engine per precision, cached side by side."""
+        prec = ops.infer_precision()
+        eng = self._fresh(device) or dict(device=device)
+        key = ("backbone", prec)
+        if key in eng:
+            return eng[key]
         def stage(seq):
             out = []
             for j in range(0, len(seq), 3):
                 conv, bn = seq[j], seq[j + 2]
                 out.append(ConvLayer(conv.weight, stride=conv.stride[0], padding=conv.padding, bn=_bn_tuple(bn),
-                                     bn_eps=bn.eps, relu_pre=True, device=device))
+                                     bn_eps=bn.eps, relu_pre=True, precision=prec, device=device))
             return out
         ups = []
         off = 0
@@ -129,12 +135,12 @@ class ConvBackbone(_Engine):
             ct, bn = seq[0], seq[2]
             ups.append(ConvLayer(ct.weight, stride=ct.stride[0], padding=ct.padding, transposed=True,
                                  output_padding=ct.output_padding[0], bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True,
-                                 out_c_total=self.out_channels, out_c_offset=off, device=device))
+                                 out_c_total=self.out_channels, out_c_offset=off, precision=prec, device=device))
             off += ct.weight.shape[1]
-        eng = dict(device=device, s1=stage(self.conv1), s2=stage(self.conv2), s3=stage(self.conv3), ups=ups)
+        eng[key] = dict(s1=stage(self.conv1), s2=stage(self.conv2), s3=stage(self.conv3), ups=ups, amax={}, f16=prec == _lib.CONV_F16X3)
         eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use
         object.__setattr__(self, "_eng", eng)
-        return eng
+        return eng[key]
 
     def forward_train(self, x):
         """Train mode (autograd, BatchNorm on batch statistics): the nn modules themselves (lidar.py:110-143)."""
@@ -150,16 +156,42 @@ class ConvBackbone(_Engine):
             return self.forward_train(x)
         self._need_eval()
         e = self._engine(x.device)
-        feats = []
-        for st in (e["s1"], e["s2"], e["s3"]):
-            for layer in st:
-                x = layer(x)
-            feats.append(x)
+        if not e["f16"]:
+            feats = []
+            for st in (e["s1"], e["s2"], e["s3"]):
+                for layer in st:
+                    x = layer(x)
+                feats.append(x)
+            oh, ow = e["ups"][0].out_hw(feats[0].shape[2], feats[0].shape[3])
+            if out is None:
+                out = torch.empty((x.shape[0], self.out_channels, oh, ow), dtype=torch.float32, device=x.device)
+            for up, f in zip(e["ups"], feats):
+                up(f, out=out)
+            return out
+        # LAV_CONV_F16X3: every layer leaves the maxima of what it writes for the layers that read it (lav_conv2d_amax) - none of
+        # them measures its input; the three up-convolutions leave the feature map's for the heads and the crops' stems
+        B = x.shape[0]
+        ams = e["amax"].get(tuple(x.shape))
+        if ams is None:
+            ams = e["amax"][tuple(x.shape)] = [Amax(x.device) for _ in range(len(e["s1"]) + len(e["s2"]) + len(e["s3"]) + 1)]
+        stages = (e["s1"], e["s2"], e["s3"])
+        feats, feat_am, am_prev, i = [], [], ops.amax_of(x), 0
+        for si, st in enumerate(stages):
+            for li, layer in enumerate(st):
+                oh, ow = layer.out_hw(x.shape[2], x.shape[3])
+                readers = ([st[li + 1]] if li + 1 < len(st) else ([stages[si + 1][0]] if si + 1 < len(stages) else [])) + \
+                          ([e["ups"][si]] if li + 1 == len(st) else [])
+                am = ams[i].reset() if any(r.uses_amax(B, oh, ow) for r in readers) else None
+                x = layer(x, amax_in=am_prev, amax_out=am)
+                am_prev, i = am, i + 1
+            feats.append(x); feat_am.append(am_prev)
         oh, ow = e["ups"][0].out_hw(feats[0].shape[2], feats[0].shape[3])
         if out is None:
-            out = torch.empty((x.shape[0], self.out_channels, oh, ow), dtype=torch.float32, device=x.device)
-        for up, f in zip(e["ups"], feats):
-            up(f, out=out)
+            out = torch.empty((B, self.out_channels, oh, ow), dtype=torch.float32, device=x.device)
+        am_out = ams[-1].reset()
+        for up, f, am in zip(e["ups"], feats, feat_am):
+            up(f, out=out, amax_in=am, amax_out=am_out)
+        out._lav_amax = am_out
         return out
 
 
@@ -220,9 +252,13 @@ class LiDARModel(_Engine):
         """Fused engine of a subset of the heads: ONE convolution 384 -> 64*len(names) (the 39 MB feature map is read once)
         and ONE grouped transposed convolution 64*len -> sum(outputs) (lav_deconv_grouped: every head's tail reads its own
         64 channels); a sigmoid head must come last (lidar.py:30-33,159-161)."""
+        prec = ops.infer_precision()
+        if prec == 0 and getattr(self, "heads_precision", 0):   # (round 5's per-model knob, still honoured when somebody sets it)
+            prec = self.heads_precision
         eng = self._fresh(device) or dict(device=device)
+        names = (names, prec)
         if names not in eng:
-            hs = [getattr(self, n) for n in names]
+            hs = [getattr(self, n) for n in names[0]]
             for h in hs:
                 if not (h._sigmoid or isinstance(h.output_activation, nn.Identity)):
                     raise RuntimeError("Head.output_activation must be identity or sigmoid for the fused epilogue")
@@ -235,7 +271,7 @@ class LiDARModel(_Engine):
             outs = [ct.weight.shape[1] for ct in cts]
             eng[names] = dict(outs=outs,
                               conv=ConvLayer(w, padding=1, bn=bn, bn_eps=hs[0].net[2].eps, relu_pre=True, device=device,
-                                             precision=getattr(self, "heads_precision", 0)),   # (the frame pipelines ask for LAV_CONV_F16X3)
+                                             precision=prec),   # (the frame pipelines ask for LAV_CONV_F16X3)
                               deconv=GroupedDeconv(cts, sigmoid_from=sum(outs[:-1]) if sig[-1] else -1, device=device))
             eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use
             object.__setattr__(self, "_eng", eng)
@@ -250,7 +286,7 @@ class LiDARModel(_Engine):
         if self.training:
             return self._heads_train(features, names)
         e = self._head_engine(tuple(names), features.device)
-        fused = e["deconv"](e["conv"](features))          # (B, sum(outs), 2H, 2W)
+        fused = e["deconv"](e["conv"](features, amax_in=ops.amax_of(features)))          # (B, sum(outs), 2H, 2W)
         return tuple(torch.split(fused, e["outs"], dim=1))
 
     def _heads_train(self, features, names):

@@ -82,8 +82,12 @@ def extract_peak(heatmap, max_pool_ks: int = 7, min_score: float = 0.1, max_det:
 
 
 class InferModel(nn.Module):
-    def __init__(self, lidar_model, uniplanner, camera_x, camera_z, device=torch.device("cuda")):
+    def __init__(self, lidar_model, uniplanner, camera_x, camera_z, device=torch.device("cuda"), precision=None):
+        """precision: lav_conv.precision of the eval engines this wrapper runs its modules at (default ops.frame_precision():
+        LAV_CONV_F16X3 - every split-kernel convolution on two fp16 pieces, the scale handed from layer to layer; waypoints stay
+        within 1e-4 of the reference, tests/test_gpu_e2e.py).  The engines are cached per precision on the modules."""
         super().__init__()
+        self.precision = ops.frame_precision() if precision is None else int(precision)
         self.lidar_model = lidar_model
         self.uniplanner = uniplanner
         self.coord_converters = [CoordConverter(yaw, lidar_xyz=[0, 0, camera_z], cam_xyz=[camera_x, 0, camera_z],
@@ -106,11 +110,12 @@ class InferModel(nn.Module):
     @torch.no_grad()
     def forward(self, lidar_points, nxps, cmd_value):
         lm = self.lidar_model
-        canvas = lm.point_pillar_net([lidar_points], [len(lidar_points)])
-        features = lm.backbone(canvas)
-        heat, size, ori, pred_bev = lm.heads(features)
-        det = self.det_decode(ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True).cpu().tolist())
-        ego_embd, ego_plan, ego_cast, other_cast, other_cmds = self.uniplanner.infer_all(features[0], det[1], cmd_value, nxps)
+        with ops.precision(self.precision):
+            canvas = lm.point_pillar_net([lidar_points], [len(lidar_points)])
+            features = lm.backbone(canvas)
+            heat, size, ori, pred_bev = lm.heads(features)
+            det = self.det_decode(ops.extract_peaks(heat[0], size[0], ori[0], apply_sigmoid=True).cpu().tolist())
+            ego_embd, ego_plan, ego_cast, other_cast, other_cmds = self.uniplanner.infer_all(features[0], det[1], cmd_value, nxps, amax=ops.amax_of(features))
         return ego_embd, ego_plan, ego_cast, other_cast, other_cmds, pred_bev, det
 
     def det_inference(self, heatmaps, sizemaps, orimaps, min_score=0.2):
@@ -166,7 +171,8 @@ class InferModel(nn.Module):
         return dets, np.zeros((0, 2)), np.zeros((0,))
 
     def uniplanner_infer(self, features, det, cmd_value, nxp):
-        return self.uniplanner.infer_all(features, det, cmd_value, nxp)
+        with ops.precision(self.precision):
+            return self.uniplanner.infer_all(features, det, cmd_value, nxp)
 
     def point_painting(self, lidar, sems):
         """Painted channels only, for already class-0-suppressed maps `sems` (3,C,H,W) - the reference's

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os as _os
+import threading as _threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -337,6 +338,79 @@ def gru_plan_diag(B: int, H: int, num_cmds: int, cmd: int, device, stream=None) 
 
 
 # ------------------------------------------------------------------------------------------ conv
+_precision_stack = _threading.local()
+
+
+def infer_precision() -> int:
+    """lav_conv.precision of the eval-mode engines built from now on by this thread: the innermost `with precision(...)`, else
+    LAV_INFER_PRECISION (f16x3 | bf16x6 | f32, default: the library's, i.e. LAV_CONV_PRECISION / bf16x6).  The frame pipelines and
+    InferModel ask for LAV_CONV_F16X3 (round 6: every split-kernel layer on two fp16 pieces, the scale handed from layer to layer);
+    an engine a trainer builds by calling a module directly keeps the default (its layers are re-packed on the device after every
+    step, which the fp16 packing does not support)."""
+    st = getattr(_precision_stack, "v", None)
+    if st:
+        return st[-1]
+    return {"f16x3": _lib.CONV_F16X3, "bf16x6": _lib.CONV_BF16X6, "f32": _lib.CONV_F32, "fp32": _lib.CONV_F32}.get(
+        _os.environ.get("LAV_INFER_PRECISION", ""), 0)
+
+
+class precision:
+    """with ops.precision(_lib.CONV_F16X3): ... - the eval engines used inside are the ones packed for that precision (engines are
+    cached per precision on their modules: nothing is written onto a module that somebody else owns)."""
+
+    def __init__(self, p: int):
+        self.p = int(p)
+
+    def __enter__(self):
+        st = getattr(_precision_stack, "v", None)
+        if st is None:
+            st = _precision_stack.v = []
+        st.append(self.p)
+        return self
+
+    def __exit__(self, *exc):
+        _precision_stack.v.pop()
+        return False
+
+
+def frame_precision() -> int:
+    """What the inference pipelines run at: LAV_CONV_F16X3 unless LAV_CONV_PRECISION asks for the exact-fp32 kernels or
+    LAV_INFER_PRECISION / LAV_HEADS_PRECISION (round 5's knob) say bf16x6."""
+    if _os.environ.get("LAV_CONV_PRECISION", "") in ("f32", "fp32"):
+        return 0
+    want = _os.environ.get("LAV_INFER_PRECISION", _os.environ.get("LAV_HEADS_PRECISION", "f16x3"))
+    return _lib.CONV_F16X3 if want == "f16x3" else 0
+
+
+class Amax:
+    """Maxima of the finite |values| of a tensor, in parts, as the launches that wrote it left them (lav_conv2d_amax): the next
+    LAV_CONV_F16X3 layer takes its power-of-two activation scale from them instead of measuring its input.  One fixed buffer;
+    `take(n)` hands out the next n slots (the same addresses on every pass over the same layers: HIP graphs may hold them)."""
+    CAPACITY = 20480
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.CAPACITY, dtype=torch.float32, device=device)
+        self.count = 0
+
+    def reset(self):
+        self.count = 0
+        return self
+
+    def take(self, n: int) -> torch.Tensor:
+        if self.count + n > self.CAPACITY:
+            raise RuntimeError(f"Amax: {self.count} + {n} parts exceed the buffer ({self.CAPACITY})")
+        v = self.buf[self.count:self.count + n]
+        self.count += n
+        return v
+
+
+def amax_of(t):
+    """The Amax a producer attached to the tensor OBJECT it returned (engine-internal hand-off between modules: backbone -> heads /
+    crops); None for anything else.  A bound, not a measurement: valid for the tensor and for whatever is a max-pool, a crop or a
+    bilinear resampling of it."""
+    return getattr(t, "_lav_amax", None)
+
+
 class ConvLayer:
     """One fused convolution of the C ABI: packed weights + epilogue vectors resident in HBM.
 
@@ -460,7 +534,23 @@ class ConvLayer:
         check(_lib.load().lav_conv_out_hw(C.byref(d), C.byref(oh), C.byref(ow)), "lav_conv_out_hw")
         return oh.value, ow.value
 
-    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None):
+    def uses_amax(self, B: int, h: int, w: int) -> bool:
+        """Whether this layer on a (B, ., h, w) input runs the fp16 three-product plan, i.e. has a use for its producers' maxima."""
+        key = ("f16", B, h, w, _os.environ.get("LAV_CONV_SPLIT"), _os.environ.get("LAV_SPLIT_SK"))
+        v = self._ws_bytes.get(key)
+        if v is None:
+            v = False
+            if self.desc.precision == _lib.CONV_F16X3:
+                d = Conv.from_buffer_copy(self.desc)
+                d.batch, d.h, d.w = B, h, w
+                info = (C.c_int * 9)()
+                v = _lib.load().lav_conv_tile_info(C.byref(d), info) == 0 and info[0] == -1 and info[7] >= 200
+            self._ws_bytes[key] = v
+        return v
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 amax_in: Optional["Amax"] = None, amax_out: Optional["Amax"] = None):
+        """amax_in: maxima that bound |x| (an Amax its producers filled); amax_out: an Amax this launch appends the maxima of |y| to."""
         x = _f32c(x, "x")
         B, ct, h, w = x.shape
         if ct != self.in_c_total:
@@ -482,9 +572,25 @@ class ConvLayer:
         if nbytes is None:
             nbytes = self._ws_bytes[key] = lib.lav_conv_workspace_bytes(C.byref(d))
         ws = _workspace("conv", nbytes, x.device) if nbytes else None
-        check(lib.lav_conv2d(C.byref(d), _ptr(x), _ptr(self.w), _ptr(self.bias), _ptr(self.scale), _ptr(self.shift),
-                             _ptr(residual), _ptr(out), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
-              "lav_conv2d")
+        if amax_in is None and amax_out is None:
+            check(lib.lav_conv2d(C.byref(d), _ptr(x), _ptr(self.w), _ptr(self.bias), _ptr(self.scale), _ptr(self.shift),
+                                 _ptr(residual), _ptr(out), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+                  "lav_conv2d")
+            return out
+        a_in = amax_in.buf if amax_in is not None and amax_in.count > 0 else None
+        a_out = None
+        if amax_out is not None:
+            ck = ("amax", B, h, w, _os.environ.get("LAV_CONV_SPLIT"), _os.environ.get("LAV_SPLIT_SK"))
+            n_out = self._ws_bytes.get(ck)
+            if n_out is None:
+                n_out = self._ws_bytes[ck] = lib.lav_conv_amax_count(C.byref(d))
+            if n_out < 1:
+                raise RuntimeError("lav_conv_amax_count: " + lib.lav_last_error().decode())
+            a_out = amax_out.take(n_out)
+        check(lib.lav_conv2d_amax(C.byref(d), _ptr(x), _ptr(self.w), _ptr(self.bias), _ptr(self.scale), _ptr(self.shift),
+                                  _ptr(residual), _ptr(out), _ptr(ws), ws.numel() if ws is not None else 0,
+                                  _ptr(a_in), amax_in.count if a_in is not None else 0, _ptr(a_out), _stream()),
+              "lav_conv2d_amax")
         return out
 
 

@@ -8,8 +8,9 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
+from . import _lib
 from .lidar import _Engine, _bn_tuple
-from .ops import ConvLayer
+from .ops import Amax, ConvLayer
 
 
 class BasicBlock(nn.Module):
@@ -47,21 +48,25 @@ class ResNet(_Engine):
         self._drop()
 
     def _engine(self, device):
-        eng = self._fresh(device)
-        if eng is not None:
-            return eng
+        """The packed layers for the calling thread's inference precision (ops.infer_precision), one engine per precision."""
+        from . import ops
+        prec = ops.infer_precision()
+        eng = self._fresh(device) or dict(device=device)
+        key = ("trunk", prec)
+        if key in eng:
+            return eng[key]
         def cl(conv, bn, **kw):
             return ConvLayer(conv.weight, stride=conv.stride[0], padding=conv.padding, bn=_bn_tuple(bn), bn_eps=bn.eps,
-                             device=device, target_cus=getattr(self, "target_cus", 0), **kw)
+                             device=device, target_cus=getattr(self, "target_cus", 0), precision=prec, **kw)
         blocks = []
         for i in range(1, 5):
             for blk in getattr(self, f"layer{i}"):
                 blocks.append(dict(c1=cl(blk.conv1, blk.bn1, relu_post=True), c2=cl(blk.conv2, blk.bn2, relu_post=True),
                                    down=None if blk.downsample is None else cl(blk.downsample[0], blk.downsample[1])))
-        eng = dict(device=device, stem=cl(self.conv1, self.bn1, relu_post=True), blocks=blocks)
+        eng[key] = dict(stem=cl(self.conv1, self.bn1, relu_post=True), blocks=blocks, amax={}, f16=prec == _lib.CONV_F16X3)
         eng["tensor_ids"] = self._tensor_ids()   # (recorded where the engine is built: lidar.py:_Engine._fresh)
         object.__setattr__(self, "_eng", eng)
-        return eng
+        return eng[key]
 
     def forward_train(self, x):
         """Train mode (autograd, BatchNorm on batch statistics): plain torch ops over the same modules."""
@@ -78,10 +83,34 @@ class ResNet(_Engine):
             return self.forward_train(x)
         e = self._engine(x.device)
         from . import ops
-        x = ops.maxpool3x3s2(e["stem"](x))     # nn.MaxPool2d(3, 2, 1)
-        for b in e["blocks"]:
-            identity = x if b["down"] is None else b["down"](x)
-            x = b["c2"](b["c1"](x), residual=identity)
+        if not e["f16"]:
+            x = ops.maxpool3x3s2(e["stem"](x))     # nn.MaxPool2d(3, 2, 1)
+            for b in e["blocks"]:
+                identity = x if b["down"] is None else b["down"](x)
+                x = b["c2"](b["c1"](x), residual=identity)
+            return x
+        # LAV_CONV_F16X3: every convolution leaves the maxima of its output for the layers that read it (lav_conv2d_amax); the stem
+        # takes those of its input from whoever made it (the crops carry the feature map's), the max-pool passes its input's on
+        B = x.shape[0]
+        ams = e["amax"].get(tuple(x.shape))
+        if ams is None:
+            ams = e["amax"][tuple(x.shape)] = [Amax(x.device) for _ in range(1 + 2 * len(e["blocks"]))]
+        blocks = e["blocks"]
+        def want(readers, h, w):
+            return any(r is not None and r.uses_amax(B, h, w) for r in readers)
+        oh, ow = e["stem"].out_hw(x.shape[2], x.shape[3])
+        ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+        am_x = ams[0].reset() if want([blocks[0]["c1"], blocks[0]["down"]], ph, pw) else None
+        x = ops.maxpool3x3s2(e["stem"](x, amax_in=ops.amax_of(x), amax_out=am_x))
+        for i, b in enumerate(blocks):
+            identity = x if b["down"] is None else b["down"](x, amax_in=am_x)
+            h1, w1 = b["c1"].out_hw(x.shape[2], x.shape[3])
+            am_h = ams[1 + 2 * i].reset() if want([b["c2"]], h1, w1) else None
+            h = b["c1"](x, amax_in=am_x, amax_out=am_h)
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            am_y = ams[2 + 2 * i].reset() if nxt is not None and want([nxt["c1"], nxt["down"]], h1, w1) else None
+            x = b["c2"](h, residual=identity, amax_in=am_h, amax_out=am_y)
+            am_x = am_y
         return x
 
 

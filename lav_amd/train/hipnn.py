@@ -141,6 +141,7 @@ def conv_relu_bn(seq, x):
 #                  weight gradient torch (correct, 1 ms per step slower: not the default)
 # LAV_TRAIN_CONV=torch routes everything back to torch.nn.functional (A/B timing, the CPU tests).
 _CONV_ENGINES = {}
+_CONV_ENGINES_MAX = 256
 
 
 def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding):
@@ -152,6 +153,8 @@ def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding)
            torch.cuda.current_stream(dev).cuda_stream)
     eng = _CONV_ENGINES.get(key)
     if eng is None:
+        if len(_CONV_ENGINES) >= _CONV_ENGINES_MAX:      # (a trainer has ~60 distinct keys; a sweep over shapes must not pin HBM forever)
+            _CONV_ENGINES.pop(next(iter(_CONV_ENGINES)))
         eng = ConvLayer(w.detach(), stride=stride, padding=tuple(padding), dilation=tuple(dilation), transposed=transposed,
                         output_padding=output_padding, device=dev)
         _CONV_ENGINES[key] = eng
@@ -178,8 +181,14 @@ class _Conv2d(torch.autograd.Function):
         lav_dgrad = os.environ.get("LAV_TRAIN_DGRAD", "hip") != "torch" and (stride == 1 or os.environ.get("LAV_TRAIN_DGRAD_STRIDED", "hip") == "hip")
         if ctx.needs_input_grad[0] and lav_dgrad:
             kh, kw = w.shape[2], w.shape[3]
+            # the adjoint's output_padding = the rows / columns of x the strided forward never reached, PER DIMENSION; the transposed
+            # plan takes one value for both and requires it below the stride - anything else goes to torch
             oph = x.shape[2] - ((dy.shape[2] - 1) * stride - 2 * padding[0] + dilation[0] * (kh - 1) + 1)
-            dx = _conv_engine("dgrad", w, stride, padding, dilation, True, oph)(dy)
+            opw = x.shape[3] - ((dy.shape[3] - 1) * stride - 2 * padding[1] + dilation[1] * (kw - 1) + 1)
+            if oph == opw and 0 <= oph < max(stride, 1) and dy.numel() > 0:
+                dx = _conv_engine("dgrad", w, stride, padding, dilation, True, oph)(dy)
+                if dx.shape != x.shape:
+                    raise RuntimeError(f"convolution data gradient {tuple(dx.shape)} != input {tuple(x.shape)}")
         need_dx_torch = ctx.needs_input_grad[0] and dx is None
         dw_hip = None
         if ctx.needs_input_grad[1]:
@@ -212,7 +221,9 @@ def _wgrad_hip(x, dy, w, stride, padding, dilation):
     if (stride == 2 and kh == 3 and os.environ.get("LAV_TRAIN_WGRAD_STRIDED", "hip") == "torch") or (
             kh == 7 and os.environ.get("LAV_TRAIN_WGRAD_STEM", "hip") == "torch"):
         return None
-    dw = torch.empty_like(w)
+    if w.dtype != torch.float32 or not w.is_contiguous() or x.data_ptr() % 16 or dy.data_ptr() % 16:
+        return None     # (the kernel writes the dense [cout][cin][k][k] layout and loads 16-byte vectors)
+    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
     nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W, kh, stride)
     ws = ops_mod._workspace("conv_wgrad", nbytes, x.device)
     check(lib.lav_conv_wgrad(_ptr(x), _ptr(dy), B, cin, cout, H, W, kh, stride, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
@@ -227,8 +238,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding=(0, 0), di
         padding = (padding, padding)
     if isinstance(dilation, int):
         dilation = (dilation, dilation)
-    if (not x.is_cuda or x.dtype != torch.float32 or w.shape[2] < 3 or not torch.is_grad_enabled()
-            or os.environ.get("LAV_TRAIN_CONV", "hip") == "torch"):
+    if (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or w.shape[2] < 3 or not torch.is_grad_enabled()
+            or x.numel() == 0 or os.environ.get("LAV_TRAIN_CONV", "hip") == "torch"):
         return F.conv2d(x, w, None, stride, tuple(padding), tuple(dilation))
     return _Conv2d.apply(x, w, int(stride), tuple(padding), tuple(dilation))
 

@@ -75,9 +75,16 @@ class UniPlanner(DecoderMixin, _Engine):
     def _cast_modules(self):
         return self.cast_grus_ego, self.cast_mlps_ego
 
-    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96, map_index=None):
+    def crop_feature(self, features, rel_locs, rel_oris, pixels_per_meter=4, crop_size=96, map_index=None, amax=None):
         """map_index (int32, per crop): take crop i from features[map_index[i]] instead of features[i] - the training
-        forwards crop several vehicles out of each sample's map without materialising one copy of the map per vehicle."""
+        forwards crop several vehicles out of each sample's map without materialising one copy of the map per vehicle.
+        amax (eval): the ops.Amax of the feature map - a bilinear crop never exceeds the map's largest magnitude, so the crops carry
+        it on to the stem convolution (LAV_CONV_F16X3's scale, lav_conv2d_amax)."""
+        if amax is not None and not self.training and map_index is None:
+            ox, oy = self.offsets()
+            crops = crop_feature(features, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
+            crops._lav_amax = amax
+            return crops
         ox, oy = self.offsets()
         if map_index is not None and features.is_cuda and (_hip_train("CROP") or not self.training):   # HIP forward + backward (autograd.Function)
             return ops.crop_rotate_indexed(features, map_index, rel_locs, rel_oris, pixels_per_meter, crop_size, ox, oy)
@@ -168,7 +175,8 @@ class UniPlanner(DecoderMixin, _Engine):
         return plan, cast, oc, om
 
     @torch.no_grad()
-    def infer_all(self, features, det, cmd, nxp):
+    def infer_all(self, features, det, cmd, nxp, amax=None):
+        """amax: the feature map's ops.Amax when the backbone left one (InferModel hands it on)."""
         dev = features.device
         H, W = features.size(1) * 2, features.size(2) * 2
         locs, oris = self.others_from_detections(det, H, W)
@@ -177,12 +185,12 @@ class UniPlanner(DecoderMixin, _Engine):
         if N > 0:
             locs_t = torch.tensor(locs, dtype=torch.float32, device=dev)
             oris_t = torch.tensor(oris, dtype=torch.float32, device=dev)
-            crops = self.crop_feature(features.expand(N, *features.size()), locs_t, oris_t, ppm_f, self.crop_size)
+            crops = self.crop_feature(features.expand(N, *features.size()), locs_t, oris_t, ppm_f, self.crop_size, amax=amax)
             _, other_cast, other_cmds = self.embed_cast(crops, oris=oris_t, locs=locs_t, want_cmds=True)
         else:  # the reference returns CPU zeros here (model_inference.py:167-168) - keep
             other_cast = torch.zeros((0, self.num_cmds, self.num_plan, 2))
             other_cmds = torch.zeros((0, self.num_cmds))
-        ego_crop = self.crop_feature(features[None], features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, self.crop_size)
+        ego_crop = self.crop_feature(features[None], features.new_zeros((1, 2)), features.new_zeros((1,)), ppm_f, self.crop_size, amax=amax)
         ego_embd, ego_cast, _ = self.embed_cast(ego_crop)
         # only the commanded branch of the plan GRU is needed: branches never interact (uniplanner.py:264-275)
         ego_plan = self.plan(ego_embd, nxp[None], cast_locs=ego_cast, pixels_per_meter=self.pixels_per_meter,

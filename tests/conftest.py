@@ -12,9 +12,15 @@ if REPO not in sys.path:
 # gradients: the naive reference kernel).  Left in the default location those entries were picked up by the NEXT process on the box -
 # round 5 measured bench.py's train_full child at 634 ms per step instead of 128 after a full test session (7 launches of
 # naive_conv_..._wrw of 68 ms each per step).  The test session therefore keeps its MIOpen databases in a directory of its own.
+# One stable directory per purpose (a fresh mkdtemp per session piled up under /tmp and redid every search).
 if "MIOPEN_USER_DB_PATH" not in os.environ:
-    import tempfile
-    _miopen_dir = tempfile.mkdtemp(prefix="lav_tests_miopen_")
+    _miopen_dir = os.path.join(os.path.expanduser("~"), ".cache", "lav_amd", "miopen_tests")
+    try:
+        os.makedirs(_miopen_dir, exist_ok=True)
+    except OSError:
+        import tempfile
+        _miopen_dir = os.path.join(tempfile.gettempdir(), "lav_amd_miopen_tests")
+        os.makedirs(_miopen_dir, exist_ok=True)
     os.environ["MIOPEN_USER_DB_PATH"] = _miopen_dir
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _miopen_dir)
 

@@ -582,3 +582,110 @@ def test_tap_pair_stem_respects_the_batch_limit(monkeypatch):
         layer(x.to(DEV), out=out)
     torch.cuda.synchronize()
     assert torch.equal(out[:N], full[:N]) and (out[N:] == 7).all()
+
+
+F16_CASES = [
+    # name, B, cin, cout, k, stride, pad, transposed, out_pad, H, W, LAV_SPLIT_FORCE ("" = the plan search)
+    ("BEV 64->64 s1 160x160", 1, 64, 64, 3, 1, 1, False, 0, 160, 160, ""),
+    ("BEV 64->128 s2", 1, 64, 128, 3, 2, 1, False, 0, 160, 160, ""),
+    ("BEV 128->128 80x80", 1, 128, 128, 3, 1, 1, False, 0, 80, 80, ""),
+    ("brake 512->512 9x24 (split-K)", 1, 512, 512, 3, 1, 1, False, 0, 9, 24, ""),
+    ("up-convolution 4x4 s2 (four parity classes)", 1, 128, 128, 4, 2, 1, True, 0, 80, 80, ""),
+    ("up-convolution 4x4 s4 op2 (16 classes, one tap each)", 1, 128, 128, 4, 4, 1, True, 2, 40, 40, ""),
+    ("ragged channels 48->40, 2x2/w4 tile", 2, 48, 40, 3, 1, 1, False, 0, 37, 51, "2,2,4,-1,0,0,0,0"),
+    ("1x2/w2 tile, two taps per barrier, split-K 2", 1, 96, 64, 3, 1, 1, False, 0, 40, 56, "1,2,2,-1,2,2,0,0"),
+    ("7x7 s2 crop stem, tap pairs, 3 crops", 3, 384, 64, 7, 2, 3, False, 0, 96, 96, ""),
+    ("7x7 s2 stem 2x2 tile, tap pairs", 2, 64, 64, 7, 2, 3, False, 0, 96, 96, "2,2,4,16,1,0,0,1"),
+    ("5x5 s1 tap pairs with the odd tap out, split-K 2", 2, 48, 40, 5, 1, 2, False, 0, 20, 36, "1,2,4,16,4,2,0,1"),
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES, ids=[c[0] for c in F16_CASES])
+def test_f16x3_on_every_split_plan(case, monkeypatch):
+    """LAV_CONV_F16X3, round 6: every plan of the split kernel (strides, tiles, tap groups, split-K, tap pairs, the parity classes
+    of a transposed convolution) on two fp16 pieces and three products.  Inputs span five decades of magnitude; against float64
+    the error stays below 2e-6 of sum |w||x| - the bar the bf16x6 kernel is held to - through bias, ReLU and BatchNorm; the
+    maxima handed in by a producer give the same bits as the measuring launch; the maxima the launch leaves are those of its output."""
+    import ctypes
+    from lav_amd import _lib, ops
+    name, B, cin, cout, k, s_, p_, tr, op, H, W, force = case
+    if force:
+        monkeypatch.setenv("LAV_CONV_SPLIT", "2")
+        monkeypatch.setenv("LAV_SPLIT_FORCE", force)
+    g = np.random.Generator(np.random.PCG64(101))
+    x = torch.from_numpy((g.standard_normal((B, cin, H, W)) * np.exp(g.uniform(-8.0, 3.0, (B, cin, H, W)))).astype(np.float32))
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.from_numpy((g.standard_normal(wshape) * np.exp(g.uniform(-4.0, 1.0, wshape)) / np.sqrt(cin * k * k)).astype(np.float32))
+    bias = rnd((cout,), 103)
+    bn = (rnd((cout,), 104, 0.1), rnd((cout,), 105).abs() + 0.5, rnd((cout,), 106).abs() + 0.5, rnd((cout,), 107, 0.1))
+    xd, wd = x.to(DEV).double(), w.to(DEV).double()
+    conv = (lambda a, b: F.conv_transpose2d(a, b, None, s_, p_, op)) if tr else (lambda a, b: F.conv2d(a, b, None, s_, p_))
+    conv64, mag = conv(xd, wd), conv(xd.abs(), wd.abs())
+    kw = dict(stride=s_, padding=(p_, p_), transposed=tr, output_padding=op, device=DEV)
+    plain = ConvLayer(w, precision=_lib.CONV_F16X3, **kw)
+    d = _lib.Conv.from_buffer_copy(plain.desc); d.batch, d.h, d.w = B, H, W
+    info = (ctypes.c_int * 9)()
+    assert _lib.load().lav_conv_tile_info(ctypes.byref(d), info) == 0
+    assert info[0] == -1 and info[7] >= 200, f"expected an fp16 split plan, got {list(info)}"
+    assert plain.uses_amax(B, H, W)
+    y = plain(x.to(DEV))
+    err = ((y.double() - conv64).abs() / mag.clamp_min(1e-30)).max().item()
+    assert err < 2e-6, f"{name}: max |y - ref| / sum|w||x| = {err:.3e}"
+    assert torch.equal(y, plain(x.to(DEV))), "bit-reproducible"
+    # a producer's maxima (here: any parts whose maximum is max |x|) instead of the measuring launch: the same scale, the same bits
+    am_in = ops.Amax(DEV)
+    parts = am_in.take(7)
+    parts.zero_(); parts[3] = x.abs().max().item(); parts[5] = 1e-3
+    am_out = ops.Amax(DEV)
+    y2 = plain(x.to(DEV), amax_in=am_in, amax_out=am_out)
+    assert torch.equal(y, y2), "handed-in maxima must give the measuring launch's bits"
+    assert am_out.count >= 1 and am_out.buf[:am_out.count].max().item() == y.abs().max().item(), "amax_out: the largest |y|"
+    assert (am_out.buf[am_out.count:] == 0).all()
+    # epilogue: bias -> ReLU -> BatchNorm affine, into a channel window
+    layer = ConvLayer(w, bias=bias, bn=bn, bn_eps=1e-3, relu_pre=True, out_c_total=cout + 8, out_c_offset=8, precision=_lib.CONV_F16X3, **kw)
+    out = torch.full((B, cout + 8) + tuple(y.shape[2:]), 7.0, device=DEV)
+    am_out.reset()
+    layer(x.to(DEV), out=out, amax_out=am_out)
+    assert (out[:, :8] == 7).all()
+    ref = F.batch_norm(F.relu(conv64 + bias.to(DEV).double()[None, :, None, None]), bn[0].to(DEV).double(), bn[1].to(DEV).double(),
+                       bn[2].to(DEV).double(), bn[3].to(DEV).double(), False, 0., 1e-3)
+    gain = (bn[2].abs() / torch.sqrt(bn[1] + 1e-3)).to(DEV).double()[None, :, None, None]
+    excess = ((out[:, 8:].double() - ref).abs() - (2e-6 * mag * gain + 1e-5 * ref.abs() + 1e-6)).max().item()
+    assert excess <= 0, f"{name}: epilogue beyond 2e-6 of sum|w||x| (through the BatchNorm gain) by {excess:.3e}"
+    assert am_out.buf[:am_out.count].max().item() == out[:, 8:].abs().max().item()
+
+
+def test_amax_hand_off_from_every_kernel_family(monkeypatch):
+    """lav_conv2d_amax: whichever kernel runs the producing layer - split (whole K / split-K), direct (whole K / split-K), tiled
+    fp32, small-cin vector kernel - the maxima it leaves are those of its output, rows beyond lav_batch_limit leave zeros, and a
+    LAV_CONV_F16X3 consumer fed from them computes what it computes from a measurement of its own."""
+    from lav_amd import _lib, ops
+    shapes = [  # cin, cout, k, stride, H, W, B, precision
+        (64, 64, 3, 1, 160, 160, 1, _lib.CONV_BF16X6),     # split, whole K
+        (512, 512, 3, 1, 9, 24, 1, _lib.CONV_BF16X6),      # split, split-K
+        (128, 128, 3, 1, 40, 40, 1, _lib.CONV_BF16X6),     # direct
+        (256, 256, 3, 1, 6, 6, 4, _lib.CONV_BF16X6),       # direct, split-K
+        (64, 64, 3, 1, 72, 192, 1, _lib.CONV_F32),         # tiled fp32
+        (3, 64, 7, 2, 96, 160, 1, 0),                      # small-cin vector kernel
+    ]
+    for i, (cin, cout, k, s_, H, W, B, prec) in enumerate(shapes):
+        x = rnd((B, cin, H, W), 200 + i).to(DEV)
+        w = rnd((cout, cin, k, k), 300 + i, scale=1.0 / np.sqrt(cin * k * k))
+        layer = ConvLayer(w, stride=s_, padding=(k // 2, k // 2), relu_post=True, precision=prec, device=DEV)
+        am = ops.Amax(DEV)
+        y = layer(x, amax_out=am)
+        assert am.count >= 1
+        assert am.buf[:am.count].max().item() == y.abs().max().item(), f"shape {i}: maxima of |y|"
+        nxt = ConvLayer(rnd((32, cout, 3, 3), 400 + i, scale=0.05), padding=(1, 1), precision=_lib.CONV_F16X3, device=DEV)
+        if nxt.uses_amax(B, y.shape[2], y.shape[3]):
+            assert torch.equal(nxt(y, amax_in=am), nxt(y)), f"shape {i}: consumer on handed-in maxima"
+    # batch limit: the dead rows of a capacity-sized launch contribute nothing
+    x = rnd((6, 64, 24, 24), 501).to(DEV)
+    x[4:] *= 1e4
+    layer = ConvLayer(rnd((64, 64, 3, 3), 502, scale=0.05), padding=(1, 1), relu_post=True, device=DEV)
+    n_dev = torch.tensor([3], dtype=torch.int32, device=DEV)
+    am = ops.Amax(DEV)
+    out = torch.zeros((6, 64, 24, 24), device=DEV)
+    with ops.batch_limit(n_dev):
+        layer(x, out=out, amax_out=am)
+    assert am.buf[:am.count].max().item() == out[:3].abs().max().item()

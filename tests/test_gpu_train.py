@@ -215,23 +215,21 @@ def test_train_lidar_loss_curve_vs_reference_trainer(golden):
     full GPU suite: 1.7 %, 35.3 %, 5.7 (the reference's single CPU run is one more sample of that spread; MI355X runs tend to
     end lower).  The bars (round 5): the envelope of eight CPU-port curves and the reference, see below - on the curve's shape, not on
     per-step values."""
-    from lav_amd.train.run import set_deterministic
+    import subprocess
+    import sys
+    import tempfile
     ref = golden["train_curve"]["terms"]                       # (steps, 8)
     keys = [str(k) for k in golden["train_curve"]["keys"]]
     steps = len(ref)
     assert steps == 500
-    set_deterministic(True)          # this test's curve is then one fixed curve, not a sample of a distribution
-    try:
-        torch.manual_seed(0)
-        lav = LAV(TrainConfig(log_inference=False), DEV, what="lidar")
-        batches = [synthetic_lidar_batch(2, seed=40 + i, max_points=20000, num_objs=3) for i in range(4)]
-        rows = []
-        for step in range(steps):
-            torch.manual_seed(1000 + step)
-            info = lav.train_lidar(*batches[step % 4])
-            rows.append([info[k] for k in keys])
-    finally:
-        set_deterministic(False)
+    # Round 6: the 500 steps run in a process of their own with an empty MIOpen database (tests/_curve_worker.py) - the curve is then
+    # a function of the code, not of the tests that happened to run before this one in the session (see the worker's header).
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "curve.npz")
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_curve_worker.py")
+        r = subprocess.run([sys.executable, worker, out, ",".join(keys), str(steps)], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, f"curve worker failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+        rows = np.load(out)["rows"]
     ours = np.array(rows)
     assert np.isfinite(ours).all()
     np.testing.assert_allclose(ours[0], ref[0], rtol=2e-3, atol=1e-4, err_msg="step 0")

@@ -198,9 +198,13 @@ def test_frame_glue_oracle_matches_reference_agent(golden):
     np.testing.assert_array_equal(stacked[:, 3:4], ref[:, 3:4])          # intensity: untouched
     np.testing.assert_array_equal(stacked[:, 8:], ref[:, 8:])            # one-hot time
     np.testing.assert_allclose(stacked[:, :3], ref[:, :3], rtol=0, atol=2e-5)
-    # painted classes: identical except at pixel-boundary flips of the projection (sgemm association, see oracle/paint.py)
-    diff = np.abs(stacked[:, 4:8] - ref[:, 4:8]).max(1) > 1e-6
-    assert diff.mean() < 2e-3, f"{diff.sum()} of {len(diff)} painted rows differ"
+    # painted classes: identical except at pixel-boundary flips of the projection (sgemm association, see oracle/paint.py) - a flip
+    # samples another pixel (differences of 1e-2 .. 1) - and the last bits of the class probabilities themselves: ERFNet runs on
+    # torch's CPU convolutions here and where the fixture was generated, and oneDNN picks its kernels by the host CPU (round 6's build
+    # container: 142 of 49 149 rows beyond 1e-6, 15 beyond 1e-4, none beyond 1e-3; round 5's: 0.1 % beyond 1e-6)
+    d = np.abs(stacked[:, 4:8] - ref[:, 4:8]).max(1)
+    assert (d > 1e-3).mean() < 2e-3, f"{(d > 1e-3).sum()} of {len(d)} painted rows sample another pixel"
+    assert (d > 1e-5).mean() < 1e-2 and np.median(d) < 1e-6, f"class probabilities: {(d > 1e-5).sum()} of {len(d)} rows beyond 1e-5, median {np.median(d):.2e}"
 
 
 def test_camera_net_oracle_matches_reference(golden):
@@ -217,9 +221,11 @@ def test_camera_net_oracle_matches_reference(golden):
     wide = torch.tensor(np.concatenate(rgbs, axis=1)[None].copy()).permute(0, 3, 1, 2).float()
     tel_rgb = torch.tensor(tel[..., :3][..., ::-1][:-96][None].copy()).permute(0, 3, 1, 2).float()
     logits = ocam.seg_forward(seg, all_rgb)
-    np.testing.assert_array_equal(logits[:, :, ::4, ::4].numpy(), g["logits_s"])      # same torch ops, same weights: bit-identical
+    # same torch ops, same weights: bit-identical on the host CPU that generated the fixture; another CPU model runs other oneDNN
+    # kernels (round 6's build container: 7e-6 of the largest logit), so the bar is the accumulation noise of an fp32 convolution stack
+    np.testing.assert_allclose(logits[:, :, ::4, ::4].numpy(), g["logits_s"], rtol=0, atol=2e-5 * float(np.abs(g["logits_s"]).max()))
     st = ocam.brake_stages(bra, wide, tel_rgb)
-    np.testing.assert_array_equal(st["x1"][:, ::8].numpy(), g["bra_x1_s"])
+    np.testing.assert_allclose(st["x1"][:, ::8].numpy(), g["bra_x1_s"], rtol=0, atol=2e-5 * float(np.abs(g["bra_x1_s"]).max()))
     np.testing.assert_allclose(st["h1"].numpy(), g["bra_h1"], rtol=1e-5, atol=1e-5 * float(np.abs(g["bra_h1"]).max()))
     np.testing.assert_allclose(st["logit"].numpy(), g["bra_logit"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(st["pred_bra"].numpy(), g["pred_bra"], rtol=0, atol=1e-6)
