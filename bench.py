@@ -30,9 +30,10 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (same guide); the split convolution kernels run on these pipes
-DTYPE = ("f32 (convolution contractions: fp32 operands split exactly into three bf16 pieces, the six leading partial products on the "
-         "bf16 matrix cores, f32 accumulate - error of an fp32 dot product, DESIGN 4.3; the head convolution: two scaled fp16 pieces, three "
-         "products, same error level, LAV_HEADS_PRECISION=bf16x6 restores; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
+DTYPE = ("f32 (convolution contractions on the matrix cores with f32 accumulate at the error of an fp32 dot product, DESIGN 4.3: the layers on "
+         "the split-operand kernel - BEV backbone, heads, crop stems, the brake net's mid-size layers - as two power-of-two-scaled fp16 pieces "
+         "per fp32 operand and three partial products, ERFNet's pairs as three bf16 pieces and six products, the small layers on the fp32 MFMA; "
+         "LAV_INFER_PRECISION=bf16x6 restores round 5's bf16 pieces everywhere; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
 
 
 def build_pipeline(device, eager=False):
@@ -417,17 +418,23 @@ def main():
     def conv_micro(reps=50):
         """The frame's largest dense kernel in isolation: the fused 384->256 3x3 convolution of the four heads on the
         (1,384,160,160) feature map - MFMA-bound, fp32 matrix peak 157.3 TFLOP/s."""
+        from lav_amd import ops
         lm = pipe.infer_model.lidar_model
         feats = torch.randn((1, 384, 160, 160), device=device)
-        lm.heads(feats)
-        layer = lm._head_engine(lm.ALL_HEADS, device)["conv"]
+        with ops.precision(pipe.precision):     # the engine the frame's heads graph runs (round 6: LAV_CONV_F16X3 through ops.precision)
+            lm.heads(feats)
+            layer = lm._head_engine(lm.ALL_HEADS, device)["conv"]
+        # the scale of the activations as the frame hands it over: maxima left by the launches that wrote the feature map (here: one part
+        # holding the tensor's maximum) - round 5 timed the measuring launch with the convolution, the frame no longer has one
+        am = ops.Amax(device)
+        am.take(4)[0] = feats.abs().max()
         for _ in range(3):
-            layer(feats)
+            layer(feats, amax_in=am)
         torch.cuda.synchronize()
         lib.lav_profile_enable(reps + 8)
-        layer(feats); torch.cuda.synchronize(); lib.lav_profile_reset()
+        layer(feats, amax_in=am); torch.cuda.synchronize(); lib.lav_profile_reset()
         for _ in range(reps):
-            layer(feats)
+            layer(feats, amax_in=am)
         torch.cuda.synchronize()
         ms, n = read("conv2d")
         lib.lav_profile_enable(0)
@@ -459,7 +466,7 @@ def main():
             # ask for on this layer), three fp16 ones, with the launch that measures the activation scale inside the timed pair
             f16 = info[7] >= 200
             executed = (3.0 if f16 else 6.0) * flops
-            return dict(bound="mfma", kernel=("k_absmax_parts + k_conv_split_f16<2,2> heads 384->256 3x3 @160x160 (f16x3: two fp16 pieces per operand, three products)"
+            return dict(bound="mfma", kernel=("k_conv_split_f16<2,2> heads 384->256 3x3 @160x160 (f16x3: two fp16 pieces per operand, three products; activation scale from the producers' maxima)"
                                               if f16 else "k_conv_split<2,2> heads 384->256 3x3 @160x160 (bf16x6 split operands)"),
                         executed_per_algorithmic=3 if f16 else 6,
                         vendor_gemm_tflops=None if vend is None else round(vend, 1),

@@ -154,8 +154,30 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
     // reduces the absmax launch's per-workgroup maxima itself (a few hundred floats from L2: no LDS, no barrier)
     float inv_sx = 1.f, out_sx = 1.f, out_sw = 1.f;
     if (F16 && (wid < 4 || wid >= 6)) {   // (the weight waves need no scale)
+        // every load of the pass in flight at once: a loop of dependent-looking scalar loads paid one memory round trip per 64 parts
+        // (round 6, first version: 57 round trips for the feature map's 3648 parts - the head convolution got SLOWER)
         float m = 0.f;
-        for (int i = lane; i < a.f16_nparts; i += 64) m = fmaxf(m, a.f16_parts[i]);
+        const int n = a.f16_nparts;
+        int i0 = 0;
+        if ((reinterpret_cast<uintptr_t>(a.f16_parts) & 15) == 0) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(a.f16_parts);
+            const int n4 = n >> 2;
+            float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int j = lane; j < n4; j += 256) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p4[min(j + 64 * u, n4 - 1)];   // (clamped: a repeated part changes no maximum)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u].x = fmaxf(acc[u].x, v[u].x); acc[u].y = fmaxf(acc[u].y, v[u].y);
+                    acc[u].z = fmaxf(acc[u].z, v[u].z); acc[u].w = fmaxf(acc[u].w, v[u].w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fmaxf(acc[u].x, acc[u].y), fmaxf(acc[u].z, acc[u].w)));
+            i0 = n4 << 2;
+        }
+        for (int i = i0 + lane; i < n; i += 64) m = fmaxf(m, a.f16_parts[i]);
         m = fmaxf(wave_finite_absmax(m), finite_abs(a.pad_value));   // (out-of-image positions hold pad_value: it must fit the scale too)
         int e = 0;
         (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1): m / 2^(e - 15) in [16384, 32768)

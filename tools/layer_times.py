@@ -23,10 +23,10 @@ records = []
 orig = ops.ConvLayer.__call__
 
 
-def hooked(self, x, out=None, residual=None):
+def hooked(self, x, out=None, residual=None, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    y = orig(self, x, out=out, residual=residual)
+    y = orig(self, x, out=out, residual=residual, **kw)
     e1.record()
     records.append((self, tuple(x.shape), e0, e1))
     return y
@@ -64,7 +64,8 @@ with torch.no_grad():
     pbest = None
     for it in range(6):
         records.clear(); pairs.clear()
-        fn()
+        with ops.precision(pipe.precision):     # (the engines the frame runs: LAV_CONV_F16X3 unless LAV_INFER_PRECISION says otherwise)
+            fn()
         torch.cuda.synchronize()
         t = [r[2].elapsed_time(r[3]) * 1e3 for r in records]
         best = t if best is None else [min(a, b) for a, b in zip(best, t)]
