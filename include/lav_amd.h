@@ -262,7 +262,7 @@ typedef struct lav_conv {
                               three products: half the matrix instructions at 22 bits per operand - the error of the dot product
                               stays at the level of its fp32 accumulation.  The activations' magnitude comes from the launches that
                               wrote them (lav_conv2d_amax below) or, without that, from one measuring launch in front of the
-                              convolution.  lav_conv_repack does not support it (such layers are packed on the host) */
+                              convolution.  Re-packing on the device: lav_conv_repack_scratch (the weights' magnitude is measured first) */
 
 /* output spatial size of the convolution */
 int lav_conv_out_hw(const lav_conv *c, int *oh, int *ow);
@@ -281,6 +281,10 @@ int lav_conv_pack_weights(const lav_conv *c, const float *h_weight, float *h_pac
 size_t lav_conv_pack_map_ints(const lav_conv *c);
 int lav_conv_pack_map(const lav_conv *c, int *h_map);
 int lav_conv_repack(const lav_conv *c, const float *d_weight, const int *d_map, float *d_packed, void *stream);
+/* the same with 512 floats of device scratch (round 6): what a LAV_CONV_F16X3 layer needs - its fp16 section is scaled by the weights'
+ * largest magnitude, which is measured on the device first (lav_conv_repack refuses such a layer) */
+int lav_conv_repack_scratch(const lav_conv *c, const float *d_weight, const int *d_map, float *d_packed, float *d_parts, size_t parts_floats,
+                            void *stream);
 int lav_bn_fold(const float *mean, const float *var, const float *gamma, const float *beta, double eps, int n, float *scale,
                 float *shift, void *stream);
 /* introspection of the launch plan (host only, no device access): info[0..8] = { MP, MC, row-blocked tiles,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "lav_conv_pack_map_ints": (_Z, [C.POINTER(Conv)]),
     "lav_conv_pack_map": (_I, [C.POINTER(Conv), _P]),
     "lav_conv_repack": (_I, [C.POINTER(Conv), _P, _P, _P, _P]),
+    "lav_conv_repack_scratch": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _Z, _P]),
     "lav_bn_fold": (_I, [_P, _P, _P, _P, C.c_double, _I, _P, _P, _P]),
     "lav_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "lav_conv_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),

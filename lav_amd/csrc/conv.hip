@@ -1027,7 +1027,8 @@ extern "C" size_t lav_conv_pack_map_ints(const lav_conv *c) {
     Plan p;
     if (build_plan(*c, p)) return 0;
     if (!has_split_packing(resolve_precision(*c))) return p.wfloats;
-    return (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 6;   // one entry per fp32 slot, then one per bf16 triple
+    // one entry per fp32 slot, then one per bf16 triple, then (LAV_CONV_F16X3) one per fp16 pair
+    return (p.wfloats + 3) / 4 * 4 + split_weight_bytes(p) / 6 + (resolve_precision(*c) == LAV_CONV_F16X3 && f16x3_layer(*c, p) ? split_weight_bytes_f16(p) / 4 : 0);
 }
 
 extern "C" int lav_conv_pack_map(const lav_conv *c, int *h_map) {
@@ -1053,6 +1054,28 @@ extern "C" int lav_conv_pack_map(const lav_conv *c, int *h_map) {
             const float v = (bf(o[frag * 1536 + within]) + bf(o[frag * 1536 + 512 + within])) + bf(o[frag * 1536 + 1024 + within]);
             h_map[nf + j] = (int)v - 1;
         }
+        if (resolve_precision(*c) == LAV_CONV_F16X3 && f16x3_layer(*c, p)) {
+            // the fp16 section: pair j = (fragment j / 512, slot j % 512) in split_pack_weights_f16's order, enumerated directly (two
+            // fp16 pieces carry 22 bits: an index above 2^22 would not survive the round trip through the packer)
+            int *m16 = h_map + nf + ntrip;
+            const int nblk = p.cout_pad / 32, nchunks = p.cin_pad / 16;
+            size_t fr = 0;
+            for (int cls = 0; cls < p.nclasses; ++cls) {
+                const auto &t = p.taps[cls];
+                for (int blk = 0; blk < nblk; ++blk)
+                    for (size_t ti = 0; ti < t.size(); ++ti)
+                        for (int ch = 0; ch < nchunks; ++ch, ++fr)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int el = 0; el < 8; ++el) {
+                                    const int co = blk * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + el;
+                                    long src = -1;
+                                    if (co < c->cout && ci < c->cin)
+                                        src = c->transposed ? (((long)ci * c->cout + co) * c->kh + t[ti].ky) * c->kw + t[ti].kx
+                                                            : (((long)co * c->cin + ci) * c->kh + t[ti].ky) * c->kw + t[ti].kx;
+                                    m16[fr * 512 + lane * 8 + el] = (int)src;
+                                }
+            }
+        }
     }
     return LAV_OK;
 }
@@ -1077,6 +1100,35 @@ __global__ __launch_bounds__(256) void k_conv_repack(const float *__restrict__ w
     }
 }
 
+// LAV_CONV_F16X3 section on the device (round 6: a trainer's forward / data-gradient convolutions on fp16 pieces): the scale is the
+// power of two that puts the largest finite |w| (512 parts of launch_absmax_parts) into [16384, 32768) - split_pack_weights_f16's
+// rule - then pair j = fp16(w / s), fp16(w / s - first piece); block 0 leaves the scale behind the section.
+__global__ __launch_bounds__(256) void k_conv_repack_f16(const float *__restrict__ w, const int *__restrict__ map16, long npairs, const float *__restrict__ parts,
+                                                         int nparts, unsigned char *__restrict__ out16) {
+    __shared__ float s_m[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, parts[i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    int e = 0;
+    (void)frexpf(m, &e);
+    const float sw = ldexpf(1.f, m > 0.f ? max(e, -100) - 15 : 0), inv = 1.f / sw;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j < npairs) {
+        const int src = map16[j];
+        const float v = src >= 0 ? w[src] * inv : 0.f;
+        const _Float16 h0 = (_Float16)v, h1 = (_Float16)(v - (float)h0);
+        _Float16 *o = reinterpret_cast<_Float16 *>(out16);
+        const long frag = j >> 9, within = j & 511;
+        o[frag * 1024 + within] = h0;
+        o[frag * 1024 + 512 + within] = h1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float *>(out16 + npairs * 4) = sw;
+}
+
 __global__ __launch_bounds__(256) void k_bn_fold(const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ gamma,
                                                  const float *__restrict__ beta, double eps, int n, float *__restrict__ scale,
                                                  float *__restrict__ shift) {
@@ -1089,17 +1141,30 @@ __global__ __launch_bounds__(256) void k_bn_fold(const float *__restrict__ mean,
 }  // namespace
 
 extern "C" int lav_conv_repack(const lav_conv *c, const float *d_weight, const int *d_map, float *d_packed, void *stream) {
+    return lav_conv_repack_scratch(c, d_weight, d_map, d_packed, nullptr, 0, stream);
+}
+
+extern "C" int lav_conv_repack_scratch(const lav_conv *c, const float *d_weight, const int *d_map, float *d_packed, float *d_parts, size_t parts_floats,
+                                       void *stream) {
     LAV_REQUIRE(c && d_weight && d_map && d_packed, "lav_conv_repack: null");
     Plan p;
     int rc = build_plan(*c, p);
     if (rc) return rc;
-    // (LAV_CONV_F16X3: the fp16 section needs the weights' largest magnitude first - such layers are re-packed on the host,
-    //  lav_amd/ops.py:ConvLayer.refresh; the frame's layers never change)
-    LAV_REQUIRE(resolve_precision(*c) != LAV_CONV_F16X3, "lav_conv_repack: LAV_CONV_F16X3 layers are packed on the host");
     const bool split = has_split_packing(resolve_precision(*c));
     const long nf = split ? (long)((p.wfloats + 3) / 4 * 4) : (long)p.wfloats, ntrip = split ? (long)(split_weight_bytes(p) / 6) : 0;
-    hipLaunchKernelGGL(k_conv_repack, dim3((unsigned)((nf + ntrip + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_weight, d_map, nf,
-                       ntrip, d_packed);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_conv_repack, dim3((unsigned)((nf + ntrip + 255) / 256)), dim3(256), 0, st, d_weight, d_map, nf, ntrip, d_packed);
+    if (resolve_precision(*c) == LAV_CONV_F16X3 && f16x3_layer(*c, p)) {
+        // round 6: the fp16 section too - the weights' largest magnitude is measured on the device (512 parts, kept in the 2 KB behind
+        // the section's scale word: lav_conv_packed_weight_floats reserves them), then one gather launch splits w / s into pieces
+        LAV_REQUIRE(d_parts && parts_floats >= F16_PARTS, "lav_conv_repack: a LAV_CONV_F16X3 layer needs %d floats of scratch for the weights' maxima", F16_PARTS);
+        const long npairs = (long)(split_weight_bytes_f16(p) / 4);
+        const long nw = (long)c->cout * c->cin * c->kh * c->kw;
+        int rc2 = launch_absmax_parts(d_weight, 1, 1, 0, 1, nw, d_parts, nullptr, st);
+        if (rc2) return rc2;
+        unsigned char *out16 = reinterpret_cast<unsigned char *>(d_packed + nf) + split_weight_bytes(p);
+        hipLaunchKernelGGL(k_conv_repack_f16, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, d_weight, d_map + nf + ntrip, npairs, d_parts, F16_PARTS, out16);
+    }
     LAV_LAUNCH_CHECK();
     return LAV_OK;
 }

@@ -480,8 +480,6 @@ class ConvLayer:
         dev = self.w.device
         probe = Conv.from_buffer_copy(self.desc)
         probe.h, probe.w = 64, 64
-        if self.desc.precision == _lib.CONV_F16X3:
-            self._map = False    # the fp16 pieces need the weights' largest magnitude first: packed on the host (the frame's layers never change)
         if dev.type == "cuda" and w.device == dev and self._map is not False:
             if self._map is None:
                 n = lib.lav_conv_pack_map_ints(C.byref(probe))
@@ -492,7 +490,11 @@ class ConvLayer:
                     self._map = m.to(dev)
         if dev.type == "cuda" and w.device == dev and self._map is not False and self._map is not None:
             wd = w.detach().to(torch.float32).contiguous()
-            check(lib.lav_conv_repack(C.byref(probe), _ptr(wd), _ptr(self._map), _ptr(self.w), _stream()), "lav_conv_repack")
+            if self.desc.precision == _lib.CONV_F16X3:   # (the fp16 pieces are scaled by the weights' largest magnitude: measured into 512 floats of scratch)
+                sc = _workspace("conv_repack", 512 * 4, dev)
+                check(lib.lav_conv_repack_scratch(C.byref(probe), _ptr(wd), _ptr(self._map), _ptr(self.w), _ptr(sc), 512, _stream()), "lav_conv_repack_scratch")
+            else:
+                check(lib.lav_conv_repack(C.byref(probe), _ptr(wd), _ptr(self._map), _ptr(self.w), _stream()), "lav_conv_repack")
         else:
             packed = torch.empty(self.w.numel(), dtype=torch.float32)
             wh = w.detach().to("cpu", torch.float32).contiguous()

@@ -144,6 +144,17 @@ _CONV_ENGINES = {}
 _CONV_ENGINES_MAX = 256
 
 
+def train_precision() -> int:
+    """lav_conv.precision of the training graph's forward / data-gradient convolutions: LAV_TRAIN_PRECISION = f16x3 (round 6: every
+    split-kernel layer on two fp16 pieces per operand and three products - the batch-32 layers are matrix / power bound like the
+    frame's head convolution -, packed weights re-gathered AND re-scaled on the device per step, lav_conv_repack_scratch; the
+    activations' scale measured by one launch in front of each convolution) | bf16x6 (round 5) | default."""
+    return {"f16x3": _lib.CONV_F16X3, "bf16x6": _lib.CONV_BF16X6}.get(os.environ.get("LAV_TRAIN_PRECISION", _TRAIN_PRECISION_DEFAULT), 0)
+
+
+_TRAIN_PRECISION_DEFAULT = "bf16x6"
+
+
 def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding):
     """One ConvLayer per (role, geometry, device, stream): the packed buffer is overwritten by every refresh, which is safe because
     pack and launch are stream-ordered and nothing keeps the packed weights beyond its launch."""
@@ -151,12 +162,14 @@ def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding)
     dev = w.device
     key = (kind, tuple(w.shape), int(stride), tuple(padding), tuple(dilation), bool(transposed), int(output_padding), dev,
            torch.cuda.current_stream(dev).cuda_stream)
+    prec = train_precision()
+    key = key + (prec,)
     eng = _CONV_ENGINES.get(key)
     if eng is None:
         if len(_CONV_ENGINES) >= _CONV_ENGINES_MAX:      # (a trainer has ~60 distinct keys; a sweep over shapes must not pin HBM forever)
             _CONV_ENGINES.pop(next(iter(_CONV_ENGINES)))
         eng = ConvLayer(w.detach(), stride=stride, padding=tuple(padding), dilation=tuple(dilation), transposed=transposed,
-                        output_padding=output_padding, device=dev)
+                        output_padding=output_padding, precision=prec, device=dev)
         _CONV_ENGINES[key] = eng
     eng._src["weight"] = w.detach()
     eng.refresh()

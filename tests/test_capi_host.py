@@ -513,7 +513,14 @@ def test_f16x3_plan_and_packing():
     ref = w[blk * 32 + (lane & 31), ch * 16 + 8 * (lane >> 5) + el, tap // 3, tap % 3].astype(np.float64)
     # h0 carries 11 bits of w / s_w, h1 11 more of what is left - down to fp16's subnormal quantum 2^-24 (in units of s_w)
     assert (np.abs(rec - ref) <= np.abs(ref) * 2.0 ** -21 + sw * 2.0 ** -24).all()
-    assert lib.lav_conv_repack(C.byref(d3), None, None, None, None) != 0        # (null arguments are refused first; the mode is host-packed)
+    assert lib.lav_conv_repack(C.byref(d3), None, None, None, None) != 0        # (null arguments are refused)
+    # the index map of the fp16 section (what lav_conv_repack_scratch gathers with): one entry per fp16 pair, in the section's order
+    nm2, nm3 = lib.lav_conv_pack_map_ints(C.byref(d2)), lib.lav_conv_pack_map_ints(C.byref(d3))
+    assert nm3 == nm2 + nb16 // 4
+    m = np.zeros(nm3, np.int32)
+    assert lib.lav_conv_pack_map(C.byref(d3), m.ctypes.data) == 0
+    m16 = m[nm2:].reshape(8, 9, 24, 64, 8)
+    assert np.array_equal(w.reshape(-1)[m16].astype(np.float64), ref)
 
 
 def test_the_test_session_keeps_miopen_databases_to_itself():

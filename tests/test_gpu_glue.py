@@ -181,11 +181,13 @@ def test_split_operand_convolution_at_the_edges_of_the_fp32_range(monkeypatch):
     assert torch.equal(y[0][:, ~reach], run(_lib.CONV_BF16X6, clean)[0][:, ~reach])
 
 
-@pytest.mark.parametrize("prec", [_lib.CONV_F32, _lib.CONV_BF16X6])
+@pytest.mark.parametrize("prec", [_lib.CONV_F32, _lib.CONV_BF16X6, _lib.CONV_F16X3])
 @pytest.mark.parametrize("case", [(64, 128, 3, 2, False), (128, 64, 4, 2, True), (384, 256, 3, 1, False)])
 def test_conv_layer_refresh_repacks_on_the_device_bit_for_bit(case, prec):
     """ConvLayer.refresh (lav_conv_repack + lav_bn_fold: the trainer's per-step log inference re-packs its student this way)
-    after an in-place parameter update == a layer built anew from the updated parameters: packed weights, bias, BatchNorm affine."""
+    after an in-place parameter update == a layer built anew from the updated parameters: packed weights, bias, BatchNorm affine.
+    LAV_CONV_F16X3 (round 6, lav_conv_repack_scratch): the fp16 section too - its scale is the power of two of the UPDATED weights'
+    largest magnitude, measured on the device (the update below changes it)."""
     cin, cout, k, s, tr = case
     torch.manual_seed(8)
     w = torch.nn.Parameter(torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device=DEV) * 0.05)
@@ -195,6 +197,7 @@ def test_conv_layer_refresh_repacks_on_the_device_bit_for_bit(case, prec):
     layer = ops.ConvLayer(w, **kw)
     with torch.no_grad():
         w.add_(torch.randn_like(w) * 0.01); bias.mul_(1.1)
+        w.view(-1)[5] = 3.7            # (a new largest weight: the fp16 section's scale doubles at least once)
         for t in bn:
             t.add_(0.01)
     layer.refresh()
