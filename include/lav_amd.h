@@ -308,6 +308,8 @@ int lav_conv2d(const lav_conv *c, const float *x, const float *w_packed, const f
  * maxima of a tensor that x is a max-pooling, a crop or a bilinear resampling of); a LAV_CONV_F16X3 layer on the split kernel takes
  * its power-of-two scale from them instead of measuring x (other layers ignore them).  A bound that is too small would overflow
  * fp16 (Inf / NaN in y); one that is 2^k too large costs k of the 22 operand bits. */
+#define LAV_AMAX_PARTS 512   /* floats lav_absmax_parts writes */
+int lav_absmax_parts(const float *x, long n, float *parts, void *stream);   /* maxima of the finite |x[0 .. n)| in LAV_AMAX_PARTS parts: one launch */
 int lav_conv_amax_count(const lav_conv *c);
 int lav_conv2d_amax(const lav_conv *c, const float *x, const float *w_packed, const float *bias, const float *scale,
                     const float *shift, const float *residual, float *y, void *workspace, size_t workspace_bytes,
@@ -502,6 +504,12 @@ int lav_bn_train_backward(const float *x, const float *y, const float *dy, int b
 size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, int h, int w, int ksize, int stride);
 int lav_conv_wgrad(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, int ksize, int stride, float *dw,
                    void *workspace, size_t workspace_bytes, void *stream);
+/* the same on TWO fp16 pieces per operand and three partial products (round 6, the weight-gradient side of LAV_CONV_F16X3): amax_x /
+ * amax_dy (device, n_amax_* floats each) hold maxima of the finite |x| / |dy| in parts - lav_absmax_parts, or what lav_conv2d_amax
+ * left - from which every task takes the two power-of-two scales; NULL, NULL: lav_conv_wgrad's bf16x6 arithmetic. */
+int lav_conv_wgrad_amax(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, int ksize, int stride, float *dw,
+                        void *workspace, size_t workspace_bytes, const float *amax_x, int n_amax_x, const float *amax_dy, int n_amax_dy,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8. Two stacked 1-D convolutions in one launch - one half of ERFNet's non_bottleneck_1d block

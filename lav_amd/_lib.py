@@ -72,6 +72,8 @@ SIGNATURES = {
     "lav_bn_fold": (_I, [_P, _P, _P, _P, C.c_double, _I, _P, _P, _P]),
     "lav_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "lav_conv_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "lav_conv_wgrad_amax": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P, _I, _P, _I, _P]),
+    "lav_absmax_parts": (_I, [_P, C.c_long, _P, _P]),
     "lav_conv_tile_info": (_I, [C.POINTER(Conv), C.POINTER(_I)]),
     "lav_conv_workspace_bytes": (_Z, [C.POINTER(Conv)]),
     "lav_conv2d": (_I, [C.POINTER(Conv), _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -73,6 +73,52 @@ inline size_t lds_claim(size_t need, size_t static_bytes = 0, bool needs_two_per
     return need;                                                                          // three or more: left alone
 }
 
+// ---- LAV_CONV_F16X3's scale hand-off (conv_f16.hip, conv_wgrad.hip): maxima of the finite |values| of a tensor, in parts
+// the largest finite |v| of the wave's lanes, in every lane
+__device__ __forceinline__ float wave_finite_absmax(float m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+}
+__device__ __forceinline__ float finite_abs(float v) {
+    const float a = fabsf(v);
+    return a <= 3.4028235e38f ? a : 0.f;
+}
+// max over parts[0 .. n) in every lane of the wave.  Every load of the pass is in flight at once: a loop of dependent-looking scalar
+// loads paid one memory round trip per 64 parts (round 6, first version: 57 round trips for the feature map's 3648 parts - the head
+// convolution got SLOWER than with its measuring launch).
+__device__ __forceinline__ float parts_absmax(const float *__restrict__ parts, int n, int lane) {
+    float m = 0.f;
+    int i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(parts) & 15) == 0) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(parts);
+        const int n4 = n >> 2;
+        float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int j = lane; j < n4; j += 256) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p4[min(j + 64 * u, n4 - 1)];   // (clamped: a repeated part changes no maximum)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[u].x = fmaxf(acc[u].x, v[u].x); acc[u].y = fmaxf(acc[u].y, v[u].y);
+                acc[u].z = fmaxf(acc[u].z, v[u].z); acc[u].w = fmaxf(acc[u].w, v[u].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fmaxf(acc[u].x, acc[u].y), fmaxf(acc[u].z, acc[u].w)));
+        i0 = n4 << 2;
+    }
+    for (int i = i0 + lane; i < n; i += 64) m = fmaxf(m, parts[i]);
+    return wave_finite_absmax(m);
+}
+// the power of two that puts a tensor's largest finite magnitude m into [16384, 32768) - fp16 overflows at 65504; exponent floored at
+// -100 (a tensor whose largest value is below 2^-100 - or subnormal - would give a subnormal scale and an infinite reciprocal)
+__device__ __forceinline__ float f16_scale_of(float m) {
+    int e = 0;
+    (void)frexpf(m, &e);                           // m = f 2^e, f in [0.5, 1): m / 2^(e - 15) in [16384, 32768)
+    return ldexpf(1.f, m > 0.f ? max(e, -100) - 15 : 0);
+}
+
 #define LAV_HIP(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t lav_e_ = (expr);                                                                        \

@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_conv_repack_f16(const float *__restrict
         o[frag * 1024 + within] = h0;
         o[frag * 1024 + 512 + within] = h1;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float *>(out16 + npairs * 4) = sw;
+    if (blockIdx.x == 0 && threadIdx.x < 4) reinterpret_cast<float *>(out16 + npairs * 4)[threadIdx.x] = threadIdx.x == 0 ? sw : 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_bn_fold(const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ gamma,

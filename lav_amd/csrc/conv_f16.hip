@@ -104,3 +104,14 @@ int launch_split_f16(const void *split_args, size_t args_bytes, int mp, int mc, 
     return fail(LAV_EINVAL, "lav_conv2d: fp16 split tile %dx%d/%d not built", mp, mc, wpx);
 }
 }  // namespace lav
+
+// Maxima of the finite |x| of a contiguous tensor of n floats in LAV_AMAX_PARTS parts (the measuring launch of LAV_CONV_F16X3 as an
+// entry point of its own: a trainer measures an activation once per step and hands the parts to the forward convolution, the data
+// gradient and the weight gradient that read it - lav_conv2d_amax, lav_conv_wgrad_amax).
+extern "C" int lav_absmax_parts(const float *x, long n, float *parts, void *stream) {
+    LAV_REQUIRE(x && parts && n >= 1, "lav_absmax_parts: bad argument");
+    const int rc = lav::launch_absmax_parts(x, 1, 1, 0, 1, n, parts, nullptr, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}

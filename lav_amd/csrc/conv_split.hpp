@@ -152,7 +152,8 @@ inline void split_pack_weights_f16(const lav_conv &c, const Plan &p, const float
         });
         cls_off += t.size() * (size_t)nblk * nchunks * 2 * 512;
     }
-    memcpy(out + split_weight_bytes_f16(p), &sw, sizeof(float));
+    const float tail[4] = {sw, 0.f, 0.f, 0.f};   // (the scale and its 12 bytes of padding: the whole buffer is defined - device re-packs compare equal)
+    memcpy(out + split_weight_bytes_f16(p), tail, sizeof(tail));
 }
 
 inline unsigned short bf16_round(float x, float &rest) {

@@ -40,17 +40,6 @@ struct SplitArgs {
     int sync_off;                    // byte offset of two LDS words behind the tile buffers (the workgroup's maximum and its arrival count)
 };
 
-// the largest finite |v| of the wave's lanes, in every lane
-__device__ __forceinline__ float wave_finite_absmax(float m) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    return m;
-}
-__device__ __forceinline__ float finite_abs(float v) {
-    const float a = fabsf(v);
-    return a <= 3.4028235e38f ? a : 0.f;
-}
-
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -154,31 +143,8 @@ __device__ __forceinline__ void split_body(const SplitArgs &a, unsigned char *sm
     // reduces the absmax launch's per-workgroup maxima itself (a few hundred floats from L2: no LDS, no barrier)
     float inv_sx = 1.f, out_sx = 1.f, out_sw = 1.f;
     if (F16 && (wid < 4 || wid >= 6)) {   // (the weight waves need no scale)
-        // every load of the pass in flight at once: a loop of dependent-looking scalar loads paid one memory round trip per 64 parts
-        // (round 6, first version: 57 round trips for the feature map's 3648 parts - the head convolution got SLOWER)
-        float m = 0.f;
-        const int n = a.f16_nparts;
-        int i0 = 0;
-        if ((reinterpret_cast<uintptr_t>(a.f16_parts) & 15) == 0) {
-            const float4 *p4 = reinterpret_cast<const float4 *>(a.f16_parts);
-            const int n4 = n >> 2;
-            float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            for (int j = lane; j < n4; j += 256) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = p4[min(j + 64 * u, n4 - 1)];   // (clamped: a repeated part changes no maximum)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[u].x = fmaxf(acc[u].x, v[u].x); acc[u].y = fmaxf(acc[u].y, v[u].y);
-                    acc[u].z = fmaxf(acc[u].z, v[u].z); acc[u].w = fmaxf(acc[u].w, v[u].w);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fmaxf(acc[u].x, acc[u].y), fmaxf(acc[u].z, acc[u].w)));
-            i0 = n4 << 2;
-        }
-        for (int i = i0 + lane; i < n; i += 64) m = fmaxf(m, a.f16_parts[i]);
-        m = fmaxf(wave_finite_absmax(m), finite_abs(a.pad_value));   // (out-of-image positions hold pad_value: it must fit the scale too)
+        float m = parts_absmax(a.f16_parts, a.f16_nparts, lane);
+        m = fmaxf(m, finite_abs(a.pad_value));   // (out-of-image positions hold pad_value: it must fit the scale too)
         int e = 0;
         (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1): m / 2^(e - 15) in [16384, 32768)
         // (exponent floored at -100: a tensor whose largest value is below 2^-100 - or subnormal - would give a subnormal scale and an

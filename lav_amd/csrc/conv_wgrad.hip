@@ -27,6 +27,11 @@
 //               the same tile, step and accumulators; a step consumes input rows 2 oy - 1, 2 oy, 2 oy + 1, so the loaders stage TWO new
 //               input rows per step into a ring of six slots, and the three kx copies of a row are its odd columns from 2 ox - 1, its even
 //               columns, and its odd columns from 2 ox + 1 (the first and third out of the same loaded registers).  LDS 6 x 18 + 12 KB.
+//   fp16 pieces (round 6, template parameter F16; lav_conv_wgrad_amax): both operands as TWO fp16 pieces of x / s_x and dY / s_dY - the
+//               powers of two that put each tensor's largest finite magnitude into [16384, 32768), from maxima the caller hands in (the
+//               measurements the forward / data-gradient convolutions of the same step already made) - and the three leading partial
+//               products on v_mfma_f32_32x32x16_f16: half the matrix instructions, 2/3 of the LDS bytes, the partial sums multiplied back
+//               by s_x and s_dY when they are written.
 #include <cstdlib>
 #include <type_traits>
 
@@ -42,11 +47,12 @@ typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int T_CO = 64, T_CI = 64, PX = 16;            // tile of the weight gradient, pixels per step
-constexpr int ENTRY = 16;                               // bytes of one lane operand (8 bf16)
-constexpr int ROW_COPY = 3 * 2 * T_CI * ENTRY;          // one kx copy of an input row: [piece 3][k half 2][ci 64] entries = 6 KB
-constexpr int ROW_SLOT = 3 * ROW_COPY;                  // three kx copies = 18 KB
-constexpr int DY_BUF = 3 * 2 * T_CO * ENTRY;            // [piece 3][k half 2][co 64] = 6 KB
-constexpr int LDS_BYTES = 4 * ROW_SLOT + 2 * DY_BUF;    // 84 KB
+constexpr int ENTRY = 16;                               // bytes of one lane operand (8 bf16 / fp16)
+// sizes for NPC pieces per operand (3 bf16 / 2 fp16):
+constexpr int row_copy(int npc) { return npc * 2 * T_CI * ENTRY; }          // one kx copy of an input row: [piece][k half 2][ci 64] entries = 6 / 4 KB
+constexpr int row_slot(int npc) { return 3 * row_copy(npc); }               // three kx copies = 18 / 12 KB
+constexpr int dy_buf(int npc) { return npc * 2 * T_CO * ENTRY; }            // [piece][k half 2][co 64] = 6 / 4 KB
+constexpr int lds_bytes(int npc) { return 4 * row_slot(npc) + 2 * dy_buf(npc); }   // 84 / 56 KB
 constexpr int PF = 3;                                   // steps the loaders' global loads run ahead of their staging
 
 struct WgradArgs {
@@ -56,6 +62,9 @@ struct WgradArgs {
     int nseg;           // 16-pixel column segments of a row
     int rows_per_block, nblocks;   // a slice = (image, block of rows)
     int ntile_ci, ntiles;
+    // F16: maxima of the finite |x| / |dY| in parts (lav_conv2d_amax's hand-off, lav_absmax_parts)
+    const float *amax_x, *amax_dy;
+    int n_amax_x, n_amax_dy;
 };
 
 // x = q0 + q1 + q2 exactly (three bf16 pieces of two values at once; conv_split.hpp: split3_pair)
@@ -69,9 +78,52 @@ __device__ __forceinline__ void split3x2(float x0, float x1, unsigned &q0, unsig
     q2 = __builtin_bit_cast(unsigned, __builtin_convertvector(wg_f32x2{s0, s1}, wg_bf16x2));
 }
 
+typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// the pieces of two values (x0 in the low half): three bf16 pieces of x exactly, or two fp16 pieces of x * inv (conv_split_kernel.hpp: split2h_pair)
+template <bool F16>
+__device__ __forceinline__ void split_pair(float x0, float x1, float inv, unsigned (&q)[F16 ? 2 : 3]) {
+    if constexpr (F16) {
+        const float u0 = x0 * inv, u1 = x1 * inv;
+        const wg_f16x2 h0 = __builtin_convertvector(wg_f32x2{u0, u1}, wg_f16x2);
+        const wg_f32x2 f0 = __builtin_convertvector(h0, wg_f32x2);
+        const wg_f16x2 h1 = __builtin_convertvector(wg_f32x2{u0 - f0[0], u1 - f0[1]}, wg_f16x2);
+        q[0] = __builtin_bit_cast(unsigned, h0);
+        q[1] = __builtin_bit_cast(unsigned, h1);
+    } else {
+        split3x2(x0, x1, q[0], q[1], q[2]);
+    }
+}
+// acc += A . B over the operands' pieces: the six leading products of three bf16 pieces, or the three of two fp16 pieces
+template <bool F16>
+__device__ __forceinline__ void mma_pieces(f32x16 &acc, const u32x4 (&av)[F16 ? 2 : 3], const u32x4 (&bv)[F16 ? 2 : 3]) {
+    if constexpr (F16) {
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[PA[k]]), __builtin_bit_cast(f16x8, bv[PB[k]]), acc, 0, 0, 0);
+    } else {
+        constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc, 0, 0, 0);
+    }
+}
+// F16: the two operand scales of a task (every wave reads the parts itself)
+template <bool F16>
+__device__ __forceinline__ void task_scales(const WgradArgs &a, int lane, float &sx, float &sdy) {
+    sx = 1.f; sdy = 1.f;
+    if constexpr (F16) {
+        sx = f16_scale_of(parts_absmax(a.amax_x, a.n_amax_x, lane));
+        sdy = f16_scale_of(parts_absmax(a.amax_dy, a.n_amax_dy, lane));
+    }
+}
+
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <bool F16>
 __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
+    constexpr int NPC = F16 ? 2 : 3, ROW_COPY = row_copy(NPC), ROW_SLOT = row_slot(NPC), DY_BUF = dy_buf(NPC);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_x = smem, *s_dy = smem + 4 * ROW_SLOT;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,6 +138,9 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
     // a segment is walked as steps j = -2 .. nrows - 1: step j computes output row y_lo + j (j >= 0) while the loaders stage input row
     // y_lo + j + 2 and dY row y_lo + j + 1 for the steps that follow; j = -2, -1 only stage (rows y_lo - 1, y_lo and dY row y_lo)
     const int T = a.nseg * (nrows + 3), T_pad = (T + PF - 1) / PF * PF;   // iterations of the task; every role runs T_pad barriers
+    float sx, sdy;
+    task_scales<F16>(a, lane, sx, sdy);
+    const float inv_x = 1.f / sx, inv_dy = 1.f / sdy;   // (powers of two: exact)
     if (wid >= 4) {
         // ------------------------------------------------------------------------------------------------ loaders
         const int lt = tid - 256;   // 0 .. 255; two items per thread and step.  Loader wave lw = 0, 1: copy kx = 0 of the input row, then
@@ -128,24 +183,24 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
             }
             if (++i_j == nrows) { i_j = -3; ++i_seg; }
         };
-        // eight consecutive floats starting SH floats into the 12 loaded ones -> three 16-byte bf16 pieces at `dst` (piece stride ps)
-        auto emit = [&](auto SH_, const float4 (&v)[3], const bool (&ok)[3], unsigned char *dst, int ps) __attribute__((always_inline)) {
+        // eight consecutive floats starting SH floats into the 12 loaded ones -> the 16-byte pieces at `dst` (piece stride ps)
+        auto emit = [&](auto SH_, const float4 (&v)[3], const bool (&ok)[3], unsigned char *dst, int ps, float inv) __attribute__((always_inline)) {
             constexpr int SH = decltype(SH_)::value;
             float f[12];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 f[4 * q] = ok[q] ? v[q].x : 0.f; f[4 * q + 1] = ok[q] ? v[q].y : 0.f; f[4 * q + 2] = ok[q] ? v[q].z : 0.f; f[4 * q + 3] = ok[q] ? v[q].w : 0.f;
             }
-            u32x4 p0, p1, p2;
+            u32x4 pc[NPC];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                unsigned q0, q1, q2;
-                split3x2(f[SH + 2 * e], f[SH + 2 * e + 1], q0, q1, q2);
-                p0[e] = q0; p1[e] = q1; p2[e] = q2;
+                unsigned q[NPC];
+                split_pair<F16>(f[SH + 2 * e], f[SH + 2 * e + 1], inv, q);
+#pragma unroll
+                for (int p = 0; p < NPC; ++p) pc[p][e] = q[p];
             }
-            *reinterpret_cast<u32x4 *>(dst) = p0;
-            *reinterpret_cast<u32x4 *>(dst + ps) = p1;
-            *reinterpret_cast<u32x4 *>(dst + 2 * ps) = p2;
+#pragma unroll
+            for (int p = 0; p < NPC; ++p) *reinterpret_cast<u32x4 *>(dst + p * ps) = pc[p];
         };
         using std::integral_constant;
         auto stage = [&](const float4 (&va)[3], const float4 (&vb)[3], const bool (&oka)[3], const bool (&okb)[3]) __attribute__((always_inline)) {
@@ -153,10 +208,10 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
             const int slot = (j + 2 + 1) & 3;   // input row y_lo + j + 2 -> ring slot (relative row + 1) mod 4
             unsigned char *xd = s_x + slot * ROW_SLOT + (kh * T_CI + ch) * ENTRY;
             // the first item's window starts 3 floats into its aligned base for kx 0 (a0 = x0 - 4), 0 floats for kx 1
-            if (kx0 == 0) emit(integral_constant<int, 3>{}, va, oka, xd, 2 * T_CI * ENTRY);
-            else emit(integral_constant<int, 0>{}, va, oka, xd + ROW_COPY, 2 * T_CI * ENTRY);
-            if (second_is_x) emit(integral_constant<int, 1>{}, vb, okb, xd + 2 * ROW_COPY, 2 * T_CI * ENTRY);
-            else emit(integral_constant<int, 0>{}, vb, okb, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
+            if (kx0 == 0) emit(integral_constant<int, 3>{}, va, oka, xd, 2 * T_CI * ENTRY, inv_x);
+            else emit(integral_constant<int, 0>{}, va, oka, xd + ROW_COPY, 2 * T_CI * ENTRY, inv_x);
+            if (second_is_x) emit(integral_constant<int, 1>{}, vb, okb, xd + 2 * ROW_COPY, 2 * T_CI * ENTRY, inv_x);
+            else emit(integral_constant<int, 0>{}, vb, okb, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY, inv_dy);
             if (++s_j == nrows) s_j = -3;
         };
 #pragma unroll
@@ -183,22 +238,19 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
     int j = -3;
     for (int t = 0; t < T_pad; ++t) {
         if (j >= 0 && t < T) {
-            u32x4 av[3];
+            u32x4 av[NPC];
             const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+            for (int p = 0; p < NPC; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
                 const int ky = t9 / 3, kx = t9 - 3 * ky;
                 // input row y + ky - 1 = relative row j + ky - 1 -> slot (j + ky - 1 + 1) & 3
                 const unsigned char *pb = s_x + ((j + ky) & 3) * ROW_SLOT + kx * ROW_COPY + b_off;
-                u32x4 bv[3];
+                u32x4 bv[NPC];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
-                constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t9], 0, 0, 0);
+                for (int p = 0; p < NPC; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                mma_pieces<F16>(acc[t9], av, bv);
             }
         }
         barrier_lds();
@@ -211,31 +263,35 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = 32 * h + 8 * (i >> 2) + 4 * kgrp + (i & 3), ci = 32 * g + l31;
-            out[((long)t * T_CO + co) * T_CI + ci] = acc[t][i];
+            out[((long)t * T_CO + co) * T_CI + ci] = F16 ? (acc[t][i] * sx) * sdy : acc[t][i];
         }
 }
 
-// eight floats -> three 16-byte bf16 pieces at dst, dst + ps, dst + 2 ps
-__device__ __forceinline__ void emit8(const float (&f)[8], unsigned char *dst, int ps) {
-    u32x4 p0, p1, p2;
+// eight floats -> their 16-byte pieces at dst, dst + ps, ...
+template <bool F16>
+__device__ __forceinline__ void emit8(const float (&f)[8], unsigned char *dst, int ps, float inv) {
+    constexpr int NPC = F16 ? 2 : 3;
+    u32x4 pc[NPC];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        unsigned q0, q1, q2;
-        split3x2(f[2 * e], f[2 * e + 1], q0, q1, q2);
-        p0[e] = q0; p1[e] = q1; p2[e] = q2;
+        unsigned q[NPC];
+        split_pair<F16>(f[2 * e], f[2 * e + 1], inv, q);
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) pc[p][e] = q[p];
     }
-    *reinterpret_cast<u32x4 *>(dst) = p0;
-    *reinterpret_cast<u32x4 *>(dst + ps) = p1;
-    *reinterpret_cast<u32x4 *>(dst + 2 * ps) = p2;
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) *reinterpret_cast<u32x4 *>(dst + p * ps) = pc[p];
 }
 
 constexpr int S2_SLOTS = 6;
-constexpr int LDS_BYTES_S2 = S2_SLOTS * ROW_SLOT + 2 * DY_BUF;   // 120 KB
+constexpr int lds_bytes_s2(int npc) { return S2_SLOTS * row_slot(npc) + 2 * dy_buf(npc); }   // 120 / 80 KB
 
 // Stride 2.  a.H, a.W = the INPUT map (both even), the dY planes are (H/2) x (W/2); rows_per_block / nseg count OUTPUT rows / 16-pixel
 // segments of an output row.  Relative input row rr = input row - (2 y_lo - 1) lives in ring slot rr % 6; iteration j (-2 .. nrows - 1)
 // multiplies output row y_lo + j (j >= 0: slots 2j, 2j+1, 2j+2) while the loaders stage rr = 2j + 3, 2j + 4 and dY row y_lo + j + 1.
+template <bool F16>
 __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
+    constexpr int NPC = F16 ? 2 : 3, ROW_COPY = row_copy(NPC), ROW_SLOT = row_slot(NPC), DY_BUF = dy_buf(NPC);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_x = smem, *s_dy = smem + S2_SLOTS * ROW_SLOT;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -250,6 +306,9 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
     const int nrows = y_hi - y_lo;
     const int r_base = 2 * y_lo - 1;   // input row of rr = 0
     const int T = a.nseg * (nrows + 2), T_pad = (T + PF - 1) / PF * PF;
+    float sx, sdy;
+    task_scales<F16>(a, lane, sx, sdy);
+    const float inv_x = 1.f / sx, inv_dy = 1.f / sdy;
     if (wid >= 4) {
         // ------------------------------------------------------------------------------------------------ loaders
         // entry (ch, kh) = 8 output pixels x0 .. x0 + 7 of channel ch = input columns c0 + (kx - 1) + 2 e, c0 = 2 x0 (a multiple of 16).
@@ -309,15 +368,15 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
                 if (odd_role) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fl[2 * e + 1];
-                    emit8(f, xd + 2 * ROW_COPY, ps);                           // kx = 2: columns c0 + 1 + 2 e
+                    emit8<F16>(f, xd + 2 * ROW_COPY, ps, inv_x);                // kx = 2: columns c0 + 1 + 2 e
 #pragma unroll
                     for (int e = 7; e > 0; --e) f[e] = f[e - 1];
                     f[0] = okr[i] && okh && okc[0] ? halo[i] : 0.f;            // kx = 0: columns c0 - 1 + 2 e
-                    emit8(f, xd, ps);
+                    emit8<F16>(f, xd, ps, inv_x);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fl[2 * e];
-                    emit8(f, xd + ROW_COPY, ps);                               // kx = 1: columns c0 + 2 e
+                    emit8<F16>(f, xd + ROW_COPY, ps, inv_x);                    // kx = 1: columns c0 + 2 e
                 }
             }
             if (!odd_role) {
@@ -326,7 +385,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
                 for (int q = 0; q < 2; ++q) {
                     f[4 * q] = okdq[q] ? vd[q].x : 0.f; f[4 * q + 1] = okdq[q] ? vd[q].y : 0.f; f[4 * q + 2] = okdq[q] ? vd[q].z : 0.f; f[4 * q + 3] = okdq[q] ? vd[q].w : 0.f;
                 }
-                emit8(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
+                emit8<F16>(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY, inv_dy);
             }
             s_base = s_base == 4 ? 0 : s_base + 2;
             if (++s_j == nrows) { s_j = -2; s_base = 2; }
@@ -355,23 +414,20 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
     int j = -2, base = 2;
     for (int t = 0; t < T_pad; ++t) {
         if (j >= 0 && t < T) {
-            u32x4 av[3];
+            u32x4 av[NPC];
             const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+            for (int p = 0; p < NPC; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
                 const int ky = t9 / 3, kx = t9 - 3 * ky;
                 int slot = base + ky;
                 slot = slot >= S2_SLOTS ? slot - S2_SLOTS : slot;
                 const unsigned char *pb = s_x + slot * ROW_SLOT + kx * ROW_COPY + b_off;
-                u32x4 bv[3];
+                u32x4 bv[NPC];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
-                constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[t9], 0, 0, 0);
+                for (int p = 0; p < NPC; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                mma_pieces<F16>(acc[t9], av, bv);
             }
         }
         barrier_lds();
@@ -384,7 +440,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = 32 * h + 8 * (i >> 2) + 4 * kgrp + (i & 3), ci = 32 * g + l31;
-            out[((long)t * T_CO + co) * T_CI + ci] = acc[t][i];
+            out[((long)t * T_CO + co) * T_CI + ci] = F16 ? (acc[t][i] * sx) * sdy : acc[t][i];
         }
 }
 
@@ -394,10 +450,12 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_s2(WgradArgs a) {
 // aligned copies (copy kx = columns 2 ox + kx - 3), double buffered: LDS 2 x 42 + 12 KB.  The four copies of the even kx are
 // shifts of the row's odd columns and the three of the odd kx shifts of its even columns, so a loader thread splits every value into
 // its three bf16 pieces ONCE per pairing (10 or 9 pair conversions for 4 or 3 copies) and only re-packs.
-constexpr int K7_ROW = 7 * ROW_COPY;                         // 42 KB
-constexpr int LDS_BYTES_K7 = 2 * K7_ROW + 2 * DY_BUF;        // 96 KB
+constexpr int k7_row(int npc) { return 7 * row_copy(npc); }                          // 42 / 28 KB
+constexpr int lds_bytes_k7(int npc) { return 2 * k7_row(npc) + 2 * dy_buf(npc); }    // 96 / 64 KB
 
+template <bool F16>
 __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
+    constexpr int NPC = F16 ? 2 : 3, ROW_COPY = row_copy(NPC), DY_BUF = dy_buf(NPC), K7_ROW = k7_row(NPC);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_x = smem, *s_dy = smem + 2 * K7_ROW;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,6 +471,9 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
     // iteration j = -1 .. nrows - 1: the compute waves multiply output row y_lo + j out of buffer j & 1 while the loaders stage row
     // y_lo + j + 1 (its input row and its dY row) into the other one
     const int T = a.nseg * (nrows + 1), T_pad = (T + PF - 1) / PF * PF;
+    float sx, sdy;
+    task_scales<F16>(a, lane, sx, sdy);
+    const float inv_x = 1.f / sx, inv_dy = 1.f / sdy;
     if (wid >= 4) {
         // ------------------------------------------------------------------------------------------------ loaders
         // entry (ch, kh) = 8 output pixels from x0 = 16 seg + 8 kh; fl[i] = input column c0 - 4 + i, c0 = 2 x0; copy kx holds
@@ -461,17 +522,17 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
             auto copies = [&](auto ODD_) __attribute__((always_inline)) {
                 constexpr bool ODD = decltype(ODD_)::value;
                 constexpr int b = ODD ? 1 : 2, NT = ODD ? 4 : 3;
-                unsigned pe[5][3], po[5][3];
+                unsigned pe[5][NPC], po[5][NPC];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    split3x2(fl[b + 4 * i], fl[b + 4 * i + 2], pe[i][0], pe[i][1], pe[i][2]);
-                    if (ODD || i < 4) split3x2(fl[b + 4 * i + 2], fl[b + 4 * i + 4], po[i][0], po[i][1], po[i][2]);
+                    split_pair<F16>(fl[b + 4 * i], fl[b + 4 * i + 2], inv_x, pe[i]);
+                    if (ODD || i < 4) split_pair<F16>(fl[b + 4 * i + 2], fl[b + 4 * i + 4], inv_x, po[i]);
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     unsigned char *dst = xd + (ODD ? 2 * t : 2 * t + 1) * ROW_COPY;
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) {
+                    for (int pc = 0; pc < NPC; ++pc) {
                         u32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (t & 1) ? po[e + (t >> 1)][pc] : pe[e + (t >> 1)][pc];
@@ -487,7 +548,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
                 for (int q = 0; q < 2; ++q) {
                     f[4 * q] = okdq[q] ? vd[q].x : 0.f; f[4 * q + 1] = okdq[q] ? vd[q].y : 0.f; f[4 * q + 2] = okdq[q] ? vd[q].z : 0.f; f[4 * q + 3] = okdq[q] ? vd[q].w : 0.f;
                 }
-                emit8(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY);
+                emit8<F16>(f, s_dy + ((j + 1) & 1) * DY_BUF + (kh * T_CO + ch) * ENTRY, 2 * T_CO * ENTRY, inv_dy);
             }
             if (++s_j == nrows) s_j = -1;
         };
@@ -515,20 +576,17 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
     int j = -1;
     for (int t = 0; t < T_pad; ++t) {
         if (j >= 0 && t < T) {
-            u32x4 av[3];
+            u32x4 av[NPC];
             const unsigned char *pa = s_dy + (j & 1) * DY_BUF + a_off;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
+            for (int p = 0; p < NPC; ++p) av[p] = *reinterpret_cast<const u32x4 *>(pa + p * 2 * T_CO * ENTRY);
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
                 const unsigned char *pb = s_x + (j & 1) * K7_ROW + kx * ROW_COPY + b_off;
-                u32x4 bv[3];
+                u32x4 bv[NPC];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
-                constexpr int PA[6] = {0, 0, 1, 0, 1, 2}, PB[6] = {0, 1, 0, 2, 1, 0};
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA[k]]), __builtin_bit_cast(bf16x8, bv[PB[k]]), acc[kx], 0, 0, 0);
+                for (int p = 0; p < NPC; ++p) bv[p] = *reinterpret_cast<const u32x4 *>(pb + p * 2 * T_CI * ENTRY);
+                mma_pieces<F16>(acc[kx], av, bv);
             }
         }
         barrier_lds();
@@ -540,7 +598,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_k7(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = 32 * h + 8 * (i >> 2) + 4 * kgrp + (i & 3), ci = 32 * g + l31;
-            out[((long)t * T_CO + co) * T_CI + ci] = acc[t][i];
+            out[((long)t * T_CO + co) * T_CI + ci] = F16 ? (acc[t][i] * sx) * sdy : acc[t][i];
         }
 }
 
@@ -601,7 +659,15 @@ extern "C" size_t lav_conv_wgrad_workspace_bytes(int batch, int cin, int cout, i
 
 extern "C" int lav_conv_wgrad(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, int ksize, int stride, float *dw,
                               void *workspace, size_t workspace_bytes, void *stream) {
+    return lav_conv_wgrad_amax(x, dy, batch, cin, cout, h, w, ksize, stride, dw, workspace, workspace_bytes, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int lav_conv_wgrad_amax(const float *x, const float *dy, int batch, int cin, int cout, int h, int w, int ksize, int stride, float *dw,
+                                   void *workspace, size_t workspace_bytes, const float *amax_x, int n_amax_x, const float *amax_dy, int n_amax_dy,
+                                   void *stream) {
     LAV_REQUIRE(x && dy && dw, "lav_conv_wgrad: null argument");
+    LAV_REQUIRE((amax_x == nullptr) == (amax_dy == nullptr) && (!amax_x || (n_amax_x >= 1 && n_amax_dy >= 1)), "lav_conv_wgrad_amax: the maxima of x and dY come together");
+    const bool f16 = amax_x != nullptr;
     LAV_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 7 && stride == 2), "lav_conv_wgrad: %dx%d kernel of stride %d (3x3 of stride 1 / 2, 7x7 of stride 2)", ksize, ksize, stride);
     LAV_REQUIRE(batch >= 1 && h >= 1 && w >= 4 && w % 4 == 0, "lav_conv_wgrad: batch %d, map %dx%d (rows of whole 16-byte pieces)", batch, h, w);
     LAV_REQUIRE(stride == 1 || (h % 2 == 0 && w % 8 == 0), "lav_conv_wgrad: stride 2 takes even heights and widths that are multiples of 8 (%dx%d)", h, w);
@@ -612,9 +678,12 @@ extern "C" int lav_conv_wgrad(const float *x, const float *dy, int batch, int ci
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr = false;
     if (!attr) {
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_s2), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_S2));
-        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_k7), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_K7));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(3)));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_s2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_s2(3)));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_k7<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_k7(3)));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2)));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_s2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_s2(2)));
+        LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_wgrad_k7<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_k7(2)));
         attr = true;
     }
     const int oh = h / stride, ow = w / stride;
@@ -625,12 +694,19 @@ extern "C" int lav_conv_wgrad(const float *x, const float *dy, int batch, int ci
     a.nblocks = wgrad_blocks_of(batch, cin, cout, h, w, ksize, stride);
     a.rows_per_block = (oh + a.nblocks - 1) / a.nblocks;
     a.ntile_ci = cin / T_CI; a.ntiles = a.ntile_ci * (cout / T_CO);
+    a.amax_x = amax_x; a.amax_dy = amax_dy; a.n_amax_x = n_amax_x; a.n_amax_dy = n_amax_dy;
     const int nslices = batch * a.nblocks;
     LAV_REQUIRE(nslices <= 65535, "lav_conv_wgrad: %d slices", nslices);
     const int tok = timer_begin("conv_wgrad", st);
-    if (ksize == 7) hipLaunchKernelGGL(k_conv_wgrad_k7, dim3(a.ntiles * 7, nslices), dim3(512), LDS_BYTES_K7, st, a);
-    else if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad, dim3(a.ntiles, nslices), dim3(512), LDS_BYTES, st, a);
-    else hipLaunchKernelGGL(k_conv_wgrad_s2, dim3(a.ntiles, nslices), dim3(512), LDS_BYTES_S2, st, a);
+    if (f16) {
+        if (ksize == 7) hipLaunchKernelGGL(k_conv_wgrad_k7<true>, dim3(a.ntiles * 7, nslices), dim3(512), lds_bytes_k7(2), st, a);
+        else if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(a.ntiles, nslices), dim3(512), lds_bytes(2), st, a);
+        else hipLaunchKernelGGL(k_conv_wgrad_s2<true>, dim3(a.ntiles, nslices), dim3(512), lds_bytes_s2(2), st, a);
+    } else {
+        if (ksize == 7) hipLaunchKernelGGL(k_conv_wgrad_k7<false>, dim3(a.ntiles * 7, nslices), dim3(512), lds_bytes_k7(3), st, a);
+        else if (stride == 1) hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(a.ntiles, nslices), dim3(512), lds_bytes(3), st, a);
+        else hipLaunchKernelGGL(k_conv_wgrad_s2<false>, dim3(a.ntiles, nslices), dim3(512), lds_bytes_s2(3), st, a);
+    }
     const int ntaps = ksize * ksize;
     const long total = (long)a.ntiles * ntaps * T_CO * T_CI;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.partial, nslices, a.ntiles, a.ntile_ci, cin, cout, ntaps, dw);

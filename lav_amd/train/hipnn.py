@@ -176,12 +176,24 @@ def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding)
     return eng
 
 
+def _measure(t: torch.Tensor):
+    """ops.Amax holding the maxima of the finite |t| (one launch, 512 parts): LAV_CONV_F16X3's activation scale, measured ONCE per
+    tensor and step and handed to every kernel that reads the tensor (forward convolution + weight gradient for x, data gradient +
+    weight gradient for dy) instead of once per launch."""
+    am = ops_mod.Amax(t.device, capacity=512)
+    check(_lib.load().lav_absmax_parts(_ptr(t), t.numel(), _ptr(am.take(512)), _stream()), "lav_absmax_parts")
+    return am
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, padding, dilation):
         x = x.contiguous()
-        y = _conv_engine("fwd", w, stride, padding, dilation, False, 0)(x)
+        eng = _conv_engine("fwd", w, stride, padding, dilation, False, 0)
+        am_x = _measure(x) if train_precision() == _lib.CONV_F16X3 and eng.uses_amax(*x.shape[:1], *x.shape[2:]) else None
+        y = eng(x, amax_in=am_x)
         ctx.save_for_backward(x, w)
+        ctx.am_x = am_x
         ctx.cfg = (stride, padding, dilation)
         return y
 
@@ -191,6 +203,7 @@ class _Conv2d(torch.autograd.Function):
         stride, padding, dilation = ctx.cfg
         dy = dy.contiguous()
         dx = dw = None
+        am_dy = _measure(dy) if train_precision() == _lib.CONV_F16X3 and dy.numel() > 0 else None
         lav_dgrad = os.environ.get("LAV_TRAIN_DGRAD", "hip") != "torch" and (stride == 1 or os.environ.get("LAV_TRAIN_DGRAD_STRIDED", "hip") == "hip")
         if ctx.needs_input_grad[0] and lav_dgrad:
             kh, kw = w.shape[2], w.shape[3]
@@ -199,13 +212,13 @@ class _Conv2d(torch.autograd.Function):
             oph = x.shape[2] - ((dy.shape[2] - 1) * stride - 2 * padding[0] + dilation[0] * (kh - 1) + 1)
             opw = x.shape[3] - ((dy.shape[3] - 1) * stride - 2 * padding[1] + dilation[1] * (kw - 1) + 1)
             if oph == opw and 0 <= oph < max(stride, 1) and dy.numel() > 0:
-                dx = _conv_engine("dgrad", w, stride, padding, dilation, True, oph)(dy)
+                dx = _conv_engine("dgrad", w, stride, padding, dilation, True, oph)(dy, amax_in=am_dy)
                 if dx.shape != x.shape:
                     raise RuntimeError(f"convolution data gradient {tuple(dx.shape)} != input {tuple(x.shape)}")
         need_dx_torch = ctx.needs_input_grad[0] and dx is None
         dw_hip = None
         if ctx.needs_input_grad[1]:
-            dw_hip = _wgrad_hip(x, dy, w, stride, padding, dilation)
+            dw_hip = _wgrad_hip(x, dy, w, stride, padding, dilation, ctx.am_x if ctx.am_x is not None and am_dy is not None else None, am_dy)
         if need_dx_torch or (ctx.needs_input_grad[1] and dw_hip is None):
             gi, gw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], list(padding), list(dilation), False, [0, 0], 1,
                                                             [need_dx_torch, ctx.needs_input_grad[1] and dw_hip is None, False])
@@ -218,8 +231,9 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def _wgrad_hip(x, dy, w, stride, padding, dilation):
-    """Weight gradient on lav_conv_wgrad where the kernel applies, else None."""
+def _wgrad_hip(x, dy, w, stride, padding, dilation, am_x=None, am_dy=None):
+    """Weight gradient on lav_conv_wgrad where the kernel applies, else None.  am_x, am_dy (ops.Amax of x and dy, both or neither):
+    the fp16 two-piece kernels (lav_conv_wgrad_amax)."""
     lib = _lib.load()
     if os.environ.get("LAV_TRAIN_WGRAD", "hip") == "torch" or not hasattr(lib, "lav_conv_wgrad"):
         return None
@@ -239,7 +253,11 @@ def _wgrad_hip(x, dy, w, stride, padding, dilation):
     dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
     nbytes = lib.lav_conv_wgrad_workspace_bytes(B, cin, cout, H, W, kh, stride)
     ws = ops_mod._workspace("conv_wgrad", nbytes, x.device)
-    check(lib.lav_conv_wgrad(_ptr(x), _ptr(dy), B, cin, cout, H, W, kh, stride, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
+    if am_x is not None and am_dy is not None and os.environ.get("LAV_TRAIN_WGRAD_F16", "1") != "0":
+        check(lib.lav_conv_wgrad_amax(_ptr(x), _ptr(dy), B, cin, cout, H, W, kh, stride, _ptr(dw), _ptr(ws), ws.numel(),
+                                      _ptr(am_x.buf), am_x.count, _ptr(am_dy.buf), am_dy.count, _stream()), "lav_conv_wgrad_amax")
+    else:
+        check(lib.lav_conv_wgrad(_ptr(x), _ptr(dy), B, cin, cout, H, W, kh, stride, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "lav_conv_wgrad")
     ops_mod.train_work["conv_wgrad_flops"] = ops_mod.train_work.get("conv_wgrad_flops", 0) + 2 * B * dy.shape[2] * dy.shape[3] * cin * cout * kh * kw
     return dw
 

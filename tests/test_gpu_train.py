@@ -565,20 +565,45 @@ def test_conv_wgrad_vs_float64(B, cin, cout, H, W, S, KS):
     assert torch.equal(outs[0], outs[1]), "the weight gradient must be bit-reproducible"
     err = ((outs[0].double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
     assert err < 2e-6, f"max |dw - ref| / sum|dy||x| = {err:.3e}"
+    # round 6: the same gradient on two fp16 pieces per operand (lav_conv_wgrad_amax) from measured maxima - operands spanning five
+    # decades of magnitude, the same bar
+    gn = np.random.Generator(np.random.PCG64(B * 77 + cin + W))
+    x5 = torch.from_numpy((gn.standard_normal(tuple(x.shape)) * np.exp(gn.uniform(-8.0, 3.0, tuple(x.shape)))).astype(np.float32))
+    dy5 = torch.from_numpy((gn.standard_normal(tuple(dy.shape)) * np.exp(gn.uniform(-9.0, 2.0, tuple(dy.shape)))).astype(np.float32))
+    ref5 = torch.nn.grad.conv2d_weight(x5.double(), (cout, cin, KS, KS), dy5.double(), stride=S, padding=KS // 2)
+    mag5 = torch.nn.grad.conv2d_weight(x5.double().abs(), (cout, cin, KS, KS), dy5.double().abs(), stride=S, padding=KS // 2)
+    x5d, dy5d = x5.to(DEV), dy5.to(DEV)
+    ax, ay = torch.zeros(512, device=DEV), torch.zeros(512, device=DEV)
+    check(lib.lav_absmax_parts(_ptr(x5d), x5d.numel(), _ptr(ax), _stream()), "lav_absmax_parts")
+    check(lib.lav_absmax_parts(_ptr(dy5d), dy5d.numel(), _ptr(ay), _stream()), "lav_absmax_parts")
+    assert ax.max().item() == x5.abs().max().item() and ay.max().item() == dy5.abs().max().item()
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, cin, KS, KS), float("nan"), device=DEV)
+        check(lib.lav_conv_wgrad_amax(_ptr(x5d), _ptr(dy5d), B, cin, cout, H, W, KS, S, _ptr(dw), _ptr(ws), ws.numel(), _ptr(ax), 512, _ptr(ay), 512,
+                                      _stream()), "lav_conv_wgrad_amax")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1]), "the fp16-piece weight gradient must be bit-reproducible"
+    err = ((outs[0].double() - ref5).abs() / mag5.clamp_min(1e-30)).max().item()
+    assert err < 2e-6, f"f16x3: max |dw - ref| / sum|dy||x| = {err:.3e}"
     assert lib.lav_conv_wgrad_workspace_bytes(1, 48, 64, 8, 8, 3, 1) == 0       # 48 input channels: not a multiple of 64
     assert lib.lav_conv_wgrad_workspace_bytes(1, 64, 64, 8, 12, 3, 2) == 0      # stride 2: the width must be a multiple of 8
     assert lib.lav_conv_wgrad_workspace_bytes(1, 64, 64, 8, 8, 3, 3) == 0
     assert lib.lav_conv_wgrad_workspace_bytes(1, 64, 64, 8, 8, 7, 1) == 0       # 7x7: stride 2 only
 
 
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
 @pytest.mark.parametrize("B,cin,cout,k,s,H,W", [(2, 64, 64, 3, 1, 24, 32), (2, 64, 128, 3, 2, 20, 24), (3, 16, 64, 7, 2, 30, 30), (2, 128, 128, 3, 1, 12, 12),
                                                  (2, 64, 64, 7, 2, 96, 96), (2, 64, 64, 3, 2, 80, 96)])
-def test_training_convolution_function_vs_torch(B, cin, cout, k, s, H, W):
-    """lav_amd.train.hipnn.conv2d - forward on lav_conv2d over the live parameter (device-side repack), data gradient on the adjoint
+def test_training_convolution_function_vs_torch(B, cin, cout, k, s, H, W, monkeypatch, prec):
+    """(prec: LAV_TRAIN_PRECISION - round 5's three bf16 pieces, or round 6's two fp16 pieces with the activations' maxima measured
+    once per tensor and handed to forward / data gradient / weight gradient.)
+    lav_amd.train.hipnn.conv2d - forward on lav_conv2d over the live parameter (device-side repack), data gradient on the adjoint
     lav_conv2d plan (the transposed convolution with the same weights, strides 1 and 2), weight gradient on lav_conv_wgrad where it applies - against torch's own
     convolution and its autograd, values and all gradients within 1e-4 of the largest reference value; a second call after the weight
     changed in place must see the new weights (the packed buffer is re-gathered on every forward)."""
     from lav_amd.train.hipnn import conv2d
+    monkeypatch.setenv("LAV_TRAIN_PRECISION", prec)
     torch.manual_seed(B + cin + k)
     x = torch.randn((B, cin, H, W), device=DEV, requires_grad=True)
     w = (torch.randn((cout, cin, k, k), device=DEV) / (cin * k * k) ** 0.5).requires_grad_(True)
