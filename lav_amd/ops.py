@@ -388,9 +388,9 @@ class Amax:
     `take(n)` hands out the next n slots (the same addresses on every pass over the same layers: HIP graphs may hold them)."""
     CAPACITY = 20480
 
-    def __init__(self, device, capacity: Optional[int] = None):
+    def __init__(self, device, capacity: Optional[int] = None, zeroed: bool = True):
         self.CAPACITY = int(capacity) if capacity else Amax.CAPACITY
-        self.buf = torch.zeros(self.CAPACITY, dtype=torch.float32, device=device)
+        self.buf = (torch.zeros if zeroed else torch.empty)(self.CAPACITY, dtype=torch.float32, device=device)
         self.count = 0
 
     def reset(self):

@@ -180,7 +180,7 @@ def _measure(t: torch.Tensor):
     """ops.Amax holding the maxima of the finite |t| (one launch, 512 parts): LAV_CONV_F16X3's activation scale, measured ONCE per
     tensor and step and handed to every kernel that reads the tensor (forward convolution + weight gradient for x, data gradient +
     weight gradient for dy) instead of once per launch."""
-    am = ops_mod.Amax(t.device, capacity=512)
+    am = ops_mod.Amax(t.device, capacity=512, zeroed=False)      # (the launch writes all 512 parts: no fill kernel per measurement)
     check(_lib.load().lav_absmax_parts(_ptr(t), t.numel(), _ptr(am.take(512)), _stream()), "lav_absmax_parts")
     return am
 
