@@ -183,14 +183,20 @@ def train_bench(args):
                         note="a step of these GRUs is a 192..400 x 512 x 1536 GEMM: latency-bound, not matrix-bound; the convolutions of the "
                              "step run on MIOpen (BatchNorm + ReLU: the fused lav_bn_train_* pairs): this is the roofline of the largest HAND-WRITTEN kernel of the step, not of the step")
     if rank == 0 and roofline is not None and hk and "conv_wgrad" in hk["kernels"] and hk["work_per_step"].get("conv_wgrad_flops"):
-        # round 5: the 3x3 stride-1 weight gradients of the BEV backbone and the fused heads convolution on lav_conv_wgrad (bf16x6:
-        # six bf16 matrix products per fp32 product, so the executed rate against the dense bf16 peak is 6x the algorithmic one)
+        # the 3x3 / 7x7 weight gradients on lav_conv_wgrad: round 5 bf16x6 (six bf16 matrix products per fp32 product), round 6 - train_full's
+        # default - f16x3 (three fp16 ones): the executed rate against the dense 16-bit peak is 6x / 3x the algorithmic one
+        from lav_amd.train import hipnn
+        from lav_amd import _lib as _l
+        with hipnn.use_precision(cfg.conv_precision or ("f16x3" if what == "lidar" else "bf16x6")):
+            nprod = 3 if hipnn.train_precision() == _l.CONV_F16X3 else 6
         k = hk["kernels"]["conv_wgrad"]
         tf = hk["work_per_step"]["conv_wgrad_flops"] / (k["ms_per_step"] * 1e-3) / 1e12
-        roofline["conv_wgrad"] = dict(bound="mfma", achieved=round(6 * tf, 1), peak=2500.0, unit="TFLOP/s (bf16, executed = 6 x algorithmic)", frac=round(6 * tf / 2500.0, 4),
+        roofline["conv_wgrad"] = dict(bound="mfma", achieved=round(nprod * tf, 1), peak=2500.0, unit=f"TFLOP/s (16-bit MFMA, executed = {nprod} x algorithmic)",
+                                      frac=round(nprod * tf / 2500.0, 4), executed_per_algorithmic=nprod,
                                       fp32_equivalent_tflops=round(tf, 1), ms_per_step=round(k["ms_per_step"], 3), launches_per_step=round(k["calls_per_step"], 1))
-        roofline["note"] = ("round 5: the 3x3 / 7x7 convolutions' forward and stride-1 data gradients are lav_conv2d launches, the large 3x3 weight gradients "
-                            "lav_conv_wgrad; transposed / 1x1 / stride-2-adjoint / small-map weight-gradient convolutions stay on MIOpen")
+        roofline["note"] = ("the 3x3 / 7x7 convolutions' forward and data gradients are lav_conv2d launches, their weight gradients lav_conv_wgrad (round 6, train_full: "
+                            "all three on two fp16 pieces per operand, every activation / gradient tensor measured once per step); transposed / 1x1 / small-map "
+                            "weight-gradient convolutions stay on MIOpen")
     if rank == 0 and roofline is not None and hk and "bn_train_fwd" in hk["kernels"]:
         # the fused train-mode BatchNorm + ReLU (+ residual) pairs (lav_bn_train_*): HBM bound, algorithmic bytes = passes over the activation
         for d in ("fwd", "bwd"):
@@ -201,7 +207,9 @@ def train_bench(args):
     if rank == 0:
         print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
-                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32 (convolutions: torch autograd / MIOpen; BatchNorm+ReLU, pillar, crop, GRU: liblav_amd)", data="synthetic",
+                              higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=("f32 (3x3 / 7x7 convolutions forward / data gradient / weight gradient: liblav_amd on the 16-bit matrix cores with fp32 operands split into "
+                                     + ("two scaled fp16 pieces, three products" if what == "lidar" and not os.environ.get("LAV_TRAIN_PRECISION", "").startswith("bf16") else "three bf16 pieces, six products")
+                                     + ", f32 accumulate; transposed / 1x1 convolutions: MIOpen f32; BatchNorm+ReLU, pillar, crop, GRU: liblav_amd f32)"), data="synthetic",
                               config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
                                           + (f", 120000-point clouds, 320x320 maps; log-only eval inference every {args.log_every} step(s)"
                                              if what == "lidar" else ", (9,320,320) BEV"),

@@ -70,8 +70,11 @@ def filter_cars(ego_locs, locs, typs):
 def random_sample(binaries, size):
     """Keep at most `size` set entries per row, chosen uniformly (bev_planner_v2.py:286-299; same RNG calls)."""
     cut = torch.zeros_like(binaries)
+    counts = binaries.sum(1).tolist()      # (ONE device->host copy for the rows' counts; the reference pays a sync per row)
+    if max(counts, default=0) <= size:
+        return binaries.clone()
     for i in range(binaries.size(0)):
-        if binaries[i].sum() <= size:
+        if counts[i] <= size:
             cut[i] = binaries[i]
         else:
             nz = torch.nonzero(binaries[i]).squeeze(1)

@@ -144,15 +144,35 @@ _CONV_ENGINES = {}
 _CONV_ENGINES_MAX = 256
 
 
+_train_precision_stack = []
+
+
 def train_precision() -> int:
-    """lav_conv.precision of the training graph's forward / data-gradient convolutions: LAV_TRAIN_PRECISION = f16x3 (round 6: every
-    split-kernel layer on two fp16 pieces per operand and three products - the batch-32 layers are matrix / power bound like the
-    frame's head convolution -, packed weights re-gathered AND re-scaled on the device per step, lav_conv_repack_scratch; the
-    activations' scale measured by one launch in front of each convolution) | bf16x6 (round 5) | default."""
-    return {"f16x3": _lib.CONV_F16X3, "bf16x6": _lib.CONV_BF16X6}.get(os.environ.get("LAV_TRAIN_PRECISION", _TRAIN_PRECISION_DEFAULT), 0)
+    """lav_conv.precision of the training graph's forward / data-gradient / weight-gradient convolutions: the environment's
+    LAV_TRAIN_PRECISION if set, else the innermost `use_precision(...)` (the trainers: LAV.train_lidar asks for f16x3, LAV.train_bev for
+    bf16x6), else bf16x6.
+      f16x3 (round 6)  every split-kernel layer and the weight-gradient kernels on two fp16 pieces per operand and three products -
+                       the batch-32 layers are matrix / power bound like the frame's head convolution -, packed weights re-gathered AND
+                       re-scaled on the device per step (lav_conv_repack_scratch), every activation and gradient tensor measured once
+                       per step (lav_absmax_parts) for the kernels that read it: train_full 132 -> 118 ms per step
+      bf16x6 (round 5) three bf16 pieces, six products."""
+    name = os.environ.get("LAV_TRAIN_PRECISION") or (_train_precision_stack[-1] if _train_precision_stack else "bf16x6")
+    return {"f16x3": _lib.CONV_F16X3, "bf16x6": _lib.CONV_BF16X6}.get(name, 0)
 
 
-_TRAIN_PRECISION_DEFAULT = "bf16x6"
+class use_precision:
+    """with use_precision("f16x3"): ... around a training step (forward AND backward)."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        _train_precision_stack.append(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _train_precision_stack.pop()
+        return False
 
 
 def _conv_engine(kind, w, stride, padding, dilation, transposed, output_padding):

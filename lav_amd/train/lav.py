@@ -51,6 +51,7 @@ class TrainConfig:
     distill: bool = True
     lr: float = 3e-4
     perceive_only: bool = False
+    conv_precision: str = ""      # "" = the trainer's default (train_lidar: f16x3, train_bev: bf16x6); LAV_TRAIN_PRECISION overrides
     motion_only: bool = False
     log_inference: bool = True     # the reference runs one eval-mode inference of sample 0 per step, for its logs only
     log_every: int = 100           # (lav_final_v2.py:228-236; logged every --num-per-log = 100 steps): here it runs on those steps
@@ -165,10 +166,12 @@ class LAV:
             other_weight = 0.
         bev, ego_locs, nxps = bev.float().to(d), ego_locs.float().to(d), nxps.float().to(d)
         cmds, idxs = cmds.long().to(d), (1 - bras).bool().to(d)
-        out = self.bev_ddp(bev, ego_locs, locs.float().to(d), oris.float().to(d), nxps, typs.to(d))
-        loss, terms = bev_losses(out, ego_locs, cmds, idxs, cfg, self.branch_weights, other_weight)
-        self.bev_optim.zero_grad()
-        loss.backward()
+        from .hipnn import use_precision
+        with use_precision(cfg.conv_precision or "bf16x6"):   # (train_bev is launch bound on the host: the fp16 pieces' extra launches cost what they save)
+            out = self.bev_ddp(bev, ego_locs, locs.float().to(d), oris.float().to(d), nxps, typs.to(d))
+            loss, terms = bev_losses(out, ego_locs, cmds, idxs, cfg, self.branch_weights, other_weight)
+            self.bev_optim.zero_grad()
+            loss.backward()
         self.bev_optim.step()
         return _scalars(loss, terms)
 
@@ -180,11 +183,14 @@ class LAV:
         bev = bev.float().to(d)
         cmds, idxs = cmds.long().to(d), (1 - bras).bool().to(d)
         self.bev_planner.eval()
-        lidar_out, uni_out = self.student_ddp(lidars, num_points, bev, ego_locs, locs, oris, nxps, typs)
-        loss, terms = lidar_losses(self.det_criterion, lidar_out, uni_out, heatmaps, sizemaps, orimaps, bev[:, [0, 1, 2]],
-                                   self.seg_mask, ego_locs, cmds, idxs, cfg, self.branch_weights)
-        self.lidar_optim.zero_grad()
-        loss.backward()
+        from .hipnn import use_precision
+        # round 6: the step's convolutions (forward, data gradient, weight gradient) on two fp16 pieces per operand (hipnn.train_precision)
+        with use_precision(cfg.conv_precision or "f16x3"):
+            lidar_out, uni_out = self.student_ddp(lidars, num_points, bev, ego_locs, locs, oris, nxps, typs)
+            loss, terms = lidar_losses(self.det_criterion, lidar_out, uni_out, heatmaps, sizemaps, orimaps, bev[:, [0, 1, 2]],
+                                       self.seg_mask, ego_locs, cmds, idxs, cfg, self.branch_weights)
+            self.lidar_optim.zero_grad()
+            loss.backward()
         self.lidar_optim.step()
         info = _scalars(loss, terms)
         # The inference below only feeds the visualisation log.  It needs the inference engines re-packed from the
