@@ -222,21 +222,41 @@ def train_bench(args):
         dist.destroy_process_group()
 
 
-def training_lines(with_cpu=True):
+def training_lines(with_cpu=True, world=1, rank=0):
     """BASELINE metric (ii) inside the default run: train_full_v2 (global batch 32) and train_bev_v2 (global batch 64), 3 warm-up +
     5 timed steps each at the reference's cadence (--log-every 1), as child processes (a fresh CUDA context each: the
     training graph's allocator state must not sit beside the frame's HIP graphs), each with its roofline and a bounded
-    cpu_baseline."""
+    cpu_baseline.
+    world > 1 (round 6: `bench.py --gpus N` under torch.distributed.run, the driver's scaling runs): EVERY rank calls this and
+    starts its own child with its RANK / LOCAL_RANK / WORLD_SIZE; the N children form a process group of their own on
+    MASTER_PORT + 1 / + 2 and run the data-parallel step at BASELINE's GLOBAL batch (32 / N resp. 64 / N samples per GPU, one
+    bucketed RCCL all-reduce per step) - `training.train_full.value` over the driver's N = 1, 2, 4, 8 lines is the scaling curve of
+    north_star's ">= 6x at 8 GPUs".  Rank 0's child prints the line."""
     import subprocess
     out = {}
-    for mode in ("train_full", "train_bev"):
+    for k, mode in enumerate(("train_full", "train_bev")):
         cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", "5", "--warmup", "3", "--log-every", "1"]
-        if with_cpu:
+        if with_cpu and world == 1:
             cmd.append("--cpu-train-baseline")
+        env = dict(os.environ)
+        if world > 1:
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1 + k)
+            # (torch.distributed.run tells its workers to use the AGENT's store at MASTER_PORT; the children rendezvous on a port of
+            # their own, where rank 0 must host the store itself - with the agent's variables inherited they wait for ever)
+            for name in [n for n in env if n.startswith("TORCHELASTIC_")]:
+                env.pop(name)
+            d = os.path.join(os.path.expanduser("~"), ".cache", "lav_amd", f"miopen_bench_rank{rank}")   # (ranks do not share a find database)
+            try:
+                os.makedirs(d, exist_ok=True)
+                env.setdefault("MIOPEN_USER_DB_PATH", d); env.setdefault("MIOPEN_CUSTOM_CACHE_DIR", d)
+            except OSError:
+                pass
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-            out[mode] = json.loads(line)
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                               timeout=float(os.environ.get("LAV_BENCH_TRAIN_TIMEOUT", "420")))
+            if rank == 0:
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                out[mode] = json.loads(line)
         except Exception as e:   # a failed training line must not take the inference line with it
             out[mode] = dict(error=f"{type(e).__name__}: {e}"[:300])
     return out
@@ -297,13 +317,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the LAV hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if world > 1:
+        # (RCCL; LAV_DIST_BACKEND=gloo lets the ranks of a test share one GPU - lav_amd/train/run.py)
+        from lav_amd.train.run import setup_distributed
+        _, _, device = setup_distributed()
+        local = device.index
+    else:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
 
     from lav_amd import _lib
     lib = _lib.load()
@@ -703,6 +726,14 @@ def main():
         except Exception as e:   # never lose the headline line to the variant
             return dict(error=repr(e)[:200])
 
+    training = None
+    if world > 1 and not args.no_train:
+        # the data-parallel training lines of this N: every rank runs a child; this process's group and frame memory go first
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        torch.cuda.empty_cache()
+        training = training_lines(with_cpu=False, world=world, rank=rank)
     if rank == 0:
         res = dict(metric="frames/s full agent fwd (32k-pt LiDAR + 3 cams)", value=round(world * args.steps / dt, 2),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=n_warm,
@@ -734,6 +765,8 @@ def main():
             res["frame_fp32_kernels"] = f32_frame()
         if world == 1 and not args.no_train:
             res["training"] = training_lines(with_cpu=not args.no_cpu_baseline)
+        elif training is not None:
+            res["training"] = training
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sds, host)
         else:
@@ -741,7 +774,8 @@ def main():
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

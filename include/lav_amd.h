@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 25
+#define LAV_ABI_VERSION 26
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -93,6 +93,16 @@ int lav_pillar_scatter(const float *points, const int *h_num_points, int batch, 
                        const lav_grid *grid, const lav_pointnet *net, float *canvas,
                        int *unique_coords, int *inverse, int *counts,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The same call leaving a BOUND of the canvas for the layer that reads it (round 6): amax_parts[0 .. lav_pillar_amax_count(batch, grid))
+ * receives, per workgroup of the canvas kernel, the largest finite value its PointNet produced (>= every value it wrote; the
+ * canvas holds ReLU outputs, so this bounds |canvas|).  LAV_CONV_F16X3 layers take their activation scale from such parts
+ * (lav_conv2d_amax) instead of measuring their input with a launch of their own: ConvBackbone's first convolution,
+ * team_code_v2/models/lidar.py:57.  amax_parts NULL = lav_pillar_scatter. */
+int lav_pillar_amax_count(int batch, const lav_grid *grid);
+int lav_pillar_scatter_amax(const float *points, const int *h_num_points, int batch, int max_points, int D,
+                            const lav_grid *grid, const lav_pointnet *net, float *canvas,
+                            int *unique_coords, int *inverse, int *counts, float *amax_parts,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Point painting: LiDAR->camera projection + semantic gather for up to 4 cameras.

@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 MAX_CAM = 4
 
 
@@ -53,6 +53,9 @@ SIGNATURES = {
     "lav_pillar_decorate_workspace_bytes": (_Z, [_I, _I, C.POINTER(Grid)]),
     "lav_pillar_scatter": (_I, [_P, C.POINTER(_I), _I, _I, _I, C.POINTER(Grid), C.POINTER(PointNet), _P, _P, _P, _P,
                                 _P, _Z, _P]),
+    "lav_pillar_amax_count": (_I, [_I, C.POINTER(Grid)]),
+    "lav_pillar_scatter_amax": (_I, [_P, C.POINTER(_I), _I, _I, _I, C.POINTER(Grid), C.POINTER(PointNet), _P, _P, _P, _P, _P,
+                                     _P, _Z, _P]),
     "lav_paint": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, C.POINTER(Camera), _P, _P, _P]),
     "lav_gru_cast": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_gru_cast_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),

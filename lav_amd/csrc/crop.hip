@@ -150,25 +150,31 @@ __global__ __launch_bounds__(256, 3) void k_crop_rotate_staged(const float *__re
     const int c_lo = blockIdx.y * FWD_CPB, nch = min(FWD_CPB, C - c_lo);
     const float *f = feat + ((long)m * C + c_lo) * plane;
     float *o_ = out + ((long)n * C + c_lo) * cc + (long)y * crop + x;
-    const int l32 = tid & 31;
+    // Staging (round 6).  Thread (c = tid / 32, column = tid % 32) fetches column `column` of channel c's box: at most 32 rows, ALL
+    // requested before the first one is used, from clamped addresses (a load under an exec-mask branch is waited for inside the
+    // branch).  The first version walked the box in seven batches of four loads, each batch a dependent L2 round trip: 5 us of
+    // latency per eight channels, which is what the kernel's 86 us for seven crops were.  The next eight channels are requested
+    // before this group's samples are computed, so their round trip runs under the LDS reads and the output stores.
+    const int l32 = tid & 31, sc = tid >> 5;
+    if (bh > 32) __builtin_trap();   // (crop_fwd_staged_ok: the box of a 16 x 16 tile is at most 28 x 28)
+    const float *fcol = f + (long)by0 * W + bx0 + min(l32, bw - 1);
+    float stg[32];
+    auto request = [&](int cs0) __attribute__((always_inline)) {
+        const int nsub = min(FWD_SUB, nch - cs0);
+        const float *src = fcol + (long)(cs0 + min(sc, nsub - 1)) * plane;
+#pragma unroll
+        for (int yy = 0; yy < 32; ++yy) stg[yy] = src[(long)min(yy, bh - 1) * W];
+    };
+    request(0);
     for (int cs0 = 0; cs0 < nch; cs0 += FWD_SUB) {
-        const int nsub = min(FWD_SUB, nch - cs0), rows = nsub * bh;
-        const float *fs = f + (long)cs0 * plane + (long)by0 * W + bx0 + l32;
-        for (int r0 = tid >> 5; r0 < rows; r0 += 32) {
-            float v[4];
-            int dst[4];
+        const int nsub = min(FWD_SUB, nch - cs0);
+        if (sc < nsub && l32 < bw) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + 8 * u, c = r / bh, yy = r - c * bh;
-                const bool ok = r < rows && l32 < bw;
-                dst[u] = ok ? c * FWD_CAP + yy * bw + l32 : -1;
-                v[u] = ok ? fs[(long)c * plane + (long)yy * W] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) (&s_f[0][0])[dst[u]] = v[u];
+            for (int yy = 0; yy < 32; ++yy)
+                if (yy < bh) s_f[sc][yy * bw + l32] = stg[yy];
         }
         __syncthreads();
+        if (cs0 + FWD_SUB < nch) request(cs0 + FWD_SUB);
         if (live) {
 #pragma unroll
             for (int c = 0; c < FWD_SUB; ++c) {

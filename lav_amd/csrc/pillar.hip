@@ -107,6 +107,7 @@ struct RowsArgs {
     const int *perm;   // perm[workgroup] = ownership class it works on (written by k_bin from the previous call's loads)
     int *load;         // load[class] = points the class held in this call (the next call's hint)
     unsigned long long *trace;
+    float *amax;       // [workgroups] or null: the largest finite value this workgroup's PointNet produced (lav_pillar_scatter_amax)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -311,6 +312,8 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     __shared__ int occ4[GW / 4];   // group number (+1) of the last group that put a point on this quad of columns
     __shared__ int newq[GW / 4];   // quads a layer's sweep touched for the first time in this group: their tile columns get zeroed
     __shared__ __attribute__((aligned(16))) int gpre[4][2][NBKT + 4];  // per wave, two slots: first record index of every bucket of a group
+    __shared__ float s_wmax[4];
+    float wmax = 0.f;   // largest finite PointNet output of this lane (round 6: the canvas' bound for the first BEV layer's fp16 scale)
 
     // fetch both cache lines of the kernel-argument segment at once (taken in turn, each is a microsecond-scale miss)
     asm volatile("" ::"s"(a.batch), "s"(canvas));
@@ -324,7 +327,10 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
     const int w = a.perm[blockIdx.x];              // the ownership class this workgroup works on (k_bin's pairing, see there)
     const int nslots = (nunits - w + W - 1) / W;   // units of the class
     if (nslots <= 0) {
-        if (tid == 0) a.load[w] = 0;
+        if (tid == 0) {
+            a.load[w] = 0;
+            if (a.amax) a.amax[blockIdx.x] = 0.f;
+        }
         return;
     }
     int load_sum = 0;
@@ -652,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
 #pragma unroll
                             for (int k = 0; k < C; ++k) acc = fmaf(h1[k], w2[k * C + c], acc);
                             const float o = acc > 0.f ? acc : 0.f;
+                            wmax = fmaxf(wmax, o <= 3.4028235e38f ? o : 0.f);
                             atomicMax(reinterpret_cast<unsigned *>(&tile[c * TS + col]), __float_as_uint(o));
                         }
                     }
@@ -741,7 +748,10 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
 #pragma unroll
                                     for (int rr = 0; rr < 4; ++rr) {
                                         const float o = d2[c][rr] > 0.f ? d2[c][rr] : 0.f;  // also maps -0 and NaN to +0
-                                        if (cols[rr] >= 0) atomicMax(trow + cols[rr], __float_as_uint(o));
+                                        if (cols[rr] >= 0) {
+                                            wmax = fmaxf(wmax, o <= 3.4028235e38f ? o : 0.f);
+                                            atomicMax(trow + cols[rr], __float_as_uint(o));
+                                        }
                                     }
                                 }
                             };
@@ -783,6 +793,12 @@ __global__ __launch_bounds__(256, 2) void k_rows(RowsArgs a, State *__restrict__
         c_next = g.first + g.gn < nslots ? fetch_counts(g.first + g.gn) : 0;
     }
     if (tid == 0) a.load[w] = load_sum;   // next call's pairing hint
+    if (a.amax) {   // (workgroup-uniform) a bound of what this workgroup wrote: replaced pillars of the clamp layers count too
+        wmax = wave_finite_absmax(wmax);
+        if (lane == 0) s_wmax[wid] = wmax;
+        barrier_lds();
+        if (tid == 0) a.amax[blockIdx.x] = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+    }
     LAV_STAMP(12);
     if constexpr (TRACE) {
         if (tid == 0) {
@@ -1035,7 +1051,7 @@ void dump_trace(const unsigned long long *d_trace, int nwg, hipStream_t st) {
 }
 
 template <int D>
-int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, bool want_keys, hipStream_t st) {
+int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *net, float *canvas, bool want_keys, float *amax, hipStream_t st) {
     const long total = (long)a.batch * a.max_points;
     const int tok_prep = timer_begin("pillar_prep", st);
     // where the canvas' zeros come from: k_rows streams them itself (default) | LAV_PILLAR_ZERO=bin: extra workgroups of k_bin fill the
@@ -1057,7 +1073,7 @@ int launch_canvas(const PillarArgs &a, const Workspace &w, const lav_pointnet *n
     RowsArgs at;
     at.batch = a.batch; at.nx = a.nx; at.ny = a.ny; at.UPR = a.UPR; at.NUP = a.NUP; at.cap = a.cap; at.rstride = a.rstride;
     at.min_x = a.min_x; at.min_y = a.min_y; at.ppm = a.ppm; at.trace = nullptr;
-    at.perm = w.perm; at.load = w.load;
+    at.perm = w.perm; at.load = w.load; at.amax = amax;
 
     if (want_trace && vec4) {
         if (!d_trace) LAV_HIP(hipMalloc(&d_trace, (size_t)persistent_workgroups() * 16 * sizeof(unsigned long long)));
@@ -1142,9 +1158,22 @@ extern "C" int lav_pillar_workspace_init(void *workspace, size_t workspace_bytes
     return LAV_OK;
 }
 
+extern "C" int lav_pillar_amax_count(int batch, const lav_grid *grid) {
+    if (!grid || batch <= 0) return 0;
+    const int upr = (grid->nx + UW - 1) / UW;
+    return std::min(std::min(persistent_workgroups(), batch * grid->ny * upr), 2048);   // = PillarArgs.nwg (fill_args)
+}
+
 extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, int batch, int max_points, int D,
                                   const lav_grid *grid, const lav_pointnet *net, float *canvas, int *unique_coords,
                                   int *inverse, int *counts, void *workspace, size_t workspace_bytes, void *stream) {
+    return lav_pillar_scatter_amax(points, h_num_points, batch, max_points, D, grid, net, canvas, unique_coords, inverse, counts, nullptr,
+                                   workspace, workspace_bytes, stream);
+}
+
+extern "C" int lav_pillar_scatter_amax(const float *points, const int *h_num_points, int batch, int max_points, int D,
+                                       const lav_grid *grid, const lav_pointnet *net, float *canvas, int *unique_coords,
+                                       int *inverse, int *counts, float *amax_parts, void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(grid && net && canvas && h_num_points, "lav_pillar_scatter: null argument");
     LAV_REQUIRE(batch >= 1 && batch <= MAX_BATCH, "lav_pillar_scatter: batch %d outside [1,%d]", batch, MAX_BATCH);
     LAV_REQUIRE(max_points >= 0 && (points || max_points == 0), "lav_pillar_scatter: bad points");
@@ -1170,9 +1199,9 @@ extern "C" int lav_pillar_scatter(const float *points, const int *h_num_points, 
     }
     const bool want_idx = unique_coords || inverse || counts;
     switch (D) {
-        case 11: rc = launch_canvas<11>(a, w, net, canvas, want_idx, st); break;
-        case 4: rc = launch_canvas<4>(a, w, net, canvas, want_idx, st); break;
-        case 8: rc = launch_canvas<8>(a, w, net, canvas, want_idx, st); break;
+        case 11: rc = launch_canvas<11>(a, w, net, canvas, want_idx, amax_parts, st); break;
+        case 4: rc = launch_canvas<4>(a, w, net, canvas, want_idx, amax_parts, st); break;
+        case 8: rc = launch_canvas<8>(a, w, net, canvas, want_idx, amax_parts, st); break;
         default: return fail(LAV_EINVAL, "lav_pillar_scatter: point width D=%d not instantiated (4,8,11)", D);
     }
     if (rc) return rc;

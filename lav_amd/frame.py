@@ -21,6 +21,7 @@ from . import ops
 from .model_inference import InferModel
 
 GAP = 5  # NUM_REPEAT + 1 (lav_agent_fast.py:32-33)
+_COPY_STREAM = os.environ.get("LAV_COPY_STREAM", "0") == "1"   # the frame's device-to-host copies on a stream of their own: measured 0.10 ms SLOWER with the side streams on (round 6, profiles/r06_frame_experiments.txt); off
 _DIAG_SKIP = set(filter(None, os.environ.get("LAV_DIAG_SKIP", "").split(",")))   # timing diagnosis: skip side graphs
 
 
@@ -193,8 +194,12 @@ class GraphedFramePipeline(FramePipeline):
         self.b_zero = torch.zeros((1, 4), **f)   # the ego vehicle's own (loc, ori)
         # capture streams double as workspace keys (lav_amd.ops._workspace): graphs that run concurrently must not
         # share split-K scratch, graphs of one stream may
-        self.s_cap, self.s_bra, self.s_ego = (torch.cuda.Stream(dev) for _ in range(3))
-        self.ev_in, self.ev_feat = torch.cuda.Event(), torch.cuda.Event()
+        # (LAV_BRAKE_PRIORITY / LAV_EGO_PRIORITY: HIP stream priority of the side streams, e.g. 1 = low; default 0.  tools/frame_ab.py)
+        self.s_cap = torch.cuda.Stream(dev)
+        self.s_bra = torch.cuda.Stream(dev, priority=int(os.environ.get("LAV_BRAKE_PRIORITY", "0")))
+        self.s_ego = torch.cuda.Stream(dev, priority=int(os.environ.get("LAV_EGO_PRIORITY", "0")))
+        self.ev_in, self.ev_feat, self.ev_heads = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.s_copy = torch.cuda.Stream(dev)   # the frame's device-to-host copies (peak rows, vehicle count)
         # the brake net runs beside the LiDAR chain: its layers are planned for part of the chip so that both fit
         side = int(os.environ.get("LAV_BRAKE_CUS", "128"))
         trunk = getattr(self.bra_model, "conv_backbone", None)
@@ -431,12 +436,24 @@ class GraphedFramePipeline(FramePipeline):
         if self.device_others:
             # peaks and count travel up while the GPU goes straight on with the others branch; the host reads them (and rebuilds
             # the detection lists of the API) while that branch runs - nothing on the GPU waits for it
-            self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
-            self.h_n.copy_(self.d_n, non_blocking=True)
-            self.ev_det.record(main)
+            # (round 6: on a copy stream of their own - issued on the main stream the two copies sat between the heads graph and the
+            # others graph, 25 us of the critical chain in the kernel trace)
+            if _COPY_STREAM:
+                self.ev_heads.record(main)
+                self.s_copy.wait_event(self.ev_heads)
+                with torch.cuda.stream(self.s_copy):
+                    self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
+                    self.h_n.copy_(self.d_n, non_blocking=True)
+                    self.ev_det.record(self.s_copy)
+            else:
+                self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
+                self.h_n.copy_(self.d_n, non_blocking=True)
+                self.ev_det.record(main)
             ob = self._replay("others_cap", self._g_others_cap, self.s_cap)
             main.wait_stream(self.s_ego)      # also keeps the next frame's input copies behind this frame's readers
             main.wait_stream(self.s_bra)
+            if _COPY_STREAM:
+                main.wait_stream(self.s_copy)     # (the next frame's heads graph rewrites the rows being copied)
             self._stamp("others graph launched")
             self.ev_det.synchronize()
             self._stamp("heads done on the GPU (event)")

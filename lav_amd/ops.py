@@ -69,9 +69,11 @@ def make_grid(min_x, max_x, min_y, max_y, ppm) -> Grid:
 
 
 def pillar_scatter(points: torch.Tensor, num_points: Sequence[int], grid: Grid, w1, b1, w2, b2,
-                   want_indices: bool = False):
+                   want_indices: bool = False, amax: Optional["Amax"] = None):
     """points (B, Nmax, D) or (N, D) f32 in HBM -> canvas (B, C, ny, nx)
-    [+ unique_coords (P,3) int32, inverse (N_kept,) int32 when want_indices]."""
+    [+ unique_coords (P,3) int32, inverse (N_kept,) int32 when want_indices].
+    amax: an Amax that receives the canvas kernel's per-workgroup maxima (lav_pillar_scatter_amax) and is attached to the canvas
+    (amax_of): the first BEV convolution then takes its fp16 scale from them instead of measuring the canvas with a launch."""
     lib = _lib.load()
     if points.dim() == 2:
         points = points[None]
@@ -94,8 +96,11 @@ def pillar_scatter(points: torch.Tensor, num_points: Sequence[int], grid: Grid, 
         uc = torch.empty((max(total, 1), 3), dtype=torch.int32, device=dev)
         inv = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
         cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
-    rc = lib.lav_pillar_scatter(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), C.byref(net),
-                                _ptr(canvas), _ptr(uc), _ptr(inv), _ptr(cnt), _ptr(ws), ws.numel(), _stream())
+    parts = amax.reset().take(lib.lav_pillar_amax_count(B, C.byref(grid))) if amax is not None else None
+    rc = lib.lav_pillar_scatter_amax(_ptr(points) if nmax > 0 else None, h_num, B, nmax, D, C.byref(grid), C.byref(net),
+                                     _ptr(canvas), _ptr(uc), _ptr(inv), _ptr(cnt), _ptr(parts), _ptr(ws), ws.numel(), _stream())
+    if amax is not None:
+        canvas._lav_amax = amax
     if rc != 0:
         # the workspace's zero-at-rest state (arrival counters, epoch words) may be half-updated: never reuse it (lav_amd.h, workspace
         # contract) - the next call zero-fills a fresh one
@@ -887,17 +892,22 @@ def copy_many(pairs) -> None:
     16-byte-aligned pairs through lav_copy_many (16-byte words), strided / uint8 sources of up to four dimensions into contiguous
     float32 destinations through lav_stage_many (the conversion torch's copy_ would do, for all of them at once); anything else
     takes Tensor.copy_."""
-    srcs, dsts, sizes, stage = [], [], [], []
+    srcs, dsts, sizes, stage, plain = [], [], [], [], []
     for dst, src in pairs:
         nb = dst.numel() * dst.element_size()
         both = src.is_cuda and dst.is_cuda and dst.is_contiguous() and src.shape == dst.shape and nb > 0
         if (both and src.is_contiguous() and src.dtype == dst.dtype and nb % 4 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
-            srcs.append(src.data_ptr()); dsts.append(dst.data_ptr()); sizes.append(nb)
+            srcs.append(src.data_ptr()); dsts.append(dst.data_ptr()); sizes.append(nb); plain.append((dst, src))
         elif both and dst.dtype == torch.float32 and src.dtype in (torch.float32, torch.uint8) and 1 <= src.dim() <= 4:
             stage.append((dst, src))
         else:
             dst.copy_(src, non_blocking=True)
     lib = _lib.load()
+    if _os.environ.get("LAV_COPY_MERGE", "1") != "0" and stage and plain and len(stage) + len(plain) <= 8 and all(d.dtype == torch.float32 for d, _ in plain):
+        # (round 6) one launch instead of two: the few contiguous float32 pairs of a frame (LiDAR rows, next waypoint) ride with the
+        # strided ones - every launch on the frame's critical chain costs ~4.5 us whatever it moves
+        stage = [(d.reshape(-1), s_.reshape(-1)) for d, s_ in plain] + stage
+        srcs = []
     for i in range(0, len(srcs), 8):
         n = len(srcs[i:i + 8])
         check(lib.lav_copy_many(n, (C.c_void_p * n)(*srcs[i:i + 8]), (C.c_void_p * n)(*dsts[i:i + 8]), (C.c_size_t * n)(*sizes[i:i + 8]), _stream()),

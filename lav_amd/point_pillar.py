@@ -7,6 +7,7 @@ canvas).  There is no torch fallback: tensors must live in HBM.
 """
 from __future__ import annotations
 
+import os
 from typing import Sequence
 
 import torch
@@ -72,6 +73,7 @@ class PointPillarNet(nn.Module):
         self.pixels_per_meter = pixels_per_meter
         self.num_input = num_input
         self._grid = ops.make_grid(min_x, max_x, min_y, max_y, pixels_per_meter)
+        self._amax = {}
 
     @staticmethod
     def _pack(lidar_list, num_points):
@@ -112,4 +114,12 @@ class PointPillarNet(nn.Module):
         if pts.shape[2] + 5 != self.num_input:
             raise RuntimeError(f"points have {pts.shape[2]} columns, PointNet expects {self.num_input - 5}")
         w1, b1, w2, b2 = self.point_net.folded(pts.device)
-        return ops.pillar_scatter(pts, n, self._grid, w1, b1, w2, b2, want_indices=return_indices)
+        # the canvas leaves with a bound of its values (one float per workgroup of the canvas kernel) for LAV_CONV_F16X3 readers; one
+        # fixed buffer per batch size and device: HIP graphs hold its address
+        am = None
+        if not return_indices and os.environ.get("LAV_PILLAR_AMAX", "1") != "0":
+            key = (int(pts.shape[0]), str(pts.device))
+            am = self._amax.get(key)
+            if am is None:
+                am = self._amax[key] = ops.Amax(pts.device, capacity=2048)
+        return ops.pillar_scatter(pts, n, self._grid, w1, b1, w2, b2, want_indices=return_indices, amax=am)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# frame_ab.py under environment variants, one process each (the knobs are read at construction), first variant repeated at the end.
+#   bash tools/frame_env_ab.sh out.txt "A=1" "B=2 C=3" ...
+out=$1; shift
+: > $out
+run() { echo "== ${1:-default}" >> $out; env $1 timeout 300 python tools/frame_ab.py --variants all,chain --rounds 2 --steps 60 2>/dev/null | tail -1 >> $out; }
+run ""
+for v in "$@"; do run "$v"; done
+run ""
+cat $out

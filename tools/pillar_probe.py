@@ -56,6 +56,26 @@ def ev_time(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+def probe_batch(label, clouds, reps=30):
+    """B clouds in one call (the kernel pair's throughput regime: the launch chain is paid once for B canvases)."""
+    if len(sys.argv) > 1 and sys.argv[1] not in label:
+        return
+    pts = [torch.from_numpy(c).to(dev) for c in clouds]
+    ns = [len(p) for p in pts]
+    for _ in range(3):
+        ppn(pts, ns)
+    torch.cuda.synchronize()
+    lib.lav_profile_enable(reps + 8)
+    ppn(pts, ns); torch.cuda.synchronize(); lib.lav_profile_reset()
+    for _ in range(reps):
+        ppn(pts, ns)
+    torch.cuda.synchronize()
+    k, p = read("pointnet_scatter"), read("pillar_prep")
+    lib.lav_profile_enable(0)
+    nb = sum(4 * (n * 11 + 64 * 320 * 320) for n in ns)
+    print(f"batch {len(pts):3d} x {label:22s} n={sum(ns):8d} kernel {k:7.1f} us ({nb / k / 1e3:6.0f} GB/s, {nb / k / 8e6 * 100:4.1f}% of 8 TB/s)  prep {p:6.1f} us  stage {k + p:7.1f} us ({nb / (k + p) / 8e6 * 100:4.1f}%)", flush=True)
+
+
 rng = np.random.default_rng(0)
 uni = np.concatenate([rng.uniform(-12, 72, (196608, 1)), rng.uniform(-42, 42, (196608, 1)), rng.uniform(-2.4, 1.6, (196608, 1)),
                       rng.uniform(0, 1, (196608, 8))], axis=1).astype(np.float32)
@@ -65,6 +85,8 @@ probe("lidar-like 3x10923", synth.stacked_lidar(10923))
 probe("lidar-like 3x65536", synth.stacked_lidar(65536))
 probe("uniform 196608", uni)
 probe("uniform 32768", uni[:32768])
+for B in (2, 4, 8, 16, 32):
+    probe_batch("lidar-like 3x10923", [synth.stacked_lidar(10923, seed=100 + b) if "seed" in synth.stacked_lidar.__code__.co_varnames else synth.stacked_lidar(10923) for b in range(B)])
 if "LAV_PILLAR_TW" not in os.environ and len(sys.argv) == 1:
     canvas = torch.empty((1, 64, 320, 320), device=dev)
     src = torch.randn((1, 64, 320, 320), device=dev)
