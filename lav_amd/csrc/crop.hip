@@ -108,7 +108,7 @@ __device__ __forceinline__ SamplePos sample_pos(int x, int y, int crop, int H, i
 __global__ __launch_bounds__(256, 3) void k_crop_rotate_staged(const float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index,
                                                                int C, int H, int W, const float *__restrict__ locs,
                                                                const float *__restrict__ oris, float ppm, int crop, float ox, float oy,
-                                                               float *__restrict__ out, const int *__restrict__ n_valid) {
+                                                               float *__restrict__ out, const int *__restrict__ n_valid, int cpb) {
     __shared__ float s_f[FWD_SUB][FWD_CAP];
     const int n = blockIdx.z;
     if (n_valid && n >= *n_valid) return;   // lav_batch_limit (workgroup-uniform)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void k_crop_rotate_staged(const float *__re
     const int o10 = (sp.cy1 - by0) * bw + (sp.cx0 - bx0), o11 = (sp.cy1 - by0) * bw + (sp.cx1 - bx0);
     const long plane = (long)H * W, cc = (long)crop * crop;
     const int m = map_index ? map_index[n] : (feat_batch > 1 ? n : 0);
-    const int c_lo = blockIdx.y * FWD_CPB, nch = min(FWD_CPB, C - c_lo);
+    const int c_lo = blockIdx.y * cpb, nch = min(cpb, C - c_lo);   // cpb: channels per workgroup (8, 16 or 32: crop_launch)
     const float *f = feat + ((long)m * C + c_lo) * plane;
     float *o_ = out + ((long)n * C + c_lo) * cc + (long)y * crop + x;
     // Staging (round 6).  Thread (c = tid / 32, column = tid % 32) fetches column `column` of channel c's box: at most 32 rows, ALL
@@ -334,27 +334,31 @@ __global__ __launch_bounds__(256, 3) void k_crop_rotate_bwd(const float *__restr
                         off[dy * BWD_MAXSPAN + dx] = w_ != 0.f ? (y - by0) * bw + (x - bx0) : 0;
                         __builtin_amdgcn_sched_barrier(0);   // one candidate at a time: nine interleaved copies of the weight arithmetic cost 100+ registers
                     }
+                // Staging (round 6, as in the forward kernel): thread (channel tid / 32, column tid % 32) fetches its column of the
+                // box - at most 32 rows, all requested before the first is used, from clamped addresses - and the next eight channels
+                // are requested before this group's products are accumulated.  The first version walked the box in seven dependent
+                // batches of four loads.
+                if (bh > 32) __builtin_trap();
+                const int l32 = tid & 31, sc = tid >> 5;
+                const float *gcol = gq + (long)by0 * crop + bx0 + min(l32, bw - 1);
+                float stg[32];
+                auto request = [&](int cs0) __attribute__((always_inline)) {
+                    const int nsub = min(BWD_SUB, nch - cs0);
+                    const float *src = gcol + (long)(cs0 + min(sc, nsub - 1)) * cc;
+#pragma unroll
+                    for (int yy = 0; yy < 32; ++yy) stg[yy] = src[(long)min(yy, bh - 1) * crop];
+                };
+                request(0);
 #pragma unroll
                 for (int cs0 = 0; cs0 < BWD_CPB; cs0 += BWD_SUB) {
                     if (cs0 < nch) {   // workgroup-uniform
-                        // rows of the box (channel-major), one per half-wave, coalesced; four rows in flight per thread
-                        const int rows = min(BWD_SUB, nch - cs0) * bh, l32 = tid & 31;
-                        const float *gs = gq + (long)cs0 * cc + (long)by0 * crop + bx0 + l32;
-                        for (int r0 = tid >> 5; r0 < rows; r0 += 32) {
-                            float v[4];
-                            int dst[4];
+                        if (sc < min(BWD_SUB, nch - cs0) && l32 < bw) {
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int r = r0 + 8 * u, c = r / bh, yy = r - c * bh;
-                                const bool ok = r < rows && l32 < bw;
-                                dst[u] = ok ? c * BWD_CAP + yy * bw + l32 : -1;
-                                v[u] = ok ? gs[(long)c * cc + (long)yy * crop] : 0.f;
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (dst[u] >= 0) (&s_g[0][0])[dst[u]] = v[u];
+                            for (int yy = 0; yy < 32; ++yy)
+                                if (yy < bh) s_g[sc][yy * bw + l32] = stg[yy];
                         }
                         __syncthreads();
+                        if (cs0 + BWD_SUB < nch) request(cs0 + BWD_SUB);
 #pragma unroll
                         for (int c = 0; c < BWD_SUB; ++c) {
 #pragma unroll
@@ -474,8 +478,13 @@ int crop_launch(const float *feat, int nmaps, const int *map_index, int C, int H
     const int tok = timer_begin("crop_rotate", st);
     if (crop_fwd_staged_ok(H, W, crop) && !getenv("LAV_CROP_FWD_GENERAL")) {   // (A/B knob)
         const int tiles = (crop + FWD_TILE - 1) / FWD_TILE;
-        hipLaunchKernelGGL(k_crop_rotate_staged, dim3(tiles * tiles, (C + FWD_CPB - 1) / FWD_CPB, n), dim3(256), 0, st, feat, nmaps, map_index, C,
-                           H, W, locs, oris, ppm, crop, ox, oy, out, lav::batch_limit());
+        // channels per workgroup: 32; 16 for a single crop (432 workgroups of 32 channels are 1.7 per CU, each a serial chain of
+        // stage -> sample -> store groups of eight channels: 19.7 vs 20.7 us; from two crops on 32 wins, 8 always loses - measured,
+        // profiles/r06_crop_probe.txt)
+        static const int cpb_env = [] { const char *e = getenv("LAV_CROP_CPB"); return e ? atoi(e) : 0; }();   // (A/B knob: 8, 16 or 32)
+        const int cpb = cpb_env == 8 || cpb_env == 16 || cpb_env == 32 ? cpb_env : (n <= 1 ? 16 : FWD_CPB);
+        hipLaunchKernelGGL(k_crop_rotate_staged, dim3(tiles * tiles, (C + cpb - 1) / cpb, n), dim3(256), 0, st, feat, nmaps, map_index, C,
+                           H, W, locs, oris, ppm, crop, ox, oy, out, lav::batch_limit(), cpb);
     } else {
         dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
         hipLaunchKernelGGL(k_crop_rotate, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block,

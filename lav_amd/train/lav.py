@@ -192,11 +192,16 @@ class LAV:
             self.lidar_optim.zero_grad()
             loss.backward()
         self.lidar_optim.step()
-        info = _scalars(loss, terms)
         # The inference below only feeds the visualisation log.  It needs the inference engines re-packed from the
         # just-updated weights (~500 small copies), so it runs on the steps that are logged, not on all of them.
+        # (round 6: enqueued BEFORE the loss terms are read back - its host work (eval(), the engines' refresh, ~100 launches) then runs
+        # while the GPU is still in the backward pass instead of behind an empty queue)
+        log = None
         if cfg.log_inference and self.steps % max(cfg.log_every, 1) == 0:
-            info.update(self.mot_inference(lidars[0], num_points[0], cmds[0], nxps[0]))
+            log = self.mot_inference(lidars[0], num_points[0], cmds[0], nxps[0])
+        info = _scalars(loss, terms)
+        if log is not None:
+            info.update(log)
         self.steps += 1
         return info
 

@@ -110,3 +110,38 @@ def test_pillar_336_grid():
     np.testing.assert_array_equal(uc.cpu().numpy(), o["unique_coords"])
     np.testing.assert_array_equal(inv.cpu().numpy(), o["inverse"])
     assert_close(canvas.cpu().numpy(), o["canvas"], atol=5e-5, rtol=2e-5, what="canvas336")
+
+
+@pytest.mark.parametrize("impl", ["mfma", "valu"])
+def test_pillar_canvas_bound_for_the_first_bev_layer(golden, ppn, impl):
+    """lav_pillar_scatter_amax (round 6): the per-workgroup maxima the canvas kernel leaves for LAV_CONV_F16X3 readers.  They bound
+    the canvas (on clouds without clamp-layer collisions: exactly its maximum), an empty canvas leaves zeros, and asking for them
+    changes no bit of the canvas."""
+    from lav_amd import ops
+    os.environ["LAV_PILLAR_IMPL"] = impl
+    try:
+        for name in ("lidar", "uniform", "edge", "one_cell", "batch2"):
+            clouds, n = pillar_cases(golden["pillar"])[name]
+            n = n or [len(c) for c in clouds]
+            lst = [torch.from_numpy(c).to(DEV) for c in clouds]
+            with_b = ppn(lst, n)
+            am = ops.amax_of(with_b)
+            assert am is not None and am.count >= 1
+            parts = am.buf[:am.count].cpu().numpy()
+            os.environ["LAV_PILLAR_AMAX"] = "0"
+            try:
+                plain = ppn(lst, n)
+            finally:
+                os.environ.pop("LAV_PILLAR_AMAX")
+            assert ops.amax_of(plain) is None
+            assert torch.equal(with_b, plain)
+            top = float(with_b.max())
+            assert np.isfinite(parts).all() and (parts >= 0).all()
+            assert parts.max() >= top, f"{name}: the parts' maximum {parts.max()} is below the canvas' {top}"
+            if name in ("lidar", "uniform", "batch2"):     # (edge / one_cell exercise the clamp layers, where a replaced pillar may count)
+                assert parts.max() == top
+        empty = ppn([torch.full((64, 11), 100.0, device=DEV)], [64])
+        am = ops.amax_of(empty)
+        assert not empty.any() and float(am.buf[:am.count].max()) == 0.0
+    finally:
+        os.environ.pop("LAV_PILLAR_IMPL", None)

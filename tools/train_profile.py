@@ -13,8 +13,9 @@ what = sys.argv[1] if len(sys.argv) > 1 else "lidar"
 if len(sys.argv) > 2 and sys.argv[2] == "bench":
     torch.backends.cudnn.benchmark = True
 dev = torch.device("cuda")
-lav = LAV(TrainConfig(), dev, what=what)
-batch = synthetic_lidar_batch(4, device=dev) if what == "lidar" else synthetic_bev_batch(8, device=dev)
+lav = LAV(TrainConfig(log_every=int(os.environ.get("LOG_EVERY", "100"))), dev, what=what)
+B = int(os.environ.get("BATCH", "4" if what == "lidar" else "8"))
+batch = synthetic_lidar_batch(B, device=dev) if what == "lidar" else synthetic_bev_batch(B, device=dev)
 step = (lambda: lav.train_lidar(*batch)) if what == "lidar" else (lambda: lav.train_bev(*batch, other_weight=0.5))
 for _ in range(3):
     step()
