@@ -168,6 +168,13 @@ def set_deterministic(on: bool = True):
     torch.backends.cudnn.deterministic = bool(on)
     if on:
         torch.backends.cudnn.benchmark = False
+    # Round 6: reproducible from PROCESS to process too.  With benchmark off torch still lets MIOpen "find" - time the applicable solvers and
+    # keep the fastest -, so which (deterministic) solver a layer gets is a measurement, and two processes on one box disagreed about once in
+    # three starts (tools/determinism_xproc.py: the first difference at step 0, 1 or 2; inside a process 24 of 24 repeats of step 0 agree).
+    # MIOpen's immediate mode takes the solver from its database / heuristic instead of a timing.
+    mi = getattr(torch.backends, "miopen", None)
+    if mi is not None and hasattr(mi, "immediate"):
+        mi.immediate = bool(on)
     torch.use_deterministic_algorithms(bool(on), warn_only=True)
 
 

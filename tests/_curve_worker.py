@@ -4,6 +4,12 @@ depends on what ran before in the process and on the find results on disk, so in
 the session (round 6: twelve new convolution tests in front of it moved the orientation term from inside its bar to 9 % beyond
 it); here it is a function of the code alone.
 
+Second half of the same fix (round 6, second session): an empty database was not enough - with `cudnn.benchmark` off torch still lets
+MIOpen TIME the applicable solvers and keep the fastest, so the choice was a measurement and the curve a random sample per process (seven
+runs of one build ended at 5.4 ... 12.2 against the reference's 8.7; one in three failed a bar).  `set_deterministic` now also switches
+MIOpen to immediate mode (`torch.backends.miopen.immediate`: the solver comes from MIOpen's database / heuristic); four processes of twelve
+steps then agree in every bit of every loss term (tools/determinism_xproc.py) and two runs of this worker give the same 500 rows.
+
     python tests/_curve_worker.py OUT.npz KEY1,KEY2,...
 """
 import os
