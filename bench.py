@@ -397,12 +397,19 @@ def main():
     n_pts = int(out["lidar_points"].shape[0])
     per_frame_us = {k: round(v[0] / args.steps * 1e3, 1) for k, v in prof.items()} if args.eager else None
 
-    def pillar_micro(n_per_sweep, reps=100):
+    def pillar_micro(n_per_sweep, reps=100, batch=1):
         """BASELINE.json config #2 in isolation: back-to-back pillar launches on one synthetic cloud, so the
-        HIP-event figures are pure kernel time (the frame loop above is host-bound between launches)."""
+        HIP-event figures are pure kernel time (the frame loop above is host-bound between launches).
+        batch > 1 (round 6): that many clouds in ONE call - what the kernel pair costs per canvas once its launch chain is amortised."""
         from lav_amd import synth
-        pts = torch.from_numpy(synth.stacked_lidar(n_per_sweep)).to(device)
-        ppn = pipe.infer_model.lidar_model.point_pillar_net
+        ppn1 = pipe.infer_model.lidar_model.point_pillar_net
+        if batch > 1:
+            clouds = [torch.from_numpy(synth.stacked_lidar(n_per_sweep, seed=synth.SEED + b)).to(device) for b in range(batch)]
+            ppn = lambda lst, ns: ppn1(clouds, [len(c) for c in clouds])
+            pts = torch.cat(clouds)
+        else:
+            pts = torch.from_numpy(synth.stacked_lidar(n_per_sweep)).to(device)
+            ppn = ppn1
         for _ in range(5):
             ppn([pts], [len(pts)])
         torch.cuda.synchronize()
@@ -425,8 +432,9 @@ def main():
             ppn([pts], [len(pts)])
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
+        in_graph = 20 if batch == 1 else 2   # (every call inside the capture allocates its canvases in the graph's pool: 0.4 GB each at 16 clouds)
         with torch.cuda.graph(gr, stream=side):
-            for _ in range(20):
+            for _ in range(in_graph):
                 ppn([pts], [len(pts)])
         gr.replay(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -434,9 +442,9 @@ def main():
         for _ in range(5):
             gr.replay()
         e1.record(); torch.cuda.synchronize()
-        region_us = e0.elapsed_time(e1) / 100 * 1e3
+        region_us = e0.elapsed_time(e1) / (5 * in_graph) * 1e3
         del gr
-        nb = 4 * (len(pts) * 11 + 64 * 320 * 320)
+        nb = 4 * (len(pts) * 11 + batch * 64 * 320 * 320)
         ks, ps = k_ms / max(k_n, 1) * 1e-3, p_ms / max(p_n, 1) * 1e-3
         kept = int(((pts[:, 0] >= -10) & (pts[:, 0] < 70) & (pts[:, 1] >= -40) & (pts[:, 1] < 40)).sum())
         fl = 10240.0 * kept    # PointNet: 2*(16*64 + 64*64) flop per kept point, on the matrix cores inside the same kernel
@@ -558,6 +566,12 @@ def main():
         return outm
 
     micro = {"config2_32768pts": pillar_micro(10923), "agent_196608pts": pillar_micro(65536)} if rank == 0 else None
+    if micro is not None:
+        try:   # sixteen config-#2 clouds in one call: the same kernels with the launch chain paid once
+            micro["config2_batch16_one_call"] = dict(pillar_micro(10923, reps=30, batch=16), clouds=16,
+                                                     note="16 clouds of 32 769 points, one lav_pillar_scatter call: the kernel pair's throughput regime - not BASELINE config #2, which is ONE cloud (roofline.frac)")
+        except Exception as e:   # never lose the headline line to a side measurement
+            micro["config2_batch16_one_call"] = dict(error=repr(e)[:200])
     conv_roof = conv_micro() if rank == 0 else None
     # roofline of the dominant pillar kernel at the frame's own size (196 608 points).  The frame loop replays HIP
     # graphs (kernels inside a graph cannot carry event pairs), so the figure comes from the back-to-back launches
@@ -570,7 +584,7 @@ def main():
         # PointNet (max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) is the binding roof) are carried beside it.
         m, mf = micro["config2_32768pts"], micro["agent_196608pts"]
         traffic, traffic_src = None, None
-        for prof_name in ("r05_pmc_pillar.json", "r04_pmc_pillar.json", "r03_pmc_pillar.json", "r02_b_pmc_pillar.json"):
+        for prof_name in ("r06_pmc_pillar.json", "r05_pmc_pillar.json", "r04_pmc_pillar.json", "r03_pmc_pillar.json", "r02_b_pmc_pillar.json"):
             try:  # HBM bytes per launch from the committed PMC pass of this kernel (counters cannot be read from inside a run)
                 with open(os.path.join(REPO, "profiles", prof_name)) as f:
                     pm = json.load(f)
