@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 26
+#define LAV_ABI_VERSION 27
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -500,6 +500,18 @@ int lav_bn_train_forward(const float *x, const float *residual, float *y, int ba
 int lav_bn_train_backward(const float *x, const float *y, const float *dy, int batch, int channels, long plane, const float *gamma,
                           const float *save_mean, const float *save_rstd, int relu_pre, int relu_post, float *dx, float *dres,
                           float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+/* The same pair leaving the BOUND of what it writes (round 6): amax_y / amax_dx (device, lav_bn_train_amax_count floats, or NULL) receive
+ * the largest finite |y| resp. |dx| of every workgroup of the normalising launch - in the training graph (lav/lav_final_v2.py:140-259)
+ * the next convolution's input is a BatchNorm's output and a convolution's output gradient is a BatchNorm's input gradient, so that a
+ * LAV_CONV_F16X3 step takes its scales from these parts (lav_conv2d_amax, lav_conv_wgrad_amax) instead of measuring every activation and
+ * gradient tensor with a launch of its own (173 lav_absmax_parts launches per train_full step). */
+int lav_bn_train_amax_count(int batch, int channels, long plane);
+int lav_bn_train_forward_amax(const float *x, const float *residual, float *y, int batch, int channels, long plane, const float *gamma,
+                              const float *beta, double eps, int relu_pre, int relu_post, float *save_mean, float *save_var,
+                              float *save_rstd, float *amax_y, void *workspace, size_t workspace_bytes, void *stream);
+int lav_bn_train_backward_amax(const float *x, const float *y, const float *dy, int batch, int channels, long plane, const float *gamma,
+                               const float *save_mean, const float *save_rstd, int relu_pre, int relu_post, float *dx, float *dres,
+                               float *dgamma, float *dbeta, float *amax_dx, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Weight gradient of a 3x3, padding-1 convolution of stride 1 or 2, or of a 7x7, padding-3, stride-2 convolution (round 5): the weight half of torch.autograd's convolution backward for
  * the stage convolutions of ConvBackbone (team_code_v2/models/lidar.py:57-108) and the four heads' first convolutions (lidar.py:147-161)

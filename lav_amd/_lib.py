@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 MAX_CAM = 4
 
 
@@ -103,6 +103,9 @@ SIGNATURES = {
     "lav_bn_train_workspace_bytes": (_Z, [_I]),
     "lav_bn_train_forward": (_I, [_P, _P, _P, _I, _I, C.c_long, _P, _P, C.c_double, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "lav_bn_train_backward": (_I, [_P, _P, _P, _I, _I, C.c_long, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_bn_train_amax_count": (_I, [_I, _I, C.c_long]),
+    "lav_bn_train_forward_amax": (_I, [_P, _P, _P, _I, _I, C.c_long, _P, _P, C.c_double, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "lav_bn_train_backward_amax": (_I, [_P, _P, _P, _I, _I, C.c_long, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "lav_attn_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "lav_linear_act": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _P]),
     "lav_maxpool3x3s2": (_I, [_P, _I, _I, _I, _I, _P, _P]),

@@ -49,6 +49,15 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *lds) {
     }
 }
 
+// largest finite |v| over the workgroup's 256 threads -> parts[part] (round 6: the tensor's bound for LAV_CONV_F16X3 readers, lav_amd.h)
+__device__ __forceinline__ void block_absmax_out(float m, float *__restrict__ parts, long part) {
+    __shared__ float s_m[4];
+    m = lav::wave_finite_absmax(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[part] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
 // visit the elements of slice (c, s): f(index into the NCHW tensor, number of valid floats 1..4)
 template <bool VEC, typename F>
 __device__ __forceinline__ void for_slice(const BnGeom &g, int c, int s, F f) {
@@ -97,7 +106,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_bn_apply(BnGeom g, const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
                                                   const float *__restrict__ gamma, const float *__restrict__ beta, double eps, int relu_pre,
                                                   int relu_post, const double *__restrict__ partial, float *__restrict__ save_mean,
-                                                  float *__restrict__ save_var, float *__restrict__ save_rstd) {
+                                                  float *__restrict__ save_var, float *__restrict__ save_rstd, float *__restrict__ amax) {
     const int c = blockIdx.x, s = blockIdx.y;
     double a, b;
     channel_sums(g, c, partial, a, b);
@@ -106,10 +115,13 @@ __global__ __launch_bounds__(256) void k_bn_apply(BnGeom g, const float *__restr
     const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + eps));
     if (s == 0 && threadIdx.x == 0) { save_mean[c] = mean; save_var[c] = (float)var_d; save_rstd[c] = rstd; }
     const float ga = gamma[c], be = beta[c];
+    float am = 0.f;
     auto one = [&](float v, float r) {
         const float t = relu_pre ? fmaxf(v, 0.f) : v;
         float o = fmaf((t - mean) * rstd, ga, be) + r;
-        return relu_post ? fmaxf(o, 0.f) : o;
+        o = relu_post ? fmaxf(o, 0.f) : o;
+        am = fmaxf(am, lav::finite_abs(o));
+        return o;
     };
     for_slice<VEC>(g, c, s, [&](long at) {
         if constexpr (VEC) {
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(BnGeom g, const float *__restr
             y[at] = one(x[at], res ? res[at] : 0.f);
         }
     });
+    if (amax) block_absmax_out(am, amax, (long)c * g.S + s);   // (kernel-uniform)
 }
 
 template <bool VEC>
@@ -168,18 +181,22 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnGeom g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ g_src,
                                                       int mask_here, const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                       const float *__restrict__ save_rstd, int relu_pre, const double *__restrict__ partial,
-                                                      float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                      float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                      float *__restrict__ amax) {
     const int c = blockIdx.x, s = blockIdx.y;
     double a, b;
     channel_sums(g, c, partial, a, b);
     if (s == 0 && threadIdx.x == 0) { dbeta[c] = (float)a; dgamma[c] = (float)b; }
     const float mean = save_mean[c], rstd = save_rstd[c];
     const float k0 = gamma[c] * rstd, mg = (float)(a / (double)g.N), mgx = (float)(b / (double)g.N);
+    float am = 0.f;
     auto one = [&](float xv, float gv, float yv) {
         if (mask_here) gv = yv > 0.f ? gv : 0.f;
         const float t = relu_pre ? fmaxf(xv, 0.f) : xv;
-        const float o = k0 * (gv - mg - (t - mean) * rstd * mgx);
-        return (relu_pre && !(xv > 0.f)) ? 0.f : o;
+        float o = k0 * (gv - mg - (t - mean) * rstd * mgx);
+        o = (relu_pre && !(xv > 0.f)) ? 0.f : o;
+        am = fmaxf(am, lav::finite_abs(o));
+        return o;
     };
     for_slice<VEC>(g, c, s, [&](long at) {
         if constexpr (VEC) {
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(BnGeom g, const float *__r
             dx[at] = one(x[at], g_src[at], mask_here ? y[at] : 1.f);
         }
     });
+    if (amax) block_absmax_out(am, amax, (long)c * g.S + s);
 }
 
 int geometry(BnGeom &g, int batch, int channels, long hw, const char *who) {
@@ -217,9 +235,22 @@ bool vec_ok(long hw, std::initializer_list<const void *> ptrs) {
 
 extern "C" size_t lav_bn_train_workspace_bytes(int channels) { return (size_t)std::max(channels, 1) * BN_MAX_SLICES * 2 * sizeof(double); }
 
+extern "C" int lav_bn_train_amax_count(int batch, int channels, long hw) {
+    BnGeom g;
+    if (batch < 1 || channels < 1 || hw < 1 || (long)batch * hw < 2 || geometry(g, batch, channels, hw, "lav_bn_train_amax_count")) return 0;
+    return g.C * g.S;
+}
+
 extern "C" int lav_bn_train_forward(const float *x, const float *residual, float *y, int batch, int channels, long hw, const float *gamma,
                                     const float *beta, double eps, int relu_pre, int relu_post, float *save_mean, float *save_var,
                                     float *save_rstd, void *workspace, size_t workspace_bytes, void *stream) {
+    return lav_bn_train_forward_amax(x, residual, y, batch, channels, hw, gamma, beta, eps, relu_pre, relu_post, save_mean, save_var, save_rstd,
+                                     nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lav_bn_train_forward_amax(const float *x, const float *residual, float *y, int batch, int channels, long hw, const float *gamma,
+                                         const float *beta, double eps, int relu_pre, int relu_post, float *save_mean, float *save_var,
+                                         float *save_rstd, float *amax_y, void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(x && y && gamma && beta && save_mean && save_var && save_rstd && workspace, "lav_bn_train_forward: null pointer");
     LAV_REQUIRE(workspace_bytes >= lav_bn_train_workspace_bytes(channels), "lav_bn_train_forward: workspace smaller than lav_bn_train_workspace_bytes");
     LAV_REQUIRE(!(relu_pre && (relu_post || residual)), "lav_bn_train_forward: relu_pre excludes relu_post / residual");
@@ -231,10 +262,10 @@ extern "C" int lav_bn_train_forward(const float *x, const float *residual, float
     const int tok = timer_begin("bn_train_fwd", st);
     if (vec_ok(hw, {x, y, residual})) {
         hipLaunchKernelGGL(k_bn_stats<true>, grid, dim3(256), 0, st, g, x, relu_pre, partial);
-        hipLaunchKernelGGL(k_bn_apply<true>, grid, dim3(256), 0, st, g, x, residual, y, gamma, beta, eps, relu_pre, relu_post, partial, save_mean, save_var, save_rstd);
+        hipLaunchKernelGGL(k_bn_apply<true>, grid, dim3(256), 0, st, g, x, residual, y, gamma, beta, eps, relu_pre, relu_post, partial, save_mean, save_var, save_rstd, amax_y);
     } else {
         hipLaunchKernelGGL(k_bn_stats<false>, grid, dim3(256), 0, st, g, x, relu_pre, partial);
-        hipLaunchKernelGGL(k_bn_apply<false>, grid, dim3(256), 0, st, g, x, residual, y, gamma, beta, eps, relu_pre, relu_post, partial, save_mean, save_var, save_rstd);
+        hipLaunchKernelGGL(k_bn_apply<false>, grid, dim3(256), 0, st, g, x, residual, y, gamma, beta, eps, relu_pre, relu_post, partial, save_mean, save_var, save_rstd, amax_y);
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
@@ -244,6 +275,13 @@ extern "C" int lav_bn_train_forward(const float *x, const float *residual, float
 extern "C" int lav_bn_train_backward(const float *x, const float *y, const float *dy, int batch, int channels, long hw, const float *gamma,
                                      const float *save_mean, const float *save_rstd, int relu_pre, int relu_post, float *dx, float *dres,
                                      float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream) {
+    return lav_bn_train_backward_amax(x, y, dy, batch, channels, hw, gamma, save_mean, save_rstd, relu_pre, relu_post, dx, dres, dgamma, dbeta, nullptr,
+                                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int lav_bn_train_backward_amax(const float *x, const float *y, const float *dy, int batch, int channels, long hw, const float *gamma,
+                                          const float *save_mean, const float *save_rstd, int relu_pre, int relu_post, float *dx, float *dres,
+                                          float *dgamma, float *dbeta, float *amax_dx, void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace, "lav_bn_train_backward: null pointer");
     LAV_REQUIRE(!relu_post || y, "lav_bn_train_backward: relu_post needs the forward output y");
     LAV_REQUIRE(workspace_bytes >= lav_bn_train_workspace_bytes(channels), "lav_bn_train_backward: workspace smaller than lav_bn_train_workspace_bytes");
@@ -258,10 +296,10 @@ extern "C" int lav_bn_train_backward(const float *x, const float *y, const float
     const int tok = timer_begin("bn_train_bwd", st);
     if (vec_ok(hw, {x, y, dy, dx, dres})) {
         hipLaunchKernelGGL(k_bn_bwd_sums<true>, grid, dim3(256), 0, st, g, x, y, dy, save_mean, save_rstd, relu_pre, relu_post, dres, partial);
-        hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, st, g, x, y, g_src, mask_here, gamma, save_mean, save_rstd, relu_pre, partial, dx, dgamma, dbeta);
+        hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, st, g, x, y, g_src, mask_here, gamma, save_mean, save_rstd, relu_pre, partial, dx, dgamma, dbeta, amax_dx);
     } else {
         hipLaunchKernelGGL(k_bn_bwd_sums<false>, grid, dim3(256), 0, st, g, x, y, dy, save_mean, save_rstd, relu_pre, relu_post, dres, partial);
-        hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, st, g, x, y, g_src, mask_here, gamma, save_mean, save_rstd, relu_pre, partial, dx, dgamma, dbeta);
+        hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, st, g, x, y, g_src, mask_here, gamma, save_mean, save_rstd, relu_pre, partial, dx, dgamma, dbeta, amax_dx);
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();

@@ -70,8 +70,9 @@ class ResNet(_Engine):
 
     def forward_train(self, x):
         """Train mode (autograd, BatchNorm on batch statistics): plain torch ops over the same modules."""
-        from .train.hipnn import bn_act, conv_module as cv   # fused BatchNorm + ReLU (+ identity); convolutions on liblav_amd (round 5)
-        x = self.maxpool(bn_act(self.bn1, cv(self.conv1, x), relu_post=True))
+        from .train.hipnn import bn_act, carry, conv_module as cv   # fused BatchNorm + ReLU (+ identity); convolutions on liblav_amd (round 5)
+        y = bn_act(self.bn1, cv(self.conv1, x), relu_post=True)
+        x = carry(self.maxpool(y), y)
         for i in range(1, 5):
             for blk in getattr(self, f"layer{i}"):
                 identity = x if blk.downsample is None else bn_act(blk.downsample[1], blk.downsample[0](x))

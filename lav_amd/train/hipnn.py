@@ -33,6 +33,41 @@ def _workspace(channels: int, device) -> torch.Tensor:
     return ws
 
 
+def _bn_amax(B, C, hw, device):
+    """An ops.Amax for what a BatchNorm launch writes (lav_bn_train_*_amax), or None when the step does not run on fp16 pieces."""
+    if train_precision() != _lib.CONV_F16X3 or os.environ.get("LAV_TRAIN_BN_AMAX", "1") == "0":
+        return None
+    n = _lib.load().lav_bn_train_amax_count(int(B), int(C), int(hw))
+    if n <= 0:
+        return None
+    am = ops_mod.Amax(device, capacity=n, zeroed=False)     # (the launch writes every part)
+    am.take(n)
+    return am
+
+
+def _tag(t, am):
+    """Attach the bound to the tensor OBJECT it describes, with the tensor's version: a later in-place change (autograd accumulating a
+    second gradient into the buffer) voids it (_trusted)."""
+    if am is not None:
+        am.version = t._version
+        t._lav_amax = am
+    return t
+
+
+def _trusted(t):
+    am = getattr(t, "_lav_amax", None)
+    return am if am is not None and getattr(am, "version", None) == t._version else None
+
+
+def carry(out, src):
+    """`out` holds a subset / a maximum of the values of `src` (a max-pooling): src's bound holds for it."""
+    am = _trusted(src)
+    if am is not None:
+        import copy
+        _tag(out, copy.copy(am))      # (shares the parts; its own version stamp)
+    return out
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, eps, relu_pre, relu_post):
@@ -42,9 +77,11 @@ class _BnAct(torch.autograd.Function):
         y = torch.empty_like(x)
         save = torch.empty((3, C), dtype=torch.float32, device=x.device)   # mean, biased var, rstd
         ws = _workspace(C, x.device)
-        check(_lib.load().lav_bn_train_forward(_ptr(x), _ptr(res), _ptr(y), B, C, H * W, _ptr(gamma.contiguous()), _ptr(beta.contiguous()),
-                                               float(eps), int(relu_pre), int(relu_post), _ptr(save[0]), _ptr(save[1]), _ptr(save[2]),
-                                               _ptr(ws), ws.numel(), _stream()), "lav_bn_train_forward")
+        am = _bn_amax(B, C, H * W, x.device)
+        check(_lib.load().lav_bn_train_forward_amax(_ptr(x), _ptr(res), _ptr(y), B, C, H * W, _ptr(gamma.contiguous()), _ptr(beta.contiguous()),
+                                                    float(eps), int(relu_pre), int(relu_post), _ptr(save[0]), _ptr(save[1]), _ptr(save[2]),
+                                                    _ptr(am.buf) if am is not None else None, _ptr(ws), ws.numel(), _stream()), "lav_bn_train_forward")
+        _tag(y, am)        # the convolution that reads y takes its scale from here (conv2d below)
         ops_mod.train_work["bn_train_fwd_bytes"] += 4 * x.numel() * (3 + (res is not None))     # x twice, y once (+ the residual)
         ctx.save_for_backward(x, y if relu_post else None, gamma, save)
         ctx.cfg = (bool(relu_pre), bool(relu_post), residual is not None)
@@ -63,9 +100,11 @@ class _BnAct(torch.autograd.Function):
         dres = torch.empty_like(x) if (has_res and relu_post) else None
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
         ws = _workspace(C, x.device)
-        check(_lib.load().lav_bn_train_backward(_ptr(x), _ptr(y), _ptr(dy), B, C, H * W, _ptr(gamma.contiguous()), _ptr(save[0]), _ptr(save[2]),
-                                                int(relu_pre), int(relu_post), _ptr(dx), _ptr(dres), _ptr(dgb[0]), _ptr(dgb[1]),
-                                                _ptr(ws), ws.numel(), _stream()), "lav_bn_train_backward")
+        am = _bn_amax(B, C, H * W, x.device)
+        check(_lib.load().lav_bn_train_backward_amax(_ptr(x), _ptr(y), _ptr(dy), B, C, H * W, _ptr(gamma.contiguous()), _ptr(save[0]), _ptr(save[2]),
+                                                     int(relu_pre), int(relu_post), _ptr(dx), _ptr(dres), _ptr(dgb[0]), _ptr(dgb[1]),
+                                                     _ptr(am.buf) if am is not None else None, _ptr(ws), ws.numel(), _stream()), "lav_bn_train_backward")
+        _tag(dx, am)       # the convolution whose output this BatchNorm read takes its gradient's scale from here (_Conv2d.backward)
         # x and dy twice, dx once; relu_post reads y (twice without a residual, else once + the masked gradient written and re-read)
         ops_mod.train_work["bn_train_bwd_bytes"] += 4 * x.numel() * (5 + (2 if relu_post else 0))
         return dx, dgb[0], dgb[1], (dres if dres is not None else dy) if has_res else None, None, None, None
@@ -200,6 +239,7 @@ def _measure(t: torch.Tensor):
     """ops.Amax holding the maxima of the finite |t| (one launch, 512 parts): LAV_CONV_F16X3's activation scale, measured ONCE per
     tensor and step and handed to every kernel that reads the tensor (forward convolution + weight gradient for x, data gradient +
     weight gradient for dy) instead of once per launch."""
+    ops_mod.train_work["absmax_launches"] = ops_mod.train_work.get("absmax_launches", 0) + 1
     am = ops_mod.Amax(t.device, capacity=512, zeroed=False)      # (the launch writes all 512 parts: no fill kernel per measurement)
     check(_lib.load().lav_absmax_parts(_ptr(t), t.numel(), _ptr(am.take(512)), _stream()), "lav_absmax_parts")
     return am
@@ -207,10 +247,12 @@ def _measure(t: torch.Tensor):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, padding, dilation):
+    def forward(ctx, x, w, stride, padding, dilation, am_in=None):
         x = x.contiguous()
         eng = _conv_engine("fwd", w, stride, padding, dilation, False, 0)
-        am_x = _measure(x) if train_precision() == _lib.CONV_F16X3 and eng.uses_amax(*x.shape[:1], *x.shape[2:]) else None
+        am_x = None
+        if train_precision() == _lib.CONV_F16X3 and eng.uses_amax(*x.shape[:1], *x.shape[2:]):
+            am_x = am_in if am_in is not None else _measure(x)
         y = eng(x, amax_in=am_x)
         ctx.save_for_backward(x, w)
         ctx.am_x = am_x
@@ -221,9 +263,12 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padding, dilation = ctx.cfg
+        am_in = _trusted(dy)
         dy = dy.contiguous()
         dx = dw = None
-        am_dy = _measure(dy) if train_precision() == _lib.CONV_F16X3 and dy.numel() > 0 else None
+        am_dy = None
+        if train_precision() == _lib.CONV_F16X3 and dy.numel() > 0:
+            am_dy = am_in if am_in is not None else _measure(dy)
         lav_dgrad = os.environ.get("LAV_TRAIN_DGRAD", "hip") != "torch" and (stride == 1 or os.environ.get("LAV_TRAIN_DGRAD_STRIDED", "hip") == "hip")
         if ctx.needs_input_grad[0] and lav_dgrad:
             kh, kw = w.shape[2], w.shape[3]
@@ -248,7 +293,7 @@ class _Conv2d(torch.autograd.Function):
                 dw = gw
         if dw_hip is not None:
             dw = dw_hip
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def _wgrad_hip(x, dy, w, stride, padding, dilation, am_x=None, am_dy=None):
@@ -292,7 +337,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, stride: int = 1, padding=(0, 0), di
     if (not x.is_cuda or x.dtype != torch.float32 or w.dtype != torch.float32 or w.shape[2] < 3 or not torch.is_grad_enabled()
             or x.numel() == 0 or os.environ.get("LAV_TRAIN_CONV", "hip") == "torch"):
         return F.conv2d(x, w, None, stride, tuple(padding), tuple(dilation))
-    return _Conv2d.apply(x, w, int(stride), tuple(padding), tuple(dilation))
+    # (the bound a producer left on x - a BatchNorm of this module, a max-pool of one - is read HERE, from the object the caller holds)
+    return _Conv2d.apply(x, w, int(stride), tuple(padding), tuple(dilation), _trusted(x))
 
 
 class _ConvT2d(torch.autograd.Function):

@@ -459,6 +459,61 @@ def test_bn_act_forward_backward_vs_torch(shape, mode):
         assert (a - b).abs().max().item() <= 1e-4 * scale, (n, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("mode", ["relu_pre", "relu_post", "residual"])
+def test_bn_act_leaves_the_bounds_of_what_it_writes(mode):
+    """lav_bn_train_forward_amax / _backward_amax (round 6): under hipnn.use_precision("f16x3") the fused BatchNorm tags its output and
+    its input gradient with the per-workgroup maxima of what the launch wrote - exactly max |y| resp. max |dx| -, the convolution that
+    reads the tensor takes them (no measuring launch), an in-place change voids the tag, and the values are those of the untagged run."""
+    from lav_amd import ops
+    from lav_amd.train import hipnn
+    torch.manual_seed(7)
+    dev = torch.device("cuda")
+    B, C, H, W = 3, 64, 40, 48
+    x = (torch.randn((B, C, H, W)) * 2.0).to(dev).requires_grad_(True)
+    res = torch.randn((B, C, H, W)).to(dev) if mode == "residual" else None
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3).to(dev).train()
+    conv = torch.nn.Conv2d(C, 64, 3, 1, 1, bias=False).to(dev)
+    kw = dict(relu_pre=mode == "relu_pre", relu_post=mode in ("relu_post", "residual"))
+    with hipnn.use_precision("f16x3"):
+        y = hipnn.bn_act(bn, x, residual=res, **kw)
+        am = hipnn._trusted(y)
+        assert am is not None and am.count == _parts(B, C, H * W)
+        assert am.buf[:am.count].max().item() == y.detach().abs().max().item()
+        ops.train_work["absmax_launches"] = 0
+        z = hipnn.conv_module(conv, y)
+        assert ops.train_work["absmax_launches"] == 0, "the convolution measured a tensor that carried its bound"
+        seen = {}
+        y.register_hook(lambda g: seen.setdefault("am", hipnn._trusted(g)) and None)   # the gradient object the BatchNorm's backward will read
+        z.square().sum().backward()
+        gx = x.grad.clone()
+        # the BatchNorm's input gradient left its own bound
+        tag = hipnn._trusted(x.grad)
+        if tag is not None:     # (leaf gradients are accumulated into .grad by autograd: the object may be a copy)
+            assert tag.buf[:tag.count].max().item() == x.grad.abs().max().item()
+        # an in-place change voids a tag
+        y2 = hipnn.bn_act(bn, x.detach(), residual=res, **kw)
+        assert hipnn._trusted(y2) is not None
+        y2.mul_(2.0)
+        assert hipnn._trusted(y2) is None
+    # the same step without the tags (LAV_TRAIN_BN_AMAX=0): same bits
+    os.environ["LAV_TRAIN_BN_AMAX"] = "0"
+    try:
+        bn2 = torch.nn.BatchNorm2d(C, eps=1e-3).to(dev).train()
+        x2 = x.detach().clone().requires_grad_(True)
+        with hipnn.use_precision("f16x3"):
+            y3 = hipnn.bn_act(bn2, x2, residual=res, **kw)
+            assert hipnn._trusted(y3) is None
+            hipnn.conv_module(conv, y3).square().sum().backward()
+        assert torch.equal(y3, y) and torch.equal(x2.grad, gx)
+    finally:
+        os.environ.pop("LAV_TRAIN_BN_AMAX")
+
+
+def _parts(B, C, hw):
+    from lav_amd import _lib
+    return _lib.load().lav_bn_train_amax_count(B, C, hw)
+
+
 def test_heads_train_mode_fused_first_convolution_matches_per_head_modules():
     """LiDARModel.heads in train mode (one 384 -> 256 convolution + one BatchNorm launch pair over the four heads) against the
     four Head modules run one by one through torch ops: outputs, feature gradient, every parameter gradient, running stats."""
