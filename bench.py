@@ -187,15 +187,15 @@ def train_bench(args):
         # default - f16x3 (three fp16 ones): the executed rate against the dense 16-bit peak is 6x / 3x the algorithmic one
         from lav_amd.train import hipnn
         from lav_amd import _lib as _l
-        with hipnn.use_precision(cfg.conv_precision or ("f16x3" if what == "lidar" else "bf16x6")):
+        with hipnn.use_precision(cfg.conv_precision or "f16x3"):
             nprod = 3 if hipnn.train_precision() == _l.CONV_F16X3 else 6
         k = hk["kernels"]["conv_wgrad"]
         tf = hk["work_per_step"]["conv_wgrad_flops"] / (k["ms_per_step"] * 1e-3) / 1e12
         roofline["conv_wgrad"] = dict(bound="mfma", achieved=round(nprod * tf, 1), peak=2500.0, unit=f"TFLOP/s (16-bit MFMA, executed = {nprod} x algorithmic)",
                                       frac=round(nprod * tf / 2500.0, 4), executed_per_algorithmic=nprod,
                                       fp32_equivalent_tflops=round(tf, 1), ms_per_step=round(k["ms_per_step"], 3), launches_per_step=round(k["calls_per_step"], 1))
-        roofline["note"] = ("the 3x3 / 7x7 convolutions' forward and data gradients are lav_conv2d launches, their weight gradients lav_conv_wgrad (round 6, train_full: "
-                            "all three on two fp16 pieces per operand, every activation / gradient tensor measured once per step); transposed / 1x1 / small-map "
+        roofline["note"] = ("the 3x3 / 7x7 convolutions' forward and data gradients are lav_conv2d launches, their weight gradients lav_conv_wgrad (round 6: "
+                            "all three on two fp16 pieces per operand, the scales from the bounds the fused BatchNorm launches leave); transposed / 1x1 / small-map "
                             "weight-gradient convolutions stay on MIOpen")
     if rank == 0 and roofline is not None and hk and "bn_train_fwd" in hk["kernels"]:
         # the fused train-mode BatchNorm + ReLU (+ residual) pairs (lav_bn_train_*): HBM bound, algorithmic bytes = passes over the activation
@@ -208,7 +208,7 @@ def train_bench(args):
         print(json.dumps(dict(metric=f"samples/s {args.mode}_v2 (synthetic batch)", value=round(per * world * steps / dt, 2),
                               unit="samples/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
                               higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=("f32 (3x3 / 7x7 convolutions forward / data gradient / weight gradient: liblav_amd on the 16-bit matrix cores with fp32 operands split into "
-                                     + ("two scaled fp16 pieces, three products" if what == "lidar" and not os.environ.get("LAV_TRAIN_PRECISION", "").startswith("bf16") else "three bf16 pieces, six products")
+                                     + ("two scaled fp16 pieces, three products" if not os.environ.get("LAV_TRAIN_PRECISION", "").startswith("bf16") else "three bf16 pieces, six products")
                                      + ", f32 accumulate; transposed / 1x1 convolutions: MIOpen f32; BatchNorm+ReLU, pillar, crop, GRU: liblav_amd f32)"), data="synthetic",
                               config=dict(workload=f"{args.mode}_v2 step: fwd + bwd + Adam, per-GPU batch {per}, global batch {per * world}"
                                           + (f", 120000-point clouds, 320x320 maps; log-only eval inference every {args.log_every} step(s)"
