@@ -307,7 +307,8 @@ def _wgrad_hip(x, dy, w, stride, padding, dilation, am_x=None, am_dy=None):
     # (maps of at least 40 x 40 pixels: below that a task has too few 16-pixel steps behind its prologue and MIOpen wins -
     # profiles/r05_wgrad_probe.txt: 64 -> 64 @24x24 x 96 crops 92 vs 68 us)
     shape_ok = kh == kw and ((kh == 3 and stride in (1, 2)) or (kh == 7 and stride == 2)) and tuple(padding) == (kh // 2, kh // 2)
-    if not (shape_ok and tuple(dilation) == (1, 1) and W % (4 * stride) == 0 and H % stride == 0 and dy.shape[2] * dy.shape[3] >= 1600
+    min_pix = int(os.environ.get("LAV_TRAIN_WGRAD_MINPIX", "1600"))
+    if not (shape_ok and tuple(dilation) == (1, 1) and W % (4 * stride) == 0 and H % stride == 0 and dy.shape[2] * dy.shape[3] >= min_pix
             and cin % 64 == 0 and cout % 64 == 0 and dy.shape[2] == H // stride and dy.shape[3] == W // stride):
         return None
     if (stride == 2 and kh == 3 and os.environ.get("LAV_TRAIN_WGRAD_STRIDED", "hip") == "torch") or (
