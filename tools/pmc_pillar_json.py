@@ -30,7 +30,7 @@ def parse(path):
 fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
 mfma = parse(sys.argv[3]) if len(sys.argv) > 3 else {}
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE" + (" / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" if mfma else "") +
-       " (separate passes) on tools/pmc_pillar.py, MI355X, round 5 (k_bin / k_rows with 64-byte records, zeros written by k_rows: the round-5 default); FETCH_SIZE doubled per "
+       " (separate passes) on tools/pmc_pillar.py, MI355X, round 6 (k_bin / k_rows with 64-byte records, zeros written by k_rows, the canvas bound written by k_rows: the default); FETCH_SIZE doubled per "
        "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported; tools/pmc_pillar_json.py"}
 for k in ("k_rows", "k_bin"):
     res[k] = {}
