@@ -45,9 +45,13 @@ torch.cuda.synchronize()
 hp = torch.cuda.Stream(device, priority=-1)
 SKIP = {"all": set(), "no_brake": {"brake"}, "no_ego": {"ego"}, "chain": {"brake", "ego"}, "hp": set()}
 res = {v: [] for v in a.variants.split(",")}
+FORCED = {"n0": 0, "n4": 4}     # the others branch forced to that many fixed poses (bench.py's forced_others)
 for _ in range(a.rounds):
     for v in res:
-        frame_mod._DIAG_SKIP = SKIP[v]
+        if v in FORCED:
+            k = FORCED[v]
+            pipe.set_forced_others([[4.0 + 3.0 * j, -8.0 - 4.0 * j] for j in range(k)], [0.2 * j - 0.3 for j in range(k)])
+        frame_mod._DIAG_SKIP = SKIP.get(v, set())
         ctx = torch.cuda.stream(hp) if v == "hp" else torch.cuda.stream(torch.cuda.current_stream())
         with ctx:
             for _ in range(6):
@@ -58,6 +62,8 @@ for _ in range(a.rounds):
                 step()
             torch.cuda.synchronize()
             res[v].append(round((time.perf_counter() - t0) / a.steps * 1e3, 4))
+        if v in FORCED:
+            pipe.set_forced_others(None)
 frame_mod._DIAG_SKIP = set()
 
 
