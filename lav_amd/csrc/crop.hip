@@ -108,13 +108,21 @@ __device__ __forceinline__ SamplePos sample_pos(int x, int y, int crop, int H, i
 __global__ __launch_bounds__(256, 3) void k_crop_rotate_staged(const float *__restrict__ feat, int feat_batch, const int *__restrict__ map_index,
                                                                int C, int H, int W, const float *__restrict__ locs,
                                                                const float *__restrict__ oris, float ppm, int crop, float ox, float oy,
-                                                               float *__restrict__ out, const int *__restrict__ n_valid, int cpb) {
+                                                               float *__restrict__ out, const int *__restrict__ n_valid, int cpb, int nslab_crops) {
     __shared__ float s_f[FWD_SUB][FWD_CAP];
-    const int n = blockIdx.z;
+    // Workgroup -> (crop, channel block, tile), XCD aware (round 6): consecutive workgroups go to the eight XCDs in turn, and the tiles of
+    // one (crop, channel block) slab read overlapping boxes of the same 32 map planes - dealt out in launch order every XCD fetched its
+    // own copy of every halo from the memory side (2.85x the slab).  Here a slab's tiles all land on ONE XCD (slab = 8 (l / (8 tiles)) +
+    // l % 8, tile = (l / 8) % tiles): the overlaps are hits in that XCD's L2.
+    const int tiles_x = (crop + FWD_TILE - 1) / FWD_TILE, tiles = tiles_x * tiles_x;
+    const int cblocks = (C + cpb - 1) / cpb;
+    const int l = blockIdx.x;
+    const int slab = 8 * (l / (8 * tiles)) + (l & 7), tile = (l >> 3) % tiles;
+    const int n = slab / cblocks, cblk = slab - n * cblocks;
+    if (n >= nslab_crops) return;                          // (the launch is padded to whole groups of eight slabs)
     if (n_valid && n >= *n_valid) return;   // lav_batch_limit (workgroup-uniform)
     const int tid = threadIdx.x;
-    const int tiles_x = (crop + FWD_TILE - 1) / FWD_TILE;
-    const int ty0 = (int)(blockIdx.x / tiles_x) * FWD_TILE, tx0 = (int)(blockIdx.x % tiles_x) * FWD_TILE;
+    const int ty0 = (tile / tiles_x) * FWD_TILE, tx0 = (tile % tiles_x) * FWD_TILE;
     const int x = tx0 + (tid & (FWD_TILE - 1)), y = ty0 + tid / FWD_TILE;
     const bool live = x < crop && y < crop;
     const float o = oris[n];
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void k_crop_rotate_staged(const float *__re
     const int o10 = (sp.cy1 - by0) * bw + (sp.cx0 - bx0), o11 = (sp.cy1 - by0) * bw + (sp.cx1 - bx0);
     const long plane = (long)H * W, cc = (long)crop * crop;
     const int m = map_index ? map_index[n] : (feat_batch > 1 ? n : 0);
-    const int c_lo = blockIdx.y * cpb, nch = min(cpb, C - c_lo);   // cpb: channels per workgroup (8, 16 or 32: crop_launch)
+    const int c_lo = cblk * cpb, nch = min(cpb, C - c_lo);   // cpb: channels per workgroup (8, 16 or 32: crop_launch)
     const float *f = feat + ((long)m * C + c_lo) * plane;
     float *o_ = out + ((long)n * C + c_lo) * cc + (long)y * crop + x;
     // Staging (round 6).  Thread (c = tid / 32, column = tid % 32) fetches column `column` of channel c's box: at most 32 rows, ALL
@@ -249,17 +257,23 @@ __device__ __forceinline__ void preimage(const CropGeom &cg, float k, float step
 
 __global__ __launch_bounds__(256, 3) void k_crop_rotate_bwd(const float *__restrict__ g, int n, const int *__restrict__ map_index, int C, int H,
                                                          int W, const float *__restrict__ locs, const float *__restrict__ oris, float ppm,
-                                                         int crop, float ox, float oy, float *__restrict__ grad_feat) {
+                                                         int crop, float ox, float oy, float *__restrict__ grad_feat, int num_maps) {
     __shared__ CropGeom s_crop[256];
     __shared__ int s_wave_cnt[4];
     __shared__ float s_g[BWD_SUB][BWD_CAP];   // the output gradients the tile can touch, BWD_SUB channels at a time
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tiles_x = (W + BWD_TW - 1) / BWD_TW;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    // workgroup -> (map, channel block, tile), XCD aware like the forward kernel: the tiles of one (map, channel block) slab stage
+    // overlapping boxes of the same crops' gradient planes - all of them on one XCD (slab = 8 (l / (8 tiles)) + l % 8)
+    const int tiles_x = (W + BWD_TW - 1) / BWD_TW, tiles = tiles_x * ((H + BWD_TH - 1) / BWD_TH);
+    const int cblocks = (C + BWD_CPB - 1) / BWD_CPB;
+    const int l = blockIdx.x;
+    const int slab = 8 * (l / (8 * tiles)) + (l & 7), tile = (l >> 3) % tiles;
+    const int m = slab / cblocks, cblk = slab - m * cblocks;
+    if (m >= num_maps) return;     // (the launch is padded to whole groups of eight slabs; workgroup-uniform)
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int tx0 = tile_x * BWD_TW, ty0 = tile_y * BWD_TH;
     const int sx = tx0 + (tid & (BWD_TW - 1)), sy = ty0 + tid / BWD_TW;
-    const int m = blockIdx.z;
-    const int c_lo = blockIdx.y * BWD_CPB;
+    const int c_lo = cblk * BWD_CPB;
     const int nch = min(BWD_CPB, C - c_lo);
     const bool inside_map = sx < W && sy < H;
     const float k = (float)crop / (float)H;
@@ -483,8 +497,9 @@ int crop_launch(const float *feat, int nmaps, const int *map_index, int C, int H
         // profiles/r06_crop_probe.txt)
         static const int cpb_env = [] { const char *e = getenv("LAV_CROP_CPB"); return e ? atoi(e) : 0; }();   // (A/B knob: 8, 16 or 32)
         const int cpb = cpb_env == 8 || cpb_env == 16 || cpb_env == 32 ? cpb_env : (n <= 1 ? 16 : FWD_CPB);
-        hipLaunchKernelGGL(k_crop_rotate_staged, dim3(tiles * tiles, (C + cpb - 1) / cpb, n), dim3(256), 0, st, feat, nmaps, map_index, C,
-                           H, W, locs, oris, ppm, crop, ox, oy, out, lav::batch_limit(), cpb);
+        const long slabs = (long)n * ((C + cpb - 1) / cpb), groups = (slabs + 7) / 8;
+        hipLaunchKernelGGL(k_crop_rotate_staged, dim3((unsigned)(groups * 8 * tiles * tiles)), dim3(256), 0, st, feat, nmaps, map_index, C,
+                           H, W, locs, oris, ppm, crop, ox, oy, out, lav::batch_limit(), cpb, n);
     } else {
         dim3 grid((crop * crop + 255) / 256, (C + c_per_block - 1) / c_per_block, n);
         hipLaunchKernelGGL(k_crop_rotate, grid, dim3(256), 0, st, feat, nmaps, map_index, C, H, W, locs, oris, ppm, crop, ox, oy, c_per_block,
@@ -530,9 +545,11 @@ extern "C" int lav_crop_rotate_backward(const float *grad_out, int num_maps, con
     const int tw = staged ? BWD_TW : 32, th = staged ? BWD_TH : 8;
     dim3 grid(((W + tw - 1) / tw) * ((H + th - 1) / th), (C + BWD_CPB - 1) / BWD_CPB, num_maps);
     const int tok = timer_begin("crop_rotate_backward", st);
-    if (staged)
-        hipLaunchKernelGGL(k_crop_rotate_bwd, grid, dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris, pixels_per_meter, crop,
-                           offset_x, offset_y, grad_feat);
+    if (staged) {
+        const long slabs = (long)num_maps * grid.y, groups = (slabs + 7) / 8;
+        hipLaunchKernelGGL(k_crop_rotate_bwd, dim3((unsigned)(groups * 8 * grid.x)), dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris,
+                           pixels_per_meter, crop, offset_x, offset_y, grad_feat, num_maps);
+    }
     else
         hipLaunchKernelGGL(k_crop_rotate_bwd_general, grid, dim3(256), 0, st, grad_out, n, map_index, C, H, W, locs, oris, pixels_per_meter,
                            crop, offset_x, offset_y, grad_feat);
