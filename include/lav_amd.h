@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LAV_ABI_VERSION 27
+#define LAV_ABI_VERSION 28
 
 #define LAV_OK 0
 #define LAV_EINVAL (-1)    /* bad argument / unsupported shape */
@@ -424,6 +424,11 @@ int lav_copy_many(int n, const void *const *src, void *const *dst, const size_t 
  *     of a tick are channels-last views (lav_agent_fast.py:252-277: stack / permute / float). */
 int lav_stage_many(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
                    void *stream);
+/* lav_stage_many_block (ABI 28): the same launch, with up to 256 bytes of HOST data (a multiple of 4) riding in its kernel arguments and
+ *     written to block_dst in HBM by the kernel: the per-tick sweep indices and float32 poses that get_stacked_lidar computes on the host
+ *     (lav_agent_fast.py:363-383) - an upload of its own would be one more packet in front of the frame's first graph. */
+int lav_stage_many_block(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
+                         const void *block, int block_bytes, void *block_dst, void *stream);
 
 /* Small dense layer out[b][o] = act(bias[o] + sum_k weight[o][k] x[b][k]) (weight in nn.Linear layout [out][in], bias or NULL;
  * act 0 = none, 1 = sigmoid): the brake classifier nn.Sequential(Linear(1024, 1), Sigmoid) of team_code_v2/models/rgb.py:62,79. */
@@ -449,6 +454,14 @@ int lav_det_decode(const float *rows, int ncls, int max_det, int cls, double min
                    double near_px, double far_px, double min_box, double cx, double cy, double skip_px, double ppm,
                    float *actors, int *n_out, void *stream);
 int lav_batch_limit(const int *d_rows);
+/* lav_det_decode_report (ABI 28): lav_det_decode, and the same launch also writes the [ncls][max_det][7] peak rows to host_rows, the
+ *     count to host_n and then increments *host_seq (system-scope release) - three pointers into pinned, device-mapped HOST memory
+ *     (hipHostMalloc).  The reference reads every detection back to the host (model_inference.py:101-108); here the host polls
+ *     host_seq instead of fetching rows and count with two device->host copies and an event between the heads and the others
+ *     graph.  All three NULL = lav_det_decode. */
+int lav_det_decode_report(const float *rows, int ncls, int max_det, int cls, double min_score, double ego_x, double ego_y,
+                          double near_px, double far_px, double min_box, double cx, double cy, double skip_px, double ppm,
+                          float *actors, int *n_out, float *host_rows, int *host_n, unsigned *host_seq, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7. Training-side pillar ops: what PointPillarNet needs in train mode, where BatchNorm1d uses batch

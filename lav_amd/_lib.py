@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAV_AMD_LIB") or os.path.join(HERE, "liblav_amd.so")   # LAV_AMD_LIB: A/B a second build
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 MAX_CAM = 4
 
 
@@ -114,6 +114,8 @@ SIGNATURES = {
     "lav_copy_many": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_Z), _P]),
     "lav_stage_many": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I), C.POINTER(C.c_long), C.POINTER(_I), _P]),
     "lav_det_decode": (_I, [_P, _I, _I, _I] + [C.c_double] * 10 + [_P, _P, _P]),
+    "lav_det_decode_report": (_I, [_P, _I, _I, _I] + [C.c_double] * 10 + [_P, _P, _P, _P, _P, _P]),
+    "lav_stage_many_block": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I), C.POINTER(C.c_long), C.POINTER(_I), _P, _I, _P, _P]),
     "lav_batch_limit": (_I, [_P]),
     "lav_pool_affine": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _P]),
     "lav_merge_ticks": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -419,7 +419,8 @@ extern "C" int lav_extract_peaks(const float *heat, int ncls, int h, int w, int 
 namespace {
 __global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ rows, int cls, int max_det, double min_score, double ego_x,
                                                    double ego_y, double near_px, double far_px, double min_box, double cx, double cy,
-                                                   double skip_px, double ppm, float *__restrict__ actors, int *__restrict__ n_out) {
+                                                   double skip_px, double ppm, float *__restrict__ actors, int *__restrict__ n_out,
+                                                   int ncls, float *host_rows, int *host_n, unsigned *host_seq) {
     const int j = threadIdx.x;
     bool ok = false;
     double X = 0, Y = 0, co = 1, si = 0;
@@ -446,16 +447,39 @@ __global__ __launch_bounds__(64) void k_det_decode(const float *__restrict__ row
         actors[2 * max_det + pos] = (float)atan2(si, co);
     }
     if (j == 0) *n_out = __popcll(m);
+    if (host_rows) {
+        // lav_det_decode_report: the peak rows and the count also go to host-visible (pinned, device-mapped) memory from inside this
+        // launch, and a sequence word behind them - what the caller would otherwise fetch with two device->host copies and an event
+        // between the heads and the others graph (three packets on the frame's critical chain).  System-scope release: the rows are
+        // out of this wave's write path before the word that announces them.
+        const int total = ncls * max_det * 7;
+        for (int i = j; i < total; i += 64) __builtin_nontemporal_store(rows[i], host_rows + i);
+        if (j == 0) __builtin_nontemporal_store((int)__popcll(m), host_n);
+        __builtin_amdgcn_s_waitcnt(0);
+        __threadfence_system();
+        __syncthreads();
+        if (j == 0) __hip_atomic_store(host_seq, __hip_atomic_load(host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 }  // namespace
+
+extern "C" int lav_det_decode_report(const float *rows, int ncls, int max_det, int cls, double min_score, double ego_x, double ego_y,
+                                     double near_px, double far_px, double min_box, double cx, double cy, double skip_px, double ppm,
+                                     float *actors, int *n_out, float *host_rows, int *host_n, unsigned *host_seq, void *stream) {
+    LAV_REQUIRE(rows && actors && n_out, "lav_det_decode: null argument");
+    LAV_REQUIRE(ncls >= 1 && cls >= 0 && cls < ncls && max_det >= 1 && max_det <= 64, "lav_det_decode: bad sizes (max_det <= 64)");
+    LAV_REQUIRE((host_rows != nullptr) == (host_n != nullptr) && (host_rows != nullptr) == (host_seq != nullptr),
+                "lav_det_decode_report: host_rows, host_n and host_seq go together");
+    hipLaunchKernelGGL(k_det_decode, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), rows, cls, max_det, min_score, ego_x, ego_y,
+                       near_px, far_px, min_box, cx, cy, skip_px, ppm, actors, n_out, ncls, host_rows, host_n, host_seq);
+    LAV_LAUNCH_CHECK();
+    return LAV_OK;
+}
 
 extern "C" int lav_det_decode(const float *rows, int ncls, int max_det, int cls, double min_score, double ego_x, double ego_y,
                               double near_px, double far_px, double min_box, double cx, double cy, double skip_px, double ppm,
                               float *actors, int *n_out, void *stream) {
-    LAV_REQUIRE(rows && actors && n_out, "lav_det_decode: null argument");
-    LAV_REQUIRE(ncls >= 1 && cls >= 0 && cls < ncls && max_det >= 1 && max_det <= 64, "lav_det_decode: bad sizes (max_det <= 64)");
-    hipLaunchKernelGGL(k_det_decode, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), rows, cls, max_det, min_score, ego_x, ego_y,
-                       near_px, far_px, min_box, cx, cy, skip_px, ppm, actors, n_out);
-    LAV_LAUNCH_CHECK();
-    return LAV_OK;
+    return lav_det_decode_report(rows, ncls, max_det, cls, min_score, ego_x, ego_y, near_px, far_px, min_box, cx, cy, skip_px, ppm, actors, n_out,
+                                 nullptr, nullptr, nullptr, stream);
 }

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void k_copy_many(CopyArgs a) {
 // the agent hands over are channels-last views (lav_agent_fast.py:252-277: stack / permute / float), the frame graphs read
 // contiguous NCHW buffers.
 constexpr int STAGE_MAX = 8;
+constexpr int STAGE_BLOCK_WORDS = 64;
 struct StageArgs {
     const void *src[STAGE_MAX];
     float *dst[STAGE_MAX];
@@ -210,9 +211,15 @@ struct StageArgs {
     long strides[STAGE_MAX][4];   // source strides in elements
     int is_u8[STAGE_MAX];
     int n;
+    // lav_stage_many_block: a small block of host data riding in the kernel arguments (the frame's 176 bytes of sweep indices and
+    // poses: an upload of its own is one more packet in front of the frame's first graph)
+    int block_words;
+    unsigned *block_dst;
+    unsigned block[STAGE_BLOCK_WORDS];
 };
 __global__ __launch_bounds__(256) void k_stage_many(StageArgs a) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.block_words) a.block_dst[threadIdx.x] = a.block[threadIdx.x];
     int k = 0;
     while (k < a.n && i >= a.end[k]) ++k;
     if (k >= a.n) return;
@@ -230,11 +237,17 @@ __global__ __launch_bounds__(256) void k_stage_many(StageArgs a) {
 }
 }  // namespace
 
-extern "C" int lav_stage_many(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
-                              void *stream) {
+extern "C" int lav_stage_many_block(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
+                                    const void *block, int block_bytes, void *block_dst, void *stream) {
     LAV_REQUIRE(n >= 0 && n <= STAGE_MAX && (n == 0 || (src && dst && dims && strides && src_is_u8)), "lav_stage_many: at most %d tensors", STAGE_MAX);
-    if (n == 0) return LAV_OK;
+    LAV_REQUIRE(block_bytes >= 0 && block_bytes <= 4 * STAGE_BLOCK_WORDS && block_bytes % 4 == 0 && (block_bytes == 0 || (block && block_dst)),
+                "lav_stage_many_block: a block of at most %d bytes, a multiple of 4", 4 * STAGE_BLOCK_WORDS);
+    if (n == 0 && block_bytes == 0) return LAV_OK;
     StageArgs a;
+    a.block_words = block_bytes / 4;
+    a.block_dst = static_cast<unsigned *>(block_dst);
+    memset(a.block, 0, sizeof(a.block));
+    if (block_bytes) memcpy(a.block, block, (size_t)block_bytes);
     long total = 0;
     for (int i = 0; i < STAGE_MAX; ++i) {
         if (i < n) {
@@ -256,9 +269,14 @@ extern "C" int lav_stage_many(int n, const void *const *src, float *const *dst, 
         a.end[i] = total;
     }
     a.n = n;
-    hipLaunchKernelGGL(k_stage_many, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(k_stage_many, dim3((unsigned)((total + 255) / 256 > 0 ? (total + 255) / 256 : 1)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
+}
+
+extern "C" int lav_stage_many(int n, const void *const *src, float *const *dst, const int *dims, const long *strides, const int *src_is_u8,
+                              void *stream) {
+    return lav_stage_many_block(n, src, dst, dims, strides, src_is_u8, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int lav_maxpool3x3s2(const float *x, int batch, int channels, int h, int w, float *y, void *stream) {

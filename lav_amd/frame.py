@@ -22,6 +22,9 @@ from .model_inference import InferModel
 
 GAP = 5  # NUM_REPEAT + 1 (lav_agent_fast.py:32-33)
 _COPY_STREAM = os.environ.get("LAV_COPY_STREAM", "0") == "1"   # the frame's device-to-host copies on a stream of their own: measured 0.10 ms SLOWER with the side streams on (round 6, profiles/r06_frame_experiments.txt); off
+_DET_REPORT = os.environ.get("LAV_DET_REPORT", "1") != "0"   # round 6: lav_det_decode writes the peak rows + count into pinned host memory itself and bumps a sequence word the host polls (no device->host copies, no event between the heads and the others graph)
+_POSE_BLOCK = os.environ.get("LAV_POSE_BLOCK", "1") != "0"   # round 6: the 176-byte pose block rides in the staging launch's kernel arguments (no upload of its own in front of the lidar graph)
+_BRAKE_AFTER = os.environ.get("LAV_BRAKE_AFTER", "in")       # "in": the brake graph starts with the frame (beside ERFNet + backbone); "feat": behind the lidar graph (beside heads / others / ego)
 _DIAG_SKIP = set(filter(None, os.environ.get("LAV_DIAG_SKIP", "").split(",")))   # timing diagnosis: skip side graphs
 
 
@@ -188,6 +191,8 @@ class GraphedFramePipeline(FramePipeline):
         self.hn_det, self.hn_actors = self.h_det.numpy(), self.h_actors.numpy()
         self.d_n = torch.zeros((1,), dtype=torch.int32, device=dev)               # number of other vehicles, device resident
         self.h_n = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.h_seq = torch.zeros((1,), dtype=torch.int32).pin_memory()             # bumped by lav_det_decode_report once rows + count are on the host
+        self.hn_seq = self.h_seq.numpy()
         self.ev_det, self.ev_end = torch.cuda.Event(), torch.cuda.Event()
         self.b_features = None   # (1,384,160,160): written by the lidar graph, read by heads / ego / others
         self.b_locs, self.b_oris = self.d_actors[:30].view(15, 2), self.d_actors[30:]
@@ -262,7 +267,8 @@ class GraphedFramePipeline(FramePipeline):
             H, W = im._bev_hw
             ops.det_decode(det_raw, self.d_actors, self.d_n, cls=1, min_score=0.2, ego_xy=(160, 280), near_px=2.0,
                            far_px=30 * im.pixels_per_meter, min_box=0.1 * im.pixels_per_meter,
-                           centre_xy=(float(W / 2 + ox * W / 2), float(H / 2 + oy * H / 2)), skip_px=4.0, ppm=up.pixels_per_meter)
+                           centre_xy=(float(W / 2 + ox * W / 2), float(H / 2 + oy * H / 2)), skip_px=4.0, ppm=up.pixels_per_meter,
+                           report=(self.h_det, self.h_n, self.h_seq) if _DET_REPORT else None)
             if self.forced_others is not None:   # measurement hook (set_forced_others): fixed poses instead of the detections
                 self.d_actors.copy_(self.forced_others[0]); self.d_n.copy_(self.forced_others[1])
         return dict(det_raw=det_raw, pred_bev=pred_bev)
@@ -339,7 +345,7 @@ class GraphedFramePipeline(FramePipeline):
             g.replay()
         return self.outs[key]
 
-    def _set_pose_buffers(self):
+    def _set_pose_buffers(self, upload=True):
         """History indices and the float32 rotation / translation of every stacked sweep (lav_agent_fast.py:363-383,
         547-565), computed on the host exactly like the reference and uploaded as three tiny tensors."""
         n_hist = min(self.frame_no + 1, self.num_frame_keep)
@@ -362,7 +368,8 @@ class GraphedFramePipeline(FramePipeline):
         self.hn_sweeps[:] = sweeps
         self.hn_R[:] = np.asarray(Rs, np.float64).astype(np.float32)
         self.hn_t[:] = np.asarray(ts, np.float64).astype(np.float32)
-        self.d_pose.copy_(self.h_pose, non_blocking=True)
+        if upload:
+            self.d_pose.copy_(self.h_pose, non_blocking=True)
 
     @torch.no_grad()
     @_at_frame_precision
@@ -404,31 +411,40 @@ class GraphedFramePipeline(FramePipeline):
                     st = self._h2d_stage[key] = torch.empty_like(t, device=self.device)   # (preserve_format: dense layouts keep their strides)
                 st.copy_(t, non_blocking=t.is_pinned())
                 pairs[k] = (b, st)
-        if all(isinstance(t, torch.Tensor) and t.is_cuda and t.shape == b.shape for b, t in pairs):
-            ops.copy_many(pairs)
-        else:
-            for b, t in pairs:
-                b.copy_(t, non_blocking=True)
-        if n < self.P:
-            self.b_tick[n:].fill_(float("nan"))
         self.poses.append((np.asarray(loc, np.float64), float(ori)))
         if len(self.poses) > self.num_frame_keep:
             self.poses.popleft()
-        self._set_pose_buffers()
+        if all(isinstance(t, torch.Tensor) and t.is_cuda and t.shape == b.shape for b, t in pairs):
+            self._set_pose_buffers(upload=not _POSE_BLOCK)
+            ops.copy_many(pairs, block=(self.d_pose, self.h_pose) if _POSE_BLOCK else None)
+        else:
+            for b, t in pairs:
+                b.copy_(t, non_blocking=True)
+            self._set_pose_buffers()
+        if n < self.P:
+            self.b_tick[n:].fill_(float("nan"))
         cmd_value = int(cmd_value)
         main = torch.cuda.current_stream()
-        self.ev_in.record(main)                                        # inputs are in their static buffers
+        brake_late = _BRAKE_AFTER == "feat"
+        if not brake_late:
+            self.ev_in.record(main)                                    # inputs are in their static buffers
         self._stamp("inputs enqueued")
         o_lidar = self._replay("lidar", self._g_lidar, self.s_cap)
         self._stamp("lidar graph launched")
-        self.s_bra.wait_event(self.ev_in)
-        with torch.cuda.stream(self.s_bra):
-            o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
+        if not brake_late:
+            self.s_bra.wait_event(self.ev_in)
+            with torch.cuda.stream(self.s_bra):
+                o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
         self.ev_feat.record(main)                                      # feature map complete
+        if brake_late:
+            self.s_bra.wait_event(self.ev_feat)
+            with torch.cuda.stream(self.s_bra):
+                o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
         self.s_ego.wait_event(self.ev_feat)
         with torch.cuda.stream(self.s_ego):
             o_ego = self._replay(("ego", cmd_value), self._g_ego, self.s_ego, cmd_value,
                                  _skip="ego" in _DIAG_SKIP and ("ego", cmd_value) in self.graphs)
+        seq0 = int(self.hn_seq[0])
         o_heads = self._replay("heads", self._g_heads, self.s_cap)
         self._stamp("brake, ego, heads graphs launched")
         self.frame_no += 1
@@ -445,7 +461,7 @@ class GraphedFramePipeline(FramePipeline):
                     self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
                     self.h_n.copy_(self.d_n, non_blocking=True)
                     self.ev_det.record(self.s_copy)
-            else:
+            elif not _DET_REPORT:
                 self.h_det.copy_(o_heads["det_raw"], non_blocking=True)
                 self.h_n.copy_(self.d_n, non_blocking=True)
                 self.ev_det.record(main)
@@ -455,7 +471,10 @@ class GraphedFramePipeline(FramePipeline):
             if _COPY_STREAM:
                 main.wait_stream(self.s_copy)     # (the next frame's heads graph rewrites the rows being copied)
             self._stamp("others graph launched")
-            self.ev_det.synchronize()
+            if _DET_REPORT and not _COPY_STREAM:
+                self._wait_report(seq0)
+            else:
+                self.ev_det.synchronize()
             self._stamp("heads done on the GPU (event)")
             if not np.isfinite(self.hn_det).all():   # the peak rows are on the host every frame: their check costs no launch
                 self.nonfinite_det_frames += 1
@@ -506,6 +525,21 @@ class GraphedFramePipeline(FramePipeline):
         return dict(ego_embd=o_ego["ego_embd"], ego_plan_locs=o_ego["ego_plan_locs"], ego_cast_locs=o_ego["ego_cast_locs"],
                     other_cast_locs=other_cast, other_cast_cmds=other_cmds, pred_bev=o_heads["pred_bev"],
                     det=det, pred_bra=o_bra["pred_bra"], lidar_points=o_lidar["lidar_points"])
+
+    def _wait_report(self, seq0, timeout_s=10.0):
+        """Spin until lav_det_decode_report has bumped the pinned sequence word past `seq0`: the peak rows and the count it wrote before
+        the word are then in h_det / h_n (system-scope release on the device, loads in program order here)."""
+        hs, spins, t_end = self.hn_seq, 0, None
+        while int(hs[0]) == seq0:
+            spins += 1
+            if spins & 0x3ff == 0:
+                now = time.perf_counter()
+                if t_end is None:
+                    t_end = now + timeout_s
+                elif now > t_end:
+                    torch.cuda.synchronize()
+                    if int(hs[0]) == seq0:
+                        raise RuntimeError("lav_det_decode_report: the heads graph completed without reporting its peak rows to the host")
 
     @torch.no_grad()
     @_at_frame_precision

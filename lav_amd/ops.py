@@ -827,16 +827,25 @@ def crop_rotate_indexed(features, map_index, locs, oris, pixels_per_meter, crop,
 
 
 def det_decode(rows: torch.Tensor, actors: torch.Tensor, n_out: torch.Tensor, *, cls: int, min_score: float, ego_xy, near_px: float,
-               far_px: float, min_box: float, centre_xy, skip_px: float, ppm: float):
+               far_px: float, min_box: float, centre_xy, skip_px: float, ppm: float, report=None):
     """Peak rows (ncls, max_det, 7) of lav_extract_peaks -> the other vehicles' ego-frame (x, y) and headings in `actors`
-    ([2*max_det] + [max_det] floats) and their number in `n_out` (int32[1]), all in HBM (lav_det_decode)."""
+    ([2*max_det] + [max_det] floats) and their number in `n_out` (int32[1]), all in HBM (lav_det_decode).
+    report = (host_rows float32 like rows, host_n int32[1], host_seq int32[1]), three PINNED host tensors: the launch also writes rows
+    and count there and then increments host_seq (lav_det_decode_report) - the host polls the word instead of copying."""
     rows = _f32c(rows, "rows")
     ncls, max_det, _ = rows.shape
     if actors.numel() < 3 * max_det or actors.dtype != torch.float32 or n_out.dtype != torch.int32:
         raise RuntimeError("det_decode: actors must hold 3*max_det float32, n_out one int32")
-    check(_lib.load().lav_det_decode(_ptr(rows), ncls, max_det, int(cls), float(min_score), float(ego_xy[0]), float(ego_xy[1]),
-                                     float(near_px), float(far_px), float(min_box), float(centre_xy[0]), float(centre_xy[1]),
-                                     float(skip_px), float(ppm), _ptr(actors), _ptr(n_out), _stream()), "lav_det_decode")
+    host = [None, None, None]
+    if report is not None:
+        h_rows, h_n, h_seq = report
+        if not (h_rows.is_pinned() and h_n.is_pinned() and h_seq.is_pinned() and h_rows.is_contiguous()) or h_rows.dtype != torch.float32 \
+                or h_rows.numel() < rows.numel() or h_n.dtype != torch.int32 or h_seq.dtype != torch.int32:
+            raise RuntimeError("det_decode: report = (pinned float32 rows, pinned int32[1] count, pinned int32[1] sequence word)")
+        host = [h_rows.data_ptr(), h_n.data_ptr(), h_seq.data_ptr()]
+    check(_lib.load().lav_det_decode_report(_ptr(rows), ncls, max_det, int(cls), float(min_score), float(ego_xy[0]), float(ego_xy[1]),
+                                            float(near_px), float(far_px), float(min_box), float(centre_xy[0]), float(centre_xy[1]),
+                                            float(skip_px), float(ppm), _ptr(actors), _ptr(n_out), *host, _stream()), "lav_det_decode")
 
 
 class batch_limit:
@@ -887,11 +896,13 @@ def nonfinite_count(tensors, counter: torch.Tensor) -> None:
                                           _ptr(counter), _stream()), "lav_nonfinite_count")
 
 
-def copy_many(pairs) -> None:
+def copy_many(pairs, block=None) -> None:
     """[(dst, src), ...] device tensors of equal shape into their destinations in at most two launches: contiguous same-dtype
     16-byte-aligned pairs through lav_copy_many (16-byte words), strided / uint8 sources of up to four dimensions into contiguous
     float32 destinations through lav_stage_many (the conversion torch's copy_ would do, for all of them at once); anything else
-    takes Tensor.copy_."""
+    takes Tensor.copy_.
+    block = (dst device tensor, src HOST tensor of the same <= 256 bytes, a multiple of 4): rides in the staging launch's kernel
+    arguments (lav_stage_many_block) instead of an upload of its own; copied with Tensor.copy_ when there is no such launch."""
     srcs, dsts, sizes, stage, plain = [], [], [], [], []
     for dst, src in pairs:
         nb = dst.numel() * dst.element_size()
@@ -912,6 +923,15 @@ def copy_many(pairs) -> None:
         n = len(srcs[i:i + 8])
         check(lib.lav_copy_many(n, (C.c_void_p * n)(*srcs[i:i + 8]), (C.c_void_p * n)(*dsts[i:i + 8]), (C.c_size_t * n)(*sizes[i:i + 8]), _stream()),
               "lav_copy_many")
+    blk = (None, 0, None)
+    if block is not None:
+        bdst, bsrc = block
+        nb = bsrc.numel() * bsrc.element_size()
+        if (stage and not bsrc.is_cuda and bsrc.is_contiguous() and bdst.is_cuda and bdst.is_contiguous() and nb % 4 == 0 and 0 < nb <= 256
+                and nb == bdst.numel() * bdst.element_size() and bdst.data_ptr() % 4 == 0):
+            blk = (bsrc.data_ptr(), nb, bdst.data_ptr())
+        else:
+            bdst.copy_(bsrc, non_blocking=True)
     for i in range(0, len(stage), 8):
         part = stage[i:i + 8]
         n = len(part)
@@ -920,9 +940,10 @@ def copy_many(pairs) -> None:
             pad = 4 - src.dim()
             dims += [1] * pad + list(src.shape)
             strides += [0] * pad + list(src.stride())
-        check(lib.lav_stage_many(n, (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in part]), (C.c_void_p * n)(*[d.data_ptr() for d, _ in part]),
-                                 (C.c_int * (4 * n))(*dims), (C.c_long * (4 * n))(*strides),
-                                 (C.c_int * n)(*[int(s_.dtype == torch.uint8) for _, s_ in part]), _stream()), "lav_stage_many")
+        b = blk if i == 0 else (None, 0, None)
+        check(lib.lav_stage_many_block(n, (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in part]), (C.c_void_p * n)(*[d.data_ptr() for d, _ in part]),
+                                       (C.c_int * (4 * n))(*dims), (C.c_long * (4 * n))(*strides),
+                                       (C.c_int * n)(*[int(s_.dtype == torch.uint8) for _, s_ in part]), b[0], b[1], b[2], _stream()), "lav_stage_many")
 
 
 def linear_act(x: torch.Tensor, weight: torch.Tensor, bias, sigmoid: bool = False) -> torch.Tensor:

@@ -145,6 +145,60 @@ def test_det_decode_on_device_matches_host_rules():
     assert len(seen) >= 5
 
 
+def test_det_decode_reports_rows_and_count_to_pinned_host_memory():
+    """lav_det_decode_report: the same launch leaves the peak rows and the count in pinned host memory and then bumps a sequence word
+    (what the frame polls instead of two device->host copies and an event): once the word has moved, rows and count are the
+    device's, bit for bit, launch after launch - eagerly and replayed from a HIP graph."""
+    import time
+    rng = np.random.default_rng(5)
+    actors = torch.zeros(45, device=DEV)
+    n_out = torch.zeros(1, dtype=torch.int32, device=DEV)
+    h_rows = torch.zeros((2, 15, 7), dtype=torch.float32).pin_memory()
+    h_n = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+    h_seq = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    d_rows = torch.zeros((2, 15, 7), device=DEV)
+    kw = dict(cls=1, min_score=0.2, ego_xy=(160, 280), near_px=2.0, far_px=120.0, min_box=0.4, centre_xy=(160.0, 240.0), skip_px=4.0, ppm=4.0)
+
+    def wait(seq0):
+        t0 = time.perf_counter()
+        while int(h_seq.numpy()[0]) == seq0:
+            assert time.perf_counter() - t0 < 10.0, "the sequence word never moved"
+
+    def fresh():
+        rows = rng.uniform(0.0, 1.0, (2, 15, 7)).astype(np.float32)
+        rows[..., 1:3] = rng.integers(0, 320, (2, 15, 2))
+        return rows
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.det_decode(d_rows, actors, n_out, report=(h_rows, h_n, h_seq), **kw)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        ops.det_decode(d_rows, actors, n_out, report=(h_rows, h_n, h_seq), **kw)
+    torch.cuda.synchronize()
+    for trial in range(30):
+        rows = fresh()
+        d_rows.copy_(torch.from_numpy(rows))
+        torch.cuda.synchronize()
+        seq0 = int(h_seq.numpy()[0])
+        if trial % 2:
+            g.replay()
+        else:
+            ops.det_decode(d_rows, actors, n_out, report=(h_rows, h_n, h_seq), **kw)
+        wait(seq0)                                            # no synchronize: the word is the only hand-off
+        got_rows, got_n = h_rows.numpy().copy(), int(h_n.numpy()[0])
+        assert int(h_seq.numpy()[0]) == seq0 + 1
+        np.testing.assert_array_equal(got_rows, rows)
+        assert got_n == int(n_out.cpu()[0])
+    # without the report the plain entry point leaves the host words alone
+    seq0 = int(h_seq.numpy()[0])
+    ops.det_decode(d_rows, actors, n_out, **kw)
+    torch.cuda.synchronize()
+    assert int(h_seq.numpy()[0]) == seq0
+    with pytest.raises(RuntimeError):
+        ops.det_decode(d_rows, actors, n_out, report=(torch.zeros(2, 15, 7), h_n, h_seq), **kw)   # not pinned
+
+
 def test_batch_limit_skips_rows_on_the_device():
     """ops.batch_limit: conv / crop / cast launches of a capacity-sized batch leave the rows beyond the device-resident count
     untouched and compute the live rows exactly as an unlimited launch does."""

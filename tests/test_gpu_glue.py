@@ -272,3 +272,21 @@ def test_copy_many_stages_strided_and_uint8_tensors_like_copy_():
     for d, s in zip(dsts, srcs):
         want = torch.empty_like(d); want.copy_(s)
         assert torch.equal(d, want)
+    # lav_stage_many_block: 176 bytes of host data ride in the same launch's kernel arguments (the frame's pose block); the host
+    # buffer may change right after the call
+    blk = torch.randint(0, 256, (176,), dtype=torch.uint8)
+    want_blk = blk.clone()
+    d_blk = torch.zeros(176, dtype=torch.uint8, device=DEV)
+    for d in dsts:
+        d.fill_(-7.0)
+    ops.copy_many(list(zip(dsts, srcs)), block=(d_blk, blk))
+    blk.zero_()
+    assert torch.equal(d_blk.cpu(), want_blk)
+    for d, s in zip(dsts, srcs):
+        want = torch.empty_like(d); want.copy_(s)
+        assert torch.equal(d, want)
+    # a block that does not fit the arguments (or no staging launch to ride in) takes Tensor.copy_
+    big = torch.randint(0, 256, (512,), dtype=torch.uint8)
+    d_big = torch.zeros(512, dtype=torch.uint8, device=DEV)
+    ops.copy_many(list(zip(dsts, srcs)), block=(d_big, big))
+    assert torch.equal(d_big.cpu(), big)
