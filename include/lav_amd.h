@@ -577,6 +577,16 @@ int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, con
                           const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
                           const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
                           const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream);
+/* lav_conv1d_pair_chain_f16 (ABI 28): the same run, same arguments and contract, on TWO power-of-two-scaled fp16 pieces per operand and
+ * three matrix products instead of three bf16 pieces and six (LAV_CONV_F16X3 for ERFNet's runs: half the matrix instructions, 2/3 of the
+ * weight bytes a row streams per pair).  The weights' scale comes from lav_conv1d_pair_pack_weights (which packs all three forms); the
+ * activations' scale is derived per workgroup and pair from the largest finite magnitude of the three rows it multiplies (the
+ * neighbours' maxima travel with the hand-off), the intermediate row's from a bound (largest input x largest L1 norm of a filter +
+ * largest |bias|).  Error: that of an fp32 dot product (tests/test_gpu_conv.py, against float64); not bit-identical to the bf16 run. */
+int lav_conv1d_pair_chain_f16(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
+                              const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
+                              const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
+                              const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream);
 int lav_conv1d_pair_chain_status(const void *workspace, int *h_timeouts_launches2, void *stream);
 size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b);
 int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,

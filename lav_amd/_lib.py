@@ -94,6 +94,7 @@ SIGNATURES = {
     "lav_conv1d_pair_chain_workspace_bytes": (_Z, [_I, _I]),
     "lav_conv1d_pair_chain_lds_bytes": (_Z, [_I, _I, _I]),
     "lav_conv1d_pair_chain": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P] + [C.POINTER(_P)] * 7 + [_P, _Z, _P]),
+    "lav_conv1d_pair_chain_f16": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P] + [C.POINTER(_P)] * 7 + [_P, _Z, _P]),
     "lav_conv1d_pair_chain_status": (_I, [_P, C.POINTER(_I), _P]),
     "lav_conv1d_pair_lds_bytes": (_Z, [_I, _I, _I]),
     "lav_conv1d_pair": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

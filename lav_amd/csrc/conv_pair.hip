@@ -828,6 +828,394 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
 #undef CH_MARK
 }
 
+// ------------------------------------------------------------------------------------------------ persistent chain, fp16 pieces
+// Round 6 (LAV_CONV_F16X3 for ERFNet's runs): the same run on TWO fp16 pieces per operand and THREE v_mfma_f32_32x32x16_f16 per 16
+// k-steps instead of three bf16 pieces and six products - half the matrix instructions, 2/3 of the weight bytes a row workgroup
+// streams per pair (393 instead of 590 KB at 128 channels), 2/3 of the LDS operand traffic.  fp16 has five exponent bits, so every
+// operand is scaled by a power of two first (exact): the weights by their convolution's largest magnitude at packing time (the
+// scale rides behind the packed pieces), the activations by a scale the WORKGROUP derives per pair from the largest finite
+// magnitude of the three rows it multiplies - its own row's maximum (a wave reduction in the epilogue that produced the row) and
+// the two neighbour rows' maxima, which travel with the hand-off: a row publishes rowmax[pair][row] before it raises its progress
+// counter.  The intermediate row (ReLU of the vertical convolution) is scaled by a BOUND instead of its maximum - (largest input
+// magnitude) x (largest L1 norm of a filter, from the packing) + largest |bias| - so that no barrier is added between the two
+// phases: two fp16 pieces keep 22 significant bits over 18 binades below the scale's top, a bound that is loose by a few binades
+// costs nothing (tests/test_gpu_conv.py holds the run to the fp32 dot product's error against float64).
+// Differences to the bf16 run above, otherwise the same kernel: the workgroup's own row stays in registers until the pair's scale
+// is known (it was converted into the next pair's LDS slot in the epilogue); the intermediate row's zero halo is laid out for the
+// run's largest horizontal dilation and written once.
+struct PairChainF16Args {
+    PairChainArgs c;
+    const float *tA[CHAIN_MAX], *tB[CHAIN_MAX];   // tails of the fp16 sections: {weight scale, largest L1 norm of a filter}
+    float *rowmax;                                // [CHAIN_MAX][B*H]: largest finite magnitude of pair i's output row
+    int dbmax;
+};
+typedef _Float16 pair_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pair_f16x8 __attribute__((ext_vector_type(8)));
+// two values -> two fp16 pieces each (= split2h_pair of conv_split_kernel.hpp): u = h0 + h1 + O(2^-22 |u|), |u| <= 32768 by the caller's scale
+__device__ __forceinline__ void pair_split2h(float u0, float u1, unsigned &q0, unsigned &q1) {
+    const pair_f16x2 h0 = __builtin_convertvector(pair_f32x2{u0, u1}, pair_f16x2);
+    const pair_f32x2 f0 = __builtin_convertvector(h0, pair_f32x2);
+    const pair_f16x2 h1 = __builtin_convertvector(pair_f32x2{u0 - f0[0], u1 - f0[1]}, pair_f16x2);
+    q0 = __builtin_bit_cast(unsigned, h0);
+    q1 = __builtin_bit_cast(unsigned, h1);
+}
+
+template <int KS, int R>
+__global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16Args fa) {
+    const PairChainArgs &a = fa.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int wid = wid8 & 3, kpart = wid8 >> 2;
+    const int C = a.C, W = a.W, H = a.H, CP = a.CP;
+    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    const int NPG = W >> 5, npg_sh = NPG >> 1;
+    const int pg = wid & (NPG - 1), cg = wid >> npg_sh;
+    const int px = pg * 32 + l31;
+    const bool co_ok = cg * 32 < CP;
+    const int nchunk = C >> 4, nblk = CP >> 5;
+    const int nrows = a.B * H;
+    // LDS: s_red [4 waves][16][64] floats, s_in [2 pieces][nchunk][2][3 rows][W] x 16 B, s_mid [2 pieces][nchunk][2][W + 2 dbmax] x 16 B
+    const int in_piece = nchunk * 2 * 3 * W * 16;
+    const int dbmax = fa.dbmax, WM = W + 2 * dbmax, mid_piece = nchunk * 2 * WM * 16;
+    float *s_red = reinterpret_cast<float *>(smem_raw);
+    unsigned char *s_in = smem_raw + 16384, *s_mid = s_in + 2 * in_piece;
+    __shared__ int s_abort;
+    __shared__ float s_epi[4][128];
+    __shared__ float s_wmax[8];   // per wave: largest finite magnitude of what it holds (first pair: the staged rows; then: the output row)
+    __shared__ float s_bmax[2];   // per wave: largest |bias| of the vertical convolution
+    __shared__ float s_m3;        // largest finite magnitude of the pair's three input rows
+    const int ch_lo = kpart * (nchunk / KS), ch_hi = kpart == KS - 1 ? nchunk : ch_lo + nchunk / KS;
+    const int nch = ch_hi - ch_lo;   // multiple of R
+    const long plane = (long)H * W;
+    const long base = (long)n * C * plane + (long)y * W + px;
+    if (tid == 0) s_abort = 0;
+
+    u32x4 wr[R][3][2];
+    auto load_w = [&](const unsigned char *wp, int t, int chunk, u32x4 (&dst)[2]) {
+        const unsigned char *p = wp + ((((long)t * nchunk + chunk) * nblk + cg) * 2) * 1024 + lane * 16;
+        dst[0] = *reinterpret_cast<const u32x4 *>(p);
+        dst[1] = *reinterpret_cast<const u32x4 *>(p + 1024);
+    };
+    // rows of `src` for s_in - all three (first pair) or only the neighbours' (t = 0, 2) - in two steps: the loads (returning the largest
+    // finite magnitude this thread saw), and the conversion once the scale is known.  task = (chunk, row, pixel), 16 channel loads
+    constexpr int NTKMAX = KS == 2 ? 2 : 3;
+    float v[NTKMAX][16];
+    bool okr[NTKMAX];
+    auto stage_load = [&](const float *src, int dA, auto ALL_ROWS_, bool coherent) __attribute__((always_inline)) -> float {
+        constexpr bool all_rows = decltype(ALL_ROWS_)::value;
+        constexpr int nrow = all_rows ? 3 : 2;
+        constexpr int NTK = all_rows ? (KS == 2 ? 2 : 3) : (KS == 2 ? 1 : 2);
+        const int ntask = nchunk * nrow * W;
+        const float *xn = src + (long)n * C * plane;
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            const int task = tid + u * 256 * KS;
+            const int tk = min(task, ntask - 1);
+            const int pxs = tk & (W - 1), q = tk >> (5 + npg_sh), c = q / nrow, tt = q - nrow * c;
+            const int t = all_rows ? tt : 2 * tt;
+            const int yy = y + (t - 1) * dA;
+            okr[u] = task < ntask && yy >= 0 && yy < H;
+            const float *sp = xn + ((long)c * 16 * H + (okr[u] ? yy : 0)) * W + pxs;
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch)
+                v[u][ch] = coherent ? __hip_atomic_load(sp + ch * plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sp[ch * plane];
+        }
+#pragma unroll
+        for (int u = 0; u < NTK; ++u)
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch) {
+                v[u][ch] = okr[u] ? v[u][ch] : 0.f;
+                m = fmaxf(m, finite_abs(v[u][ch]));
+            }
+        return m;
+    };
+    auto stage_store = [&](auto ALL_ROWS_, float inv) __attribute__((always_inline)) {
+        constexpr bool all_rows = decltype(ALL_ROWS_)::value;
+        constexpr int nrow = all_rows ? 3 : 2;
+        constexpr int NTK = all_rows ? (KS == 2 ? 2 : 3) : (KS == 2 ? 1 : 2);
+        const int ntask = nchunk * nrow * W;
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            const int task = tid + u * 256 * KS;
+            if (task < ntask) {
+                const int pxs = task & (W - 1), q = task >> (5 + npg_sh), c = q / nrow, tt = q - nrow * c;
+                const int t = all_rows ? tt : 2 * tt;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 q2[2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned p0, p1;
+                        pair_split2h(v[u][8 * h + 2 * e] * inv, v[u][8 * h + 2 * e + 1] * inv, p0, p1);
+                        q2[0][e] = p0; q2[1][e] = p1;
+                    }
+                    const int entry = ((c * 2 + h) * 3 + t) * W + pxs;
+                    *reinterpret_cast<u32x4 *>(s_in + entry * 16) = q2[0];
+                    *reinterpret_cast<u32x4 *>(s_in + in_piece + entry * 16) = q2[1];
+                }
+            }
+        }
+    };
+    // ---- first pair: the three rows of the run's input, scaled by their own largest magnitude (one extra barrier per RUN)
+    float m3;
+    {
+        const float lm = wave_finite_absmax(stage_load(a.x0, a.dA[0], std::true_type{}, false));
+        if (lane == 0) s_wmax[wid8] = lm;
+    }
+    if (co_ok) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) load_w(a.wA[0], t, ch_lo + i, wr[i][t]);
+    }
+    // the block's input row in registers (what the block's second pair adds back): this lane's 16 channels of pixel px
+    float blk_in[16], own[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { blk_in[r] = a.x0[base + (long)min(cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, C - 1) * plane]; own[r] = 0.f; }
+    {   // zero halo of the intermediate row, once for the run (both pieces, all 8-channel groups)
+        const int ngrp = nchunk * 2, nh = 2 * dbmax;
+        for (int i = tid; i < 2 * ngrp * nh; i += 256 * KS) {
+            const int j = i % nh, g = (i / nh) % ngrp, pl = i / (nh * ngrp);
+            *reinterpret_cast<u32x4 *>(s_mid + pl * mid_piece + (g * WM + (j < dbmax ? j : W + j)) * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();
+    {
+        m3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * KS; ++i) m3 = fmaxf(m3, s_wmax[i]);
+        stage_store(std::true_type{}, 1.f / f16_scale_of(m3));
+    }
+
+    auto mma3 = [&](f32x16 &acc, const u32x4 (&w)[2], const u32x4 (&b)[2]) {
+        constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};   // smallest terms first: w1 b0, w0 b1, w0 b0
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pair_f16x8, w[HA[k]]), __builtin_bit_cast(pair_f16x8, b[HB[k]]), acc, 0, 0, 0);
+    };
+    float m_own = 0.f;   // (wave 0) largest finite magnitude of this row's last output
+
+    for (int p = 0; p < a.npairs; ++p) {
+        const int dA = a.dA[p], dB = a.dB[p];
+        const unsigned char *wA = a.wA[p], *wB = a.wB[p];
+        const bool last = p + 1 == a.npairs;
+        const float swA = fa.tA[p][0], l1A = fa.tA[p][1], swB = fa.tB[p][0];
+        if (p > 0) {
+            // ---- the two neighbour rows of the previous pair's output: wait for their counters, take their maxima, then stage them
+            if (wid8 == 0) {
+                const int yu = y - dA, yd = y + dA;
+                long long spins = 0;
+                bool ok = false;
+                while (!ok) {
+                    const int fu = yu >= 0 ? __hip_atomic_load(a.flags + n * H + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
+                    const int fd = yd < H ? __hip_atomic_load(a.flags + n * H + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
+                    ok = fu >= p && fd >= p;
+                    if (!ok) {
+                        ++spins;
+                        const bool timed_out = spins > a.spin_limit;
+                        const bool peer_gone = !timed_out && (spins & 63) == 0 && __hip_atomic_load(a.sticky + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (timed_out || peer_gone) {
+                            if (lane == 0) {
+                                s_abort = 1;
+                                if (timed_out) { atomicAdd(a.sticky, 1); __hip_atomic_store(a.sticky + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (ok) {
+                    const float *rm = fa.rowmax + (long)(p - 1) * nrows + n * H;
+                    const float mu = yu >= 0 ? __hip_atomic_load(rm + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    const float md = yd < H ? __hip_atomic_load(rm + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    if (lane == 0) s_m3 = fmaxf(m_own, fmaxf(finite_abs(mu), finite_abs(md)));
+                }
+            }
+            __syncthreads();
+            if (*(volatile int *)&s_abort) {
+                // (uniform after the barrier.)  As in the bf16 run: this row stops here and voids its row of the run's result
+                float *o = a.out[a.npairs - 1] + (long)n * C * plane + (long)y * W;
+                for (int i = tid; i < C * W; i += 256 * KS) o[(long)(i / W) * plane + (i % W)] = __uint_as_float(0x7fc00000u);
+                return;
+            }
+            m3 = s_m3;
+            const float inv = 1.f / f16_scale_of(m3);
+            (void)stage_load(a.out[p - 1], dA, std::false_type{}, true);
+            stage_store(std::false_type{}, inv);
+            if (co_ok && kpart == 0) {   // the own row, kept in registers since the previous pair's epilogue
+#pragma unroll
+                for (int g8 = 0; g8 < 4; ++g8) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) pair_split2h(own[4 * g8 + 2 * e] * inv, own[4 * g8 + 2 * e + 1] * inv, pk[0][e], pk[1][e]);
+                    const int grp = cg * 4 + g8;
+                    if (grp * 8 < C) {
+                        const int entry = (grp * 3 + 1) * W + px;   // (chunk * 2 + k half) = grp, row slot t = 1
+                        *reinterpret_cast<u32x2 *>(s_in + entry * 16 + half * 8) = u32x2{pk[0][0], pk[0][1]};
+                        *reinterpret_cast<u32x2 *>(s_in + in_piece + entry * 16 + half * 8) = u32x2{pk[1][0], pk[1][1]};
+                    }
+                }
+            }
+        }
+        {   // the pair's epilogue vectors through LDS, and the largest |bias| of the vertical convolution (for the intermediate row's bound)
+            float bm = 0.f;
+            if (tid < C) {
+                const float b0 = a.bA[p][tid];
+                s_epi[0][tid] = b0;
+                s_epi[1][tid] = a.bB[p][tid];
+                s_epi[2][tid] = a.scale[p][tid];
+                s_epi[3][tid] = a.shift[p][tid];
+                bm = finite_abs(b0);
+            }
+            if (wid8 < 2) {
+                bm = wave_finite_absmax(bm);
+                if (lane == 0) s_bmax[wid8] = bm;
+            }
+        }
+        __syncthreads();
+        const float sx = f16_scale_of(m3);
+        // |relu(conv + bias)| <= (largest input) x (largest L1 norm of a filter) + largest |bias|: the intermediate row's scale without a reduction
+        const float smid = f16_scale_of(fminf(fmaf(m3, l1A, fmaxf(s_bmax[0], s_bmax[1])), 3.0e38f));
+        const float fA = sx * swA, inv_mid = 1.f / smid, fB = smid * swB;
+
+        // ---- phase A: vertical taps
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (co_ok) {
+            for (int j0 = 0; j0 < nch; j0 += R) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ch = ch_lo + j0 + i;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        u32x4 b[2];
+                        const int entry = ((ch * 2 + half) * 3 + t) * W + px;
+                        b[0] = *reinterpret_cast<const u32x4 *>(s_in + entry * 16);
+                        b[1] = *reinterpret_cast<const u32x4 *>(s_in + in_piece + entry * 16);
+                        mma3(acc, wr[i][t], b);
+                    }
+                    const int nxt = j0 + i + R;
+                    const unsigned char *wsrc = nxt < nch ? wA : wB;
+                    const int nch_src = nxt < nch ? ch_lo + nxt : ch_lo + nxt - nch;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) load_w(wsrc, t, nch_src, wr[i][t]);
+                }
+            }
+        }
+        if constexpr (KS == 2) {
+            if (kpart == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+            }
+            __syncthreads();
+            if (kpart == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+            }
+        }
+        if (co_ok && kpart == 0) {
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int cch = min(cg * 32 + 8 * g8 + 4 * half + 2 * e, C - 2);
+                    const float v0 = fmaf(acc[4 * g8 + 2 * e], fA, s_epi[0][cch]), v1 = fmaf(acc[4 * g8 + 2 * e + 1], fA, s_epi[0][cch + 1]);
+                    pair_split2h((v0 > 0.f ? v0 : 0.f) * inv_mid, (v1 > 0.f ? v1 : 0.f) * inv_mid, pk[0][e], pk[1][e]);
+                }
+                const int grp = cg * 4 + g8;
+                if (grp * 8 < C) {
+                    *reinterpret_cast<u32x2 *>(s_mid + (grp * WM + dbmax + px) * 16 + half * 8) = u32x2{pk[0][0], pk[0][1]};
+                    *reinterpret_cast<u32x2 *>(s_mid + mid_piece + (grp * WM + dbmax + px) * 16 + half * 8) = u32x2{pk[1][0], pk[1][1]};
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: horizontal taps over the intermediate; the ring is refilled with the NEXT pair's first vertical fragments
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char *wNext = a.wA[last ? p : p + 1];
+        if (co_ok) {
+            for (int j0 = 0; j0 < nch; j0 += R) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int ch = ch_lo + j0 + i;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        u32x4 b[2];
+                        const int entry = (ch * 2 + half) * WM + dbmax + px + (t - 1) * dB;
+                        b[0] = *reinterpret_cast<const u32x4 *>(s_mid + entry * 16);
+                        b[1] = *reinterpret_cast<const u32x4 *>(s_mid + mid_piece + entry * 16);
+                        mma3(acc, wr[i][t], b);
+                    }
+                    const int nxt = j0 + i + R;
+                    const unsigned char *wsrc = nxt < nch ? wB : wNext;
+                    const int nch_src = nxt < nch ? ch_lo + nxt : ch_lo + nxt - nch;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) load_w(wsrc, t, nch_src, wr[i][t]);
+                }
+            }
+        }
+        if constexpr (KS == 2) {
+            if (kpart == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[(wid * 16 + r) * 64 + lane] = acc[r];
+            }
+            __syncthreads();
+            if (kpart == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += s_red[(wid * 16 + r) * 64 + lane];
+            }
+        }
+        // ---- epilogue: bias, BatchNorm, block residual, ReLU; the row goes out write-through, stays in registers for the next pair, and
+        //      leaves its largest finite magnitude
+        float lm = 0.f;
+        if (co_ok && kpart == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, co_ = min(co, C - 1);
+                float vv = fmaf(fmaf(acc[r], fB, s_epi[1][co_]), s_epi[2][co_], s_epi[3][co_]);
+                if (a.res[p]) vv += blk_in[r];
+                if (a.relu[p]) vv = vv > 0.f ? vv : 0.f;
+                own[r] = co < C ? vv : 0.f;
+                lm = fmaxf(lm, finite_abs(own[r]));
+            }
+            float *yo = a.out[p];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < C) {
+                    if (last) yo[base + co * plane] = own[r];
+                    else __hip_atomic_store(yo + base + co * plane, own[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (!last && a.res[p]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) blk_in[r] = own[r];
+            }
+        }
+        if (last) break;
+        if (kpart == 0) {
+            lm = wave_finite_absmax(lm);
+            if (lane == 0) s_wmax[wid] = lm;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row stores have left (write-through): maximum and counter may follow
+        __syncthreads();
+        if (wid8 == 0) {
+            m_own = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+            if (lane == 0) {
+                __hip_atomic_store(fa.rowmax + (long)p * nrows + n * H + y, m_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.flags + n * H + y, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (*(volatile int *)&s_abort) return;
+    }
+}
+
 // fp32 floats of the exact packing of one convolution of a pair
 inline size_t pair_f32_floats(int channels) {
     const int CP = (channels + 31) / 32 * 32;
@@ -836,6 +1224,10 @@ inline size_t pair_f32_floats(int channels) {
 inline size_t pair_split_bytes(int channels) {
     const int CP = (channels + 31) / 32 * 32;
     return (size_t)3 * (channels / 16) * (CP / 32) * 3 * 1024;
+}
+inline size_t pair_f16_bytes(int channels) {   // two fp16 pieces instead of three bf16 ones
+    const int CP = (channels + 31) / 32 * 32;
+    return (size_t)3 * (channels / 16) * (CP / 32) * 2 * 1024;
 }
 inline bool pair_use_split() {
     static const bool v = [] {
@@ -848,8 +1240,8 @@ inline bool pair_use_split() {
 
 extern "C" size_t lav_conv1d_pair_packed_weight_floats(int channels) {
     if (channels < 16 || channels % 16) return 0;
-    // the exact fp32 packing followed by the three-piece bf16 packing
-    return pair_f32_floats(channels) + pair_split_bytes(channels) / 4;
+    // the exact fp32 packing, the three-piece bf16 packing, the two-piece fp16 packing (round 6) and its tail {scale, largest L1 norm of a filter, 0, 0}
+    return pair_f32_floats(channels) + pair_split_bytes(channels) / 4 + pair_f16_bytes(channels) / 4 + 4;
 }
 
 extern "C" int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_packed) {
@@ -889,6 +1281,35 @@ extern "C" int lav_conv1d_pair_pack_weights(int channels, const float *h_weight,
                         const size_t frag = ((((size_t)t * nchunk + ch) * (CP / 32) + blk) * 3) * 512;
                         o[frag + lane * 8 + e] = p0; o[frag + 512 + lane * 8 + e] = p1; o[frag + 1024 + lane * 8 + e] = p2;
                     }
+    // fp16 packing (lav_conv1d_pair_chain_f16): [tap][chunk][cout block][piece 2][lane][8 channels] fp16 of w / s, s = the power of two that
+    // puts the largest |w| into [16384, 32768); behind it {s, max over cout of sum |w[cout]|, 0, 0}
+    {
+        const size_t nw = (size_t)C * C * 3;
+        float m = 0.f, l1 = 0.f;
+        for (size_t i = 0; i < nw; ++i) { const float v = fabsf(h_weight[i]); if (v <= 3.4028235e38f && v > m) m = v; }
+        for (int co = 0; co < C; ++co) {
+            double acc = 0.0;
+            for (int k = 0; k < C * 3; ++k) { const float v = fabsf(h_weight[(size_t)co * C * 3 + k]); if (v <= 3.4028235e38f) acc += v; }
+            l1 = std::max(l1, (float)(acc * (1.0 + 1e-6)));
+        }
+        int ex = 0;
+        (void)frexpf(m, &ex);
+        const float sw = ldexpf(1.f, m > 0.f ? std::max(ex, -100) - 15 : 0), inv = 1.f / sw;
+        _Float16 *h = reinterpret_cast<_Float16 *>(h_packed + pair_f32_floats(C) + pair_split_bytes(C) / 4);
+        for (int t = 0; t < 3; ++t)
+            for (int ch = 0; ch < nchunk; ++ch)
+                for (int blk = 0; blk < CP / 32; ++blk)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = blk * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + e;
+                            const float w = co < C ? h_weight[((size_t)co * C + ci) * 3 + t] * inv : 0.f;
+                            const _Float16 h0 = (_Float16)w, h1 = (_Float16)(w - (float)h0);
+                            const size_t frag = ((((size_t)t * nchunk + ch) * (CP / 32) + blk) * 2) * 512;
+                            h[frag + lane * 8 + e] = h0; h[frag + 512 + lane * 8 + e] = h1;
+                        }
+        float *tail = h_packed + pair_f32_floats(C) + pair_split_bytes(C) / 4 + pair_f16_bytes(C) / 4;
+        tail[0] = sw; tail[1] = l1; tail[2] = 0.f; tail[3] = 0.f;
+    }
     return LAV_OK;
 }
 
@@ -994,17 +1415,18 @@ __global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *launches)
 }  // namespace
 
 extern "C" size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h) {
-    return batch > 0 && h > 0 ? 256 + lav::align_up((size_t)(batch * h) * sizeof(int), 256) : 0;   // sticky counters + per-row progress
+    // sticky counters + per-row progress + (fp16 run) every pair's per-row maxima
+    return batch > 0 && h > 0 ? 256 + lav::align_up((size_t)(batch * h) * sizeof(int), 256) + (size_t)CHAIN_MAX * batch * h * sizeof(float) : 0;
 }
 
 extern "C" size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max) {
     return 16384 + (size_t)channels * w * 18 + (size_t)channels * (w + 2 * d_b_max) * 6;
 }
 
-extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
-                                     const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
-                                     const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
-                                     const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream) {
+static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
+                             const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
+                             const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
+                             const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream) {
     LAV_REQUIRE(pair_use_split(), "lav_conv1d_pair_chain: the persistent run exists for the bf16x6 kernels only (LAV_CONV_PRECISION=f32 runs the pairs one launch each)");
     LAV_REQUIRE(batch >= 1 && h >= 1 && npairs >= 1 && npairs <= CHAIN_MAX, "lav_conv1d_pair_chain: 1..%d pairs", CHAIN_MAX);
     LAV_REQUIRE(w == 32 || w == 64 || w == 128, "lav_conv1d_pair_chain: row width %d not in {32, 64, 128}", w);
@@ -1054,6 +1476,41 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
     // block's input row and the next pair's prefetch (364 bytes of scratch per lane)
     const int ring2 = nch2 % 2 == 0 ? 2 : 1;
     const int tok = timer_begin("conv1d_pair", st);
+    if (f16) {
+        PairChainF16Args fa;
+        fa.c = a;
+        fa.c.trace = nullptr;
+        const size_t sec = pair_f32_floats(channels) + pair_split_bytes(channels) / 4;   // floats in front of the fp16 section
+        for (int i = 0; i < CHAIN_MAX; ++i) {
+            const int j = i < npairs ? i : npairs - 1;
+            fa.c.wA[i] = reinterpret_cast<const unsigned char *>(wa_packed[j] + sec);
+            fa.c.wB[i] = reinterpret_cast<const unsigned char *>(wb_packed[j] + sec);
+            fa.tA[i] = wa_packed[j] + sec + pair_f16_bytes(channels) / 4;
+            fa.tB[i] = wb_packed[j] + sec + pair_f16_bytes(channels) / 4;
+        }
+        fa.rowmax = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + lav::align_up((size_t)nflag * sizeof(int), 256));
+        fa.dbmax = dbmax;
+        const size_t lds16 = 16384 + (size_t)channels * w * 12 + (size_t)channels * (w + 2 * dbmax) * 4;
+        constexpr size_t F16_STATIC_LDS = 2064 + 64;   // s_abort, s_epi, s_wmax, s_bmax, s_m3
+#define LAV_CHAIN16_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
+        static size_t cap = 0; \
+        if (!cap) { \
+            cap = (160 * 1024 - F16_STATIC_LDS) / 16 * 16; \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain_f16<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) { \
+                (void)hipGetLastError(); \
+                cap = 152 * 1024; \
+                LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain_f16<KS_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap)); \
+            } \
+        } \
+        /* (the residency rule above was checked with the bf16 run's LDS size: this run claims what THAT one would, so the same rows per CU) */ \
+        hipLaunchKernelGGL((k_conv1d_pair_chain_f16<KS_, R_>), dim3(batch * h), dim3(256 * KS_), \
+                           std::min(cap, std::max(lds16, lav::lds_claim(lds, F16_STATIC_LDS, batch * h > cus))), st, fa); }
+        LAV_CHAIN16_CASE(1, 1) LAV_CHAIN16_CASE(1, 2) LAV_CHAIN16_CASE(2, 1) LAV_CHAIN16_CASE(2, 2)
+#undef LAV_CHAIN16_CASE
+        timer_end(tok, st);
+        LAV_LAUNCH_CHECK();
+        return LAV_OK;
+    }
 #define LAV_CHAIN_CASE(KS_, R_) if (ks2 == KS_ && ring2 == R_) { \
         static size_t cap = 0;   /* (the kernel also holds CHAIN_STATIC_LDS bytes of static LDS: the dynamic part may claim 160 KB minus that) */ \
         if (!cap) { \
@@ -1093,6 +1550,22 @@ extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int 
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
     return LAV_OK;
+}
+
+extern "C" int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
+                                     const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
+                                     const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
+                                     const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return pair_chain_launch(false, batch, channels, h, w, npairs, d_a, d_b, residual, relu_post, x, wa_packed, bias_a, wb_packed, bias_b, scale, shift, out,
+                             workspace, workspace_bytes, stream);
+}
+
+extern "C" int lav_conv1d_pair_chain_f16(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
+                                         const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
+                                         const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
+                                         const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream) {
+    return pair_chain_launch(true, batch, channels, h, w, npairs, d_a, d_b, residual, relu_post, x, wa_packed, bias_a, wb_packed, bias_b, scale, shift, out,
+                             workspace, workspace_bytes, stream);
 }
 
 extern "C" int lav_conv1d_pair_chain_status(const void *workspace, int *h_timeouts_launches2, void *stream) {

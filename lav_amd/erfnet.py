@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import Conv1dPair, Conv1dPairChain, ConvLayer, GroupedDeconv
+from .ops import Conv1dPair, Conv1dPairChain, ConvLayer, GroupedDeconv, infer_precision
 
 _USE_PAIRS = os.environ.get("LAV_ERFNET_PAIRS", "1") != "0"   # A/B switch: 0 = four lav_conv2d launches per block
 
@@ -205,13 +205,14 @@ class ERFNet(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     def _engine(self, device, input_affine=None, softmax=False):
-        if self._eng is None or self._eng[0] != (device, input_affine, softmax):
+        key = (device, input_affine, softmax, infer_precision())   # (the runs of blocks are built for the precision in force: fp16 pieces under LAV_CONV_F16X3)
+        if self._eng is None or self._eng[0] != key:
             stages = [self.encoder.initial_block.engine(device, input_affine)]
             stages += [m.engine(device) for m in self.encoder.layers]
             stages += [m.engine(device) for m in self.decoder.layers]
             stages = _chain_blocks(stages)
             stages.append(GroupedDeconv([self.decoder.output_conv], softmax=softmax, device=device))   # 16 -> classes, k2 s2: memory bound
-            object.__setattr__(self, "_eng", ((device, input_affine, softmax), stages))
+            object.__setattr__(self, "_eng", (key, stages))
         return self._eng[1]
 
     def forward(self, x, input_affine=None, softmax=False):

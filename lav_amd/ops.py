@@ -719,6 +719,9 @@ class Conv1dPairChain:
             raise RuntimeError("Conv1dPairChain: pairs of one channel count, each with its BatchNorm affine")
         self.pairs, self.residual = list(pairs), [int(bool(r)) for r in residual]
         self._bufs = {}
+        # round 6: engines built for LAV_CONV_F16X3 (the inference pipelines' default) run on two fp16 pieces per operand
+        # (lav_conv1d_pair_chain_f16); LAV_ERFNET_F16=0 keeps the bf16x6 run
+        self.f16 = infer_precision() == _lib.CONV_F16X3 and _os.environ.get("LAV_ERFNET_F16", "1") != "0"
 
     def supported(self, x: torch.Tensor) -> bool:
         lib = _lib.load()
@@ -742,11 +745,11 @@ class Conv1dPairChain:
         out = bufs + [torch.empty_like(x)]
         # sized ONCE for the largest run the chip can hold (2 rows per CU): the buffer never grows, so the sticky time-out / launch
         # counters of already captured graphs stay the ones pair_chain_status() reads
-        ws = _workspace("pair_chain", max(lib.lav_conv1d_pair_chain_workspace_bytes(B, h), 256 + 4 * 2 * _cu_count(x.device)), x.device)
+        ws = _workspace("pair_chain", max(lib.lav_conv1d_pair_chain_workspace_bytes(B, h), lib.lav_conv1d_pair_chain_workspace_bytes(2 * _cu_count(x.device), 1)), x.device)
         ia = lambda vals: (C.c_int * n)(*vals)
         pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
         ps = self.pairs
-        check(lib.lav_conv1d_pair_chain(B, ch, h, w, n, ia([p.da for p in ps]), ia([p.db for p in ps]), ia(self.residual),
+        check((lib.lav_conv1d_pair_chain_f16 if self.f16 else lib.lav_conv1d_pair_chain)(B, ch, h, w, n, ia([p.da for p in ps]), ia([p.db for p in ps]), ia(self.residual),
                                         ia([int(p.relu_post) for p in ps]), _ptr(x), pa([p.wa for p in ps]), pa([p.ba for p in ps]),
                                         pa([p.wb for p in ps]), pa([p.bb for p in ps]), pa([p.scale for p in ps]), pa([p.shift for p in ps]),
                                         pa(out), _ptr(ws), ws.numel(), _stream()), "lav_conv1d_pair_chain")

@@ -484,7 +484,81 @@ def test_pair_chain_is_bit_identical_to_the_pairs_launched_one_by_one(ch, h, w, 
     assert all(torch.equal(o, want) for o in outs), "the persistent run differs from the single launches beside the stem kernel"
 
 
-def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):
+@pytest.mark.parametrize("ch,h,w,dils", [(128, 36, 32, (2, 4, 8, 16)), (64, 72, 64, (1, 1, 1)), (64, 20, 64, (1, 3)), (16, 144, 128, (1, 1))])
+def test_pair_chain_on_fp16_pieces_keeps_the_fp32_dot_products_error(ch, h, w, dils):
+    """lav_conv1d_pair_chain_f16 (round 6: the persistent run on two scaled fp16 pieces per operand and three products, the activation
+    scale derived per workgroup and pair from its own row's maximum and the neighbours' maxima that travel with the hand-off, the
+    intermediate row's from a bound) against float64: no further from it than a small multiple of the bf16x6 run (which holds the error
+    of an fp32 dot product), on inputs whose ROWS differ by six decades (a scale taken from the wrong rows overflows fp16 or drops the
+    small rows' bits), with an all-zero image in the batch, repeatedly, and deterministic from launch to launch."""
+    import torch.nn as nn
+    from lav_amd import _lib, ops
+    from lav_amd.ops import Conv1dPair, Conv1dPairChain
+    torch.manual_seed(ch + h + 1)
+    B = 3
+    mods, pairs, res = [], [], []
+    for d in dils:
+        for dd in (1, d):
+            ca = nn.Conv2d(ch, ch, (3, 1), padding=(dd, 0), dilation=(dd, 1))
+            cb = nn.Conv2d(ch, ch, (1, 3), padding=(0, dd), dilation=(1, dd))
+            bn = nn.BatchNorm2d(ch, eps=1e-3).eval()
+            with torch.no_grad():
+                bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+            mods.append((ca, cb, bn))
+            pairs.append(Conv1dPair(ca, cb, bn, device=DEV))
+            res.append(len(pairs) % 2 == 0)
+    with ops.precision(_lib.CONV_F16X3):
+        chain16 = Conv1dPairChain(pairs, res)
+    with ops.precision(_lib.CONV_BF16X6):
+        chain_bf = Conv1dPairChain(pairs, res)
+    assert chain16.f16 and not chain_bf.f16
+
+    def ref64(x):
+        y = x.double().cpu()
+        with torch.no_grad():
+            for i in range(0, len(mods), 2):
+                blk = y
+                for k in (i, i + 1):
+                    ca, cb, bn = (m.double() for m in mods[k])
+                    y = bn(cb(torch.relu(ca(y))))
+                    if k == i:
+                        y = torch.relu(y)
+                y = torch.relu(y + blk)
+        for trip in mods:
+            for m in trip:
+                m.float()
+        return y
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((B, ch, h, w), generator=g)
+    cases = {"plain": x.clone()}
+    rows = x.clone()
+    rows *= (10.0 ** torch.linspace(-3, 3, h))[None, None, :, None]     # six decades from the top row to the bottom one
+    rows[1] = 0.0                                                       # an all-zero image: maxima of zero
+    cases["rows over six decades"] = rows
+    cases["tiny"] = x * 1e-20
+    for name, xin in cases.items():
+        xd = xin.to(DEV)
+        assert chain16.supported(xd)
+        want = ref64(xin)
+        got16 = chain16(xd)
+        got_bf = chain_bf(xd)
+        torch.cuda.synchronize()
+        assert chain16.timeouts(xd) == 0
+        assert bool(torch.isfinite(got16).all()), name
+        # per image row (the rows' magnitudes differ): error against the row's own largest value
+        top = want.abs().amax(dim=(1, 3), keepdim=True).clamp_min(1e-300)
+        e16 = ((got16.double().cpu() - want).abs() / top).max().item()
+        ebf = ((got_bf.double().cpu() - want).abs() / top).max().item()
+        assert e16 <= max(4 * ebf, 4e-6), f"{name}: fp16-piece run {e16:.3e} of the row maximum from float64, bf16x6 run {ebf:.3e}"
+        for _ in range(3):
+            again = chain16(xd)
+        torch.cuda.synchronize()
+        assert torch.equal(again, got16), name
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch, f16):
     """A workgroup of the persistent run that waits too long for a neighbour row (forced: a spin limit of 0) gives up instead of
     hanging the device, and the sticky counter of the workspace says that the result is void; the next launch is valid again."""
     import torch.nn as nn
@@ -496,7 +570,10 @@ def test_pair_chain_timeout_is_counted_and_never_hangs(monkeypatch):
     for d in (1, 2, 1, 4, 1, 8):
         pairs.append(Conv1dPair(nn.Conv2d(ch, ch, (3, 1), padding=(d, 0), dilation=(d, 1)), nn.Conv2d(ch, ch, (1, 3), padding=(0, d), dilation=(1, d)),
                                 nn.BatchNorm2d(ch, eps=1e-3).eval(), device=DEV))
-    chain = Conv1dPairChain(pairs, [i % 2 == 1 for i in range(len(pairs))])
+    from lav_amd import _lib
+    with ops.precision(_lib.CONV_F16X3 if f16 else _lib.CONV_BF16X6):
+        chain = Conv1dPairChain(pairs, [i % 2 == 1 for i in range(len(pairs))])
+    assert chain.f16 == f16
     x = torch.randn((3, ch, h, w), device=DEV)
     good = chain(x)
     torch.cuda.synchronize()
