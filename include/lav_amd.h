@@ -547,6 +547,26 @@ int lav_conv_wgrad_amax(const float *x, const float *dy, int batch, int cin, int
                         void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 7c. Transposed convolutions with kernel == stride ("pointwise" up-convolutions, ABI 28): every output pixel has one contributing
+ *     input pixel and tap, so the layer is k*k independent [cout x cin] x [cin x pixels] products - two of the BEV backbone's three
+ *     up-convolutions (team_code_v2/models/lidar.py:114-131: ConvTranspose2d(64, 128, 1, 1) and ConvTranspose2d(128, 128, 4, 4, 1, 2),
+ *     each + ReLU + eval BatchNorm into a slice of the 384-channel feature map):
+ *     y[n][out_c_offset + co][k iy + ky - pad][k ix + kx - pad] = scale[co] * relu?(sum_ci w[ci][co][ky][kx] x[n][ci][iy][ix]) + shift[co];
+ *     output positions without a contributing input pixel (output_padding) hold scale * relu?(0) + shift.  Exact fp32 products and
+ *     accumulation on v_mfma_f32_32x32x2_f32.  Supported: k in {1, 4}, cin in {64, 128}, cout a multiple of 128 (k = 1) / 32 (k = 4),
+ *     pad < k; k = 1 without padding.  x [batch][cin][ih][iw], y [batch][out_c_total][OH][OW], OH = (ih - 1) k - 2 pad + k + out_pad.
+ *     lav_upconv_pointwise_pack repacks the PyTorch ConvTranspose2d weight [cin][cout][k][k] on the host
+ *     (lav_upconv_pointwise_packed_floats floats).  amax_out (or NULL): lav_upconv_pointwise_parts floats, the largest finite |y| each
+ *     workgroup wrote - what lav_conv2d_amax leaves for LAV_CONV_F16X3 readers of the feature map.
+ * ------------------------------------------------------------------------------------------ */
+size_t lav_upconv_pointwise_packed_floats(int cin, int cout, int k);
+int lav_upconv_pointwise_pack(int cin, int cout, int k, const float *h_weight, float *h_packed);
+int lav_upconv_pointwise_parts(int batch, int cin, int cout, int ih, int iw, int k, int pad, int out_pad);
+int lav_upconv_pointwise(int batch, int cin, int cout, int ih, int iw, int k, int pad, int out_pad, const float *x, const float *w_packed,
+                         const float *scale, const float *shift, int relu_pre, int out_c_total, int out_c_offset, float *y,
+                         float *amax_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * 8. Two stacked 1-D convolutions in one launch - one half of ERFNet's non_bottleneck_1d block
  *    (lav/models/erfnet.py:45-56):  y = relu?( (conv1x3_dB( relu( conv3x1_dA(x) + bias_a ) ) + bias_b) * scale + shift
  *    + residual ).  x, y, residual [batch][channels][h][w] (same shape), stride 1, "same" padding (pad = dilation).

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblav_amd.so")
-SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "gru_seq.hip", "conv.hip", "conv_f16.hip", "conv_pair.hip", "deconv.hip", "crop.hip", "frame.hip", "attn.hip", "bn_train.hip", "conv_wgrad.hip"]
+SOURCES = ["misc.hip", "pillar.hip", "paint.hip", "gru.hip", "gru_seq.hip", "conv.hip", "conv_f16.hip", "conv_pair.hip", "deconv.hip", "crop.hip", "frame.hip", "attn.hip", "bn_train.hip", "conv_wgrad.hip", "upconv.hip"]
 # Parity-critical float32 arithmetic (cell ids, decoration, camera projection) must round every multiply and
 # add separately, like the oracle: these translation units are compiled with FMA contraction off (the header
 # helpers __fadd_rn/__fmul_rn are plain operators that clang would otherwise fuse after inlining).

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import ops
-from .ops import Amax, ConvLayer, GroupedDeconv
+from .ops import Amax, ConvLayer, GroupedDeconv, PointwiseUpconv
 from .point_pillar import PointPillarNet
 
 _NORM = dict(eps=1e-3, momentum=0.01)
@@ -133,9 +133,14 @@ class ConvBackbone(_Engine):
         off = 0
         for seq in (self.upconv1, self.upconv2, self.upconv3):
             ct, bn = seq[0], seq[2]
-            ups.append(ConvLayer(ct.weight, stride=ct.stride[0], padding=ct.padding, transposed=True,
-                                 output_padding=ct.output_padding[0], bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True,
-                                 out_c_total=self.out_channels, out_c_offset=off, precision=prec, device=device))
+            if prec == _lib.CONV_F16X3 and PointwiseUpconv.takes(ct):
+                # (round 6) kernel == stride: one input pixel and tap per output pixel - the 1x1 and the 4x4 / stride-4 layer on the
+                # pointwise kernel (exact fp32, lav_upconv_pointwise) instead of an implicit-GEMM plan with a 4-8 step K loop
+                ups.append(PointwiseUpconv(ct, bn, relu_pre=True, out_c_total=self.out_channels, out_c_offset=off, device=device))
+            else:
+                ups.append(ConvLayer(ct.weight, stride=ct.stride[0], padding=ct.padding, transposed=True,
+                                     output_padding=ct.output_padding[0], bn=_bn_tuple(bn), bn_eps=bn.eps, relu_pre=True,
+                                     out_c_total=self.out_channels, out_c_offset=off, precision=prec, device=device))
             off += ct.weight.shape[1]
         eng[key] = dict(s1=stage(self.conv1), s2=stage(self.conv2), s3=stage(self.conv3), ups=ups, amax={}, f16=prec == _lib.CONV_F16X3)
         eng["tensor_ids"] = self._tensor_ids()   # recorded where the engine is built, not at its first use

@@ -656,6 +656,78 @@ class GroupedDeconv:
         return out
 
 
+class PointwiseUpconv:
+    """ConvTranspose2d with kernel == stride (no bias) -> ReLU -> eval BatchNorm into a channel slice of a wider map, as ONE
+    lav_upconv_pointwise launch: exact fp32 matrix products, no pipeline to fill (round 6: the BEV backbone's 1x1 and 4x4 / stride-4
+    up-convolutions, 21.5 + 31.1 us on the implicit-GEMM kernels).  Same call surface as the ConvLayer it stands in for:
+    `__call__(x, out=, amax_in=, amax_out=)`, `out_hw`, `uses_amax` (never: it reads fp32), `refresh` (re-packs on the device)."""
+
+    @staticmethod
+    def takes(ct, device=None) -> bool:
+        k, s = ct.kernel_size, ct.stride
+        return (isinstance(ct, torch.nn.ConvTranspose2d) and k[0] == k[1] == s[0] == s[1] and k[0] in (1, 4) and ct.bias is None
+                and ct.in_channels in (64, 128) and ct.out_channels % (128 if k[0] == 1 else 32) == 0 and ct.groups == 1
+                and ct.dilation == (1, 1) and ct.padding[0] == ct.padding[1] < k[0] and ct.output_padding[0] == ct.output_padding[1]
+                and (k[0] > 1 or (ct.padding[0] == 0 and ct.output_padding[0] == 0))
+                and _os.environ.get("LAV_UPCONV_POINTWISE", "1") != "0")
+
+    def __init__(self, ct, bn, *, relu_pre=True, out_c_total=None, out_c_offset=0, device=None):
+        if not PointwiseUpconv.takes(ct):
+            raise RuntimeError("PointwiseUpconv: ConvTranspose2d with kernel == stride in {1, 4}, 64 / 128 input channels, no bias")
+        self.k, self.pad, self.opad = ct.kernel_size[0], ct.padding[0], ct.output_padding[0]
+        self.cin, self.cout = ct.in_channels, ct.out_channels
+        self.relu_pre = bool(relu_pre)
+        self.out_c_total = int(out_c_total) if out_c_total else self.cout
+        self.out_c_offset = int(out_c_offset)
+        self._src = (ct.weight, bn)
+        self.device = torch.device(device) if device is not None else ct.weight.device
+        self.w = self.scale = self.shift = None
+        self.refresh()
+
+    def refresh(self):
+        """Packed weights and folded BatchNorm from the CURRENT parameter values: a permutation and five small float64 launches on the
+        device the parameters live on (lav_upconv_pointwise_pack is the host form of the same permutation)."""
+        w, bn = self._src
+        w = w.detach().to(torch.float32)
+        if self.k == 1:   # [ci][co] -> [128-cout tile][32-cout tile j][ci][32]
+            p = w.reshape(self.cin, self.cout // 128, 4, 32).permute(1, 2, 0, 3)
+        else:             # [ci][co][ky][kx] -> [ky][32-cout tile][kx][ci][32]
+            p = w.reshape(self.cin, self.cout // 32, 32, 4, 4).permute(3, 1, 4, 0, 2)
+        p = p.contiguous().reshape(-1).to(self.device)
+        scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        shift = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+        if self.w is None:
+            self.w, self.scale, self.shift = p, scale.float().to(self.device).contiguous(), shift.float().to(self.device).contiguous()
+        else:     # in place: HIP graphs hold these addresses
+            self.w.copy_(p); self.scale.copy_(scale.float()); self.shift.copy_(shift.float())
+
+    def out_hw(self, h: int, w: int):
+        f = lambda v: (v - 1) * self.k - 2 * self.pad + self.k + self.opad
+        return f(h), f(w)
+
+    def uses_amax(self, B: int, h: int, w: int) -> bool:
+        return False
+
+    def __call__(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, amax_in=None, amax_out=None) -> torch.Tensor:
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        B, c, h, w = x.shape
+        if c != self.cin:
+            raise RuntimeError(f"PointwiseUpconv: input has {c} channels, layer expects {self.cin}")
+        oh, ow = self.out_hw(h, w)
+        if out is None:
+            out = torch.empty((B, self.out_c_total, oh, ow), dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (B, self.out_c_total, oh, ow) or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
+            raise RuntimeError(f"PointwiseUpconv: out must be a contiguous float32 {(B, self.out_c_total, oh, ow)} tensor in HBM")
+        a_out = None
+        if amax_out is not None:
+            a_out = amax_out.take(lib.lav_upconv_pointwise_parts(B, self.cin, self.cout, h, w, self.k, self.pad, self.opad))
+        check(lib.lav_upconv_pointwise(B, self.cin, self.cout, h, w, self.k, self.pad, self.opad, _ptr(x), _ptr(self.w), _ptr(self.scale),
+                                       _ptr(self.shift), int(self.relu_pre), self.out_c_total, self.out_c_offset, _ptr(out), _ptr(a_out), _stream()),
+              "lav_upconv_pointwise")
+        return out
+
+
 class Conv1dPair:
     """conv(3,1) -> ReLU -> conv(1,3) (+ eval BatchNorm, + residual, ReLU) as ONE lav_conv1d_pair launch: half of ERFNet's
     non_bottleneck_1d block.  `supported(x)` tells whether the row-tile kernel takes this shape."""

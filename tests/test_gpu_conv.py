@@ -766,3 +766,92 @@ def test_amax_hand_off_from_every_kernel_family(monkeypatch):
     with ops.batch_limit(n_dev):
         layer(x, out=out, amax_out=am)
     assert am.buf[:am.count].max().item() == out[:3].abs().max().item()
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,opad,h,w,B", [(64, 128, 1, 0, 0, 160, 160, 1), (128, 128, 4, 1, 2, 40, 40, 1), (64, 96, 4, 0, 0, 9, 13, 2),
+                                                       (128, 256, 1, 0, 0, 7, 50, 3), (128, 32, 4, 3, 1, 5, 5, 1), (64, 64, 4, 2, 3, 11, 6, 2)])
+def test_pointwise_upconv_matches_torch(cin, cout, k, pad, opad, h, w, B):
+    """lav_upconv_pointwise (round 6: transposed convolutions with kernel == stride as k*k independent exact-fp32 matrix products - the
+    BEV backbone's 1x1 and 4x4 / stride-4 up-convolutions, team_code_v2/models/lidar.py:114-131) against ConvTranspose2d -> ReLU ->
+    eval BatchNorm in float64: the error of an fp32 dot product; the channel slice of a wider map is written and nothing else; the
+    parts it leaves bound what it wrote (and equal its largest magnitude); the host packer is the device permutation; refresh()
+    follows in-place parameter changes."""
+    import torch.nn as nn
+    from lav_amd import _lib, ops
+    from lav_amd.ops import Amax, PointwiseUpconv
+    import ctypes as C
+    torch.manual_seed(cin + cout + k + h)
+    ct = nn.ConvTranspose2d(cin, cout, k, k, pad, opad, bias=False).to(DEV)
+    bn = nn.BatchNorm2d(cout, eps=1e-3).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    assert PointwiseUpconv.takes(ct)
+    total, off = cout + 48, 16
+    layer = PointwiseUpconv(ct, bn, relu_pre=True, out_c_total=total, out_c_offset=off, device=DEV)
+    x = torch.randn((B, cin, h, w), device=DEV)
+
+    def ref():
+        with torch.no_grad():
+            y = F.conv_transpose2d(x.double().cpu(), ct.weight.double().cpu(), None, k, pad, opad)
+            return F.batch_norm(torch.relu(y), bn.running_mean.double().cpu(), bn.running_var.double().cpu(), bn.weight.double().cpu(),
+                                bn.bias.double().cpu(), False, 0.0, bn.eps)
+    want = ref()
+    oh, ow = layer.out_hw(h, w)
+    assert tuple(want.shape) == (B, cout, oh, ow)
+    out = torch.full((B, total, oh, ow), -7.0, device=DEV)
+    am = Amax(DEV)
+    layer(x, out=out, amax_out=am)
+    torch.cuda.synchronize()
+    got = out[:, off:off + cout].double().cpu()
+    # error of an fp32 dot product: |sum w x| accumulated in fp32 over cin terms
+    with torch.no_grad():
+        mag = F.conv_transpose2d(x.double().abs().cpu(), ct.weight.double().abs().cpu(), None, k, pad, opad) * (bn.weight.double().cpu() / torch.sqrt(bn.running_var.double().cpu() + bn.eps)).abs()[None, :, None, None]
+    err = (got - want).abs()
+    assert bool((err <= 2e-6 * mag + 1e-6 * want.abs() + 1e-7).all()), f"max err {err.max().item():.3e}"
+    assert bool((out[:, :off] == -7.0).all()) and bool((out[:, off + cout:] == -7.0).all()), "wrote outside its channel slice"
+    assert am.count == _lib.load().lav_upconv_pointwise_parts(B, cin, cout, h, w, k, pad, opad) > 0
+    assert float(am.buf[:am.count].max()) == float(out[:, off:off + cout].abs().max())
+    # host packer == the device permutation
+    lib = _lib.load()
+    n = lib.lav_upconv_pointwise_packed_floats(cin, cout, k)
+    assert n == layer.w.numel()
+    hw = ct.weight.detach().cpu().contiguous()
+    packed = torch.empty(n, dtype=torch.float32)
+    assert lib.lav_upconv_pointwise_pack(cin, cout, k, hw.data_ptr(), packed.data_ptr()) == 0
+    assert torch.equal(packed, layer.w.cpu())
+    # in-place parameter change -> refresh() -> the same buffers, new values
+    ptrs = (layer.w.data_ptr(), layer.scale.data_ptr())
+    with torch.no_grad():
+        ct.weight.mul_(0.5); bn.bias.add_(0.25)
+    layer.refresh()
+    assert ptrs == (layer.w.data_ptr(), layer.scale.data_ptr())
+    layer(x, out=out)
+    torch.cuda.synchronize()
+    want2 = ref()
+    assert (out[:, off:off + cout].double().cpu() - want2).abs().max().item() < 1e-4 * max(1.0, want2.abs().max().item())
+
+
+def test_backbone_takes_the_pointwise_upconvs_only_for_the_fp16_engines():
+    """ConvBackbone's engine: at LAV_CONV_F16X3 (the inference pipelines) upconv1 / upconv3 run on lav_upconv_pointwise, upconv2 (4x4 stride 2:
+    four taps per output pixel) and every other precision stay on lav_conv2d; both engines agree to the error of an fp32 dot product and
+    the feature map's bound covers the pointwise layers' slices."""
+    from lav_amd import _lib, ops
+    from lav_amd.ops import PointwiseUpconv
+    from tests.util import build_models
+    lm, _ = build_models(DEV)
+    bb = lm.backbone
+    x = torch.randn((1, 64, 320, 320), device=DEV).relu_()
+    with ops.precision(_lib.CONV_F16X3):
+        e16 = bb._engine(x.device)
+        y16 = bb(x)
+    kinds = [type(u).__name__ for u in e16["ups"]]
+    assert kinds == ["PointwiseUpconv", "ConvLayer", "PointwiseUpconv"], kinds
+    am = ops.amax_of(y16)
+    assert am is not None and float(am.buf[:am.count].max()) >= float(y16.abs().max())
+    with ops.precision(_lib.CONV_BF16X6):
+        ebf = bb._engine(x.device)
+        ybf = bb(x)
+    assert all(type(u).__name__ == "ConvLayer" for u in ebf["ups"])
+    torch.cuda.synchronize()
+    scale = float(ybf.abs().max())
+    assert float((y16 - ybf).abs().max()) < 3e-5 * scale
