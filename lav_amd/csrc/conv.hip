@@ -545,10 +545,13 @@ int choose_tile(const lav_conv &c, const Plan &p, ConvArgs &a, int &MP, int &MC,
             const int ks_max = force_ks ? force_ks : (nchunks >= 4 ? std::min(16, nchunks / 2) : 1);
             // partial sums: ks slabs of the output written by the tiles and read back by the reduce launch (~4 TB/s)
             const double slab_us = (double)c.batch * c.cout * p.OH * p.OW * 4.0 * 2.0 / 4e6;
+            // what a split costs besides its partial-sum traffic: the reduce launch.  6 us was calibrated on stand-alone layers; LAV_CONV_KS_COST
+            // re-prices it (round 6: inside the frame the extra launch and its workgroups also cost the other streams - tools/frame_ab.py)
+            static const double ks_cost = [] { const char *e = getenv("LAV_CONV_KS_COST"); return e ? atof(e) : 6.0; }();
             for (int ks = force_ks ? force_ks : 1; ks <= ks_max; ++ks) {
                 const long wgs = g.nwg * ks;
                 const double t = (double)((wgs + ncu - 1) / ncu) * ((nchunks + ks - 1) / ks) * unit +
-                                 (double)((wgs + ncu * per_cu - 1) / (ncu * per_cu)) * 5.0 + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
+                                 (double)((wgs + ncu * per_cu - 1) / (ncu * per_cu)) * 5.0 + (ks > 1 ? ks_cost + ks * slab_us : 0.0);
                 if (t < best * (ks > 1 ? 0.97 : 1.0) - 1e-9) {   // a larger split must pay for its partial-sum traffic
                     best = t; MP = cd[0]; MC = cd[1]; bg = g; found = true; a.ksplit = ks;
                 }
@@ -813,8 +816,14 @@ DirectPlan choose_direct(const lav_conv &c, const Plan &p) {
                 // every tap re-reads its operands from L2 (no LDS tile): ~10.8 TB/s over the chip bounds large layers; a wave's
                 // load batches are serialised a ring at a time (+0.05 us per batch favours more, shorter waves)
                 const double l2_us = (double)wgs * taps * cks * 32 * 4.0 * (mc + 1) / 10.8e6;
+                // (the reduce launch: 3.5 us is what it adds to a layer measured alone (tools/direct_probe.py); inside the frame it is one more
+                //  launch in a chain of dependent ones and its workgroups compete with the other streams'.  Round 6 priced it by the frame
+                //  (tools/frame_ab.py, profiles/r06_frame_experiments.txt section 8): 3.5 -> 2.031-2.040 ms, 7 / 8 -> 2.021-2.031, 9.5 -> 2.012-2.025,
+                //  10.5 -> 2.017-2.031, 11.2 / 12 -> 2.026-2.038 (the ego branch's 256- and 512-channel layers lose their split: 531 -> 564 us),
+                //  never -> 2.052-2.061.  LAV_CONV_DIRECT_KS_COST re-prices it.)
+                static const double dks_cost = [] { const char *e = getenv("LAV_CONV_DIRECT_KS_COST"); return e ? atof(e) : 9.5; }();
                 const double t = 6.5 + std::max((mc == 1 ? 1.5 : 1.15) * waves_per_simd * mpw * 0.0267, l2_us) + 0.05 * taps * (cw / 8) +
-                                 0.04 * mc * waves * std::max(1.0, (double)wgs / 256.0) + (ks > 1 ? 3.5 + ks * slab_us : 0.0);   // + LDS reduction per workgroup round
+                                 0.04 * mc * waves * std::max(1.0, (double)wgs / 256.0) + (ks > 1 ? dks_cost + ks * slab_us : 0.0);   // + LDS reduction per workgroup round
                 if (t < d.cost) d = DirectPlan{true, waves, ks, cw, t, tiles, mc};
             }
         }

@@ -282,7 +282,8 @@ inline SplitPlan choose_split(const lav_conv &c, const Plan &p) {
                         // a K loop of very few steps (1x1 and stride-4 up-convolutions, parity classes of one tap) never fills the
                         // loader / compute pipeline: measured 21-35 us where the direct fp32 kernel takes 17-29 (round-4 sweep)
                         const double short_loop_us = nchunks * min_taps <= 8 ? 6.0 : 0.0;
-                        const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + short_loop_us + nch * chunk_us) + (ks > 1 ? 6.0 + ks * slab_us : 0.0);
+                        static const double sks_cost = [] { const char *e = getenv("LAV_SPLIT_KS_COST"); return e ? atof(e) : 6.0; }();   // price of the reduce launch
+                        const double t = (double)((wgs + ncu - 1) / ncu) * (c_fixed + short_loop_us + nch * chunk_us) + (ks > 1 ? sks_cost + ks * slab_us : 0.0);
                         if (t < best.cost * (ks > 1 ? 0.97 : 1.0) - 1e-9) {
                             best = SplitPlan{true, MP, MC, WPX, tw, th, tiles_x, (int)tiles, Wst, Wsub, ROWS, plane, G, ks, 3 * G, lds, t, tp};
                         }
@@ -391,6 +392,28 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
     // launch has neither (lav_conv2d measures its output with a launch)
     s.amax_out = sp.ksplit == 1 && !sp.sk_w ? io.out : nullptr;
     s.sync_off = (int)((sp.lds + 15) / 16 * 16);
+    auto print_trace = [&]() {
+        static int runs = 0;
+        if (s.trace && ++runs % 8 == 0) {   // debug: where the workgroups' time goes (cycles of the shader clock)
+        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+        if (nwg <= 65536) {
+            std::vector<long long> h(nwg * 8);
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                double pro = 0, loop = 0, cw = 0, lconv = 0, lw = 0, dw = 0;
+                long long t0 = h[0], t1 = 0;
+                for (size_t i = 0; i < nwg; ++i) {
+                    pro += (double)(h[i * 8 + 1] - h[i * 8]); loop += (double)(h[i * 8 + 2] - h[i * 8 + 1]);
+                    cw += (double)h[i * 8 + 4]; lconv += (double)h[i * 8 + 5]; lw += (double)h[i * 8 + 6]; dw += (double)h[i * 8 + 7];
+                    t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 2]);
+                }
+                const int nst = (s.nchunks / sp.ksplit) * p.taps_per_class;
+                fprintf(stderr, "[split trace] %zu wgs %dx%d/w%d tw%d ring %d ks%d, %d steps: span %.0f kcyc | per wg: prologue wait %.0f, loop %.0f cyc (%.0f per step) | barrier wait: compute %.0f, loaders %.0f (convert %.0f) %.0f\n",
+                        nwg, sp.MP, sp.MC, sp.WPX, sp.tw, sp.wring, sp.ksplit, nst, (double)(t1 - t0) / 1e3, pro / nwg, loop / nwg, loop / nwg / std::max(nst, 1),
+                        cw / nwg, lw / nwg, lconv / nwg, dw / nwg);
+            }
+        }
+    }
+    };
     if (sp.f16) {
         // w_f16: the fp16 section of the packed weights (class offsets in two-piece units); the scale of x from the producers' maxima,
         // else measured here
@@ -434,6 +457,7 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
         }
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
+        print_trace();
         return LAV_OK;
     }
     if (sp.sk_w) {
@@ -480,25 +504,6 @@ inline int launch_split(const lav_conv &c, const Plan &p, const SplitPlan &sp, c
     }
     timer_end(tok, st);
     LAV_LAUNCH_CHECK();
-    static int runs = 0;
-    if (s.trace && ++runs % 8 == 0) {   // debug: where the workgroups' time goes (cycles of the shader clock)
-        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
-        if (nwg <= 65536) {
-            std::vector<long long> h(nwg * 8);
-            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-                double pro = 0, loop = 0, cw = 0, lconv = 0, lw = 0, dw = 0;
-                long long t0 = h[0], t1 = 0;
-                for (size_t i = 0; i < nwg; ++i) {
-                    pro += (double)(h[i * 8 + 1] - h[i * 8]); loop += (double)(h[i * 8 + 2] - h[i * 8 + 1]);
-                    cw += (double)h[i * 8 + 4]; lconv += (double)h[i * 8 + 5]; lw += (double)h[i * 8 + 6]; dw += (double)h[i * 8 + 7];
-                    t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 2]);
-                }
-                const int nst = (s.nchunks / sp.ksplit) * p.taps_per_class;
-                fprintf(stderr, "[split trace] %zu wgs %dx%d/w%d tw%d ring %d ks%d, %d steps: span %.0f kcyc | per wg: prologue wait %.0f, loop %.0f cyc (%.0f per step) | barrier wait: compute %.0f, loaders %.0f (convert %.0f) %.0f\n",
-                        nwg, sp.MP, sp.MC, sp.WPX, sp.tw, sp.wring, sp.ksplit, nst, (double)(t1 - t0) / 1e3, pro / nwg, loop / nwg, loop / nwg / std::max(nst, 1),
-                        cw / nwg, lw / nwg, lconv / nwg, dw / nwg);
-            }
-        }
-    }
+    print_trace();
     return LAV_OK;
 }
