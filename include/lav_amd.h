@@ -607,6 +607,14 @@ int lav_conv1d_pair_chain_f16(int batch, int channels, int h, int w, int npairs,
                               const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
                               const float *const *wb_packed, const float *const *bias_b, const float *const *scale,
                               const float *const *shift, float *const *out, void *workspace, size_t workspace_bytes, void *stream);
+/* lav_conv1d_pair_chain_region (ABI 28): several runs that follow each other on one stream share ONE cleaning of their progress counters.
+ * The runs THIS THREAD enqueues from now on keep their counters at rows [row_offset, row_offset + batch * h) of the workspace's counter
+ * array (capacity: what lav_conv1d_pair_chain_workspace_bytes was asked for, rounded up to 64 rows) and, in front of the run, zero the
+ * first clean_rows counters of the array (clean_rows > 0: the first run of a sequence, for all of them), nothing (0: a launch earlier on the
+ * stream cleaned this run's rows - each region is good for ONE run per cleaning), or their own rows (-1 with row_offset 0: the default,
+ * one small launch in front of every run).  ERFNet's four runs per frame: one cleaning launch instead of four (lav/models/erfnet.py:109-131).
+ * A pointer-free thread-local setting like lav_batch_limit: captured launches keep what was set when they were enqueued. */
+int lav_conv1d_pair_chain_region(int row_offset, int clean_rows);
 int lav_conv1d_pair_chain_status(const void *workspace, int *h_timeouts_launches2, void *stream);
 size_t lav_conv1d_pair_lds_bytes(int channels, int w, int d_b);
 int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, int d_b, const float *x, const float *wa_packed,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "lav_upconv_pointwise_parts": (_I, [_I] * 8),
     "lav_upconv_pointwise": (_I, [_I] * 8 + [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "lav_conv1d_pair_chain_workspace_bytes": (_Z, [_I, _I]),
+    "lav_conv1d_pair_chain_region": (_I, [_I, _I]),
     "lav_conv1d_pair_chain_lds_bytes": (_Z, [_I, _I, _I]),
     "lav_conv1d_pair_chain": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P] + [C.POINTER(_P)] * 7 + [_P, _Z, _P]),
     "lav_conv1d_pair_chain_f16": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _P] + [C.POINTER(_P)] * 7 + [_P, _Z, _P]),

@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
     const long plane = (long)H * W;
     const long base = (long)n * C * plane + (long)y * W + px;
     if (tid == 0) s_abort = 0;
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(a.sticky + 1, 1);   // launches on this workspace (k_zero_ints did this until round 6: it no longer runs in front of every launch)
 
     u32x4 wr[R][3][3];
     auto load_w = [&](const unsigned char *wp, int t, int chunk, u32x4 (&dst)[3]) {
@@ -846,7 +847,8 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
 struct PairChainF16Args {
     PairChainArgs c;
     const float *tA[CHAIN_MAX], *tB[CHAIN_MAX];   // tails of the fp16 sections: {weight scale, largest L1 norm of a filter}
-    float *rowmax;                                // [CHAIN_MAX][B*H]: largest finite magnitude of pair i's output row
+    float *rowmax;                                // [CHAIN_MAX][rm_stride], the run's rows from its region's first: largest finite magnitude of pair i's output row
+    int rm_stride;
     int dbmax;
 };
 typedef _Float16 pair_f16x2 __attribute__((ext_vector_type(2)));
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
     const int px = pg * 32 + l31;
     const bool co_ok = cg * 32 < CP;
     const int nchunk = C >> 4, nblk = CP >> 5;
-    const int nrows = a.B * H;
+    const long rm_stride = fa.rm_stride;
     // LDS: s_red [4 waves][16][64] floats, s_in [2 pieces][nchunk][2][3 rows][W] x 16 B, s_mid [2 pieces][nchunk][2][W + 2 dbmax] x 16 B
     const int in_piece = nchunk * 2 * 3 * W * 16;
     const int dbmax = fa.dbmax, WM = W + 2 * dbmax, mid_piece = nchunk * 2 * WM * 16;
@@ -889,6 +891,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
     const long plane = (long)H * W;
     const long base = (long)n * C * plane + (long)y * W + px;
     if (tid == 0) s_abort = 0;
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(a.sticky + 1, 1);
 
     u32x4 wr[R][3][2];
     auto load_w = [&](const unsigned char *wp, int t, int chunk, u32x4 (&dst)[2]) {
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                     }
                 }
                 if (ok) {
-                    const float *rm = fa.rowmax + (long)(p - 1) * nrows + n * H;
+                    const float *rm = fa.rowmax + (long)(p - 1) * rm_stride + n * H;
                     const float mu = yu >= 0 ? __hip_atomic_load(rm + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
                     const float md = yd < H ? __hip_atomic_load(rm + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
                     if (lane == 0) s_m3 = fmaxf(m_own, fmaxf(finite_abs(mu), finite_abs(md)));
@@ -1207,7 +1210,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
         if (wid8 == 0) {
             m_own = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
             if (lane == 0) {
-                __hip_atomic_store(fa.rowmax + (long)p * nrows + n * H + y, m_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fa.rowmax + (long)p * rm_stride + n * H + y, m_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(a.flags + n * H + y, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1406,17 +1409,28 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
 }
 
 namespace {
-__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *launches) {
+__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *abort_word) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0;
-    if (i == 0) { atomicAdd(launches, 1); launches[1] = 0; }   // launches = sticky + 1; sticky[2] = this launch's abort word
+    if (i == 0) *abort_word = 0;   // sticky[2]: the abort word of the launches that follow
 }
 
+// lav_conv1d_pair_chain_region: where this thread's next runs keep their counters, and what they clean first
+thread_local int g_chain_row_offset = 0, g_chain_clean_rows = -1;
+inline size_t chain_cap_rows(size_t workspace_bytes) { return workspace_bytes > 256 ? (workspace_bytes - 256) / 68 / 64 * 64 : 0; }
 }  // namespace
 
 extern "C" size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h) {
-    // sticky counters + per-row progress + (fp16 run) every pair's per-row maxima
-    return batch > 0 && h > 0 ? 256 + lav::align_up((size_t)(batch * h) * sizeof(int), 256) + (size_t)CHAIN_MAX * batch * h * sizeof(float) : 0;
+    // sticky counters | per-row progress counters (capacity rounded up to 64 rows) | (fp16 run) every pair's per-row maxima
+    if (batch <= 0 || h <= 0) return 0;
+    const size_t cap = ((size_t)batch * h + 63) / 64 * 64;
+    return 256 + cap * 68;
+}
+
+extern "C" int lav_conv1d_pair_chain_region(int row_offset, int clean_rows) {
+    LAV_REQUIRE(row_offset >= 0 && clean_rows >= -1 && (clean_rows >= 0 || row_offset == 0), "lav_conv1d_pair_chain_region: offset >= 0, clean_rows >= 0 (or -1 at offset 0: the default)");
+    g_chain_row_offset = row_offset; g_chain_clean_rows = clean_rows;
+    return LAV_OK;
 }
 
 extern "C" size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max) {
@@ -1461,7 +1475,11 @@ static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, in
         dbmax = std::max(dbmax, d_b[j]);
     }
     LAV_REQUIRE(!residual[0], "lav_conv1d_pair_chain: the run starts at a block boundary (its first pair has no residual)");
-    a.x0 = x; a.sticky = static_cast<int *>(workspace); a.flags = a.sticky + 64;
+    const size_t cap_rows = chain_cap_rows(workspace_bytes);
+    const int row_off = g_chain_row_offset, clean_rows = g_chain_clean_rows;
+    LAV_REQUIRE((size_t)row_off + (size_t)batch * h <= cap_rows && (clean_rows < 0 || (size_t)clean_rows <= cap_rows),
+                "lav_conv1d_pair_chain: rows %d + %d exceed the workspace's %zu counters (lav_conv1d_pair_chain_region)", row_off, batch * h, cap_rows);
+    a.x0 = x; a.sticky = static_cast<int *>(workspace); a.flags = a.sticky + 64 + row_off;
     a.B = batch; a.C = channels; a.H = h; a.W = w; a.CP = (channels + 31) / 32 * 32; a.npairs = npairs;
     const char *lim = getenv("LAV_CHAIN_SPIN_LIMIT");   // test knob: 0 makes every wait that is not satisfied at once a time-out
     a.spin_limit = lim ? std::max(0ll, atoll(lim)) : (1ll << 21);
@@ -1469,7 +1487,10 @@ static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, in
     LAV_REQUIRE(lds <= 152 * 1024, "lav_conv1d_pair_chain: %zu bytes of LDS needed", lds);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nflag = batch * h;
-    hipLaunchKernelGGL(k_zero_ints, dim3((nflag + 255) / 256), dim3(256), 0, st, a.flags, nflag, a.sticky + 1);
+    // counters at zero: this run's own (default), the first `clean_rows` of the array (the first of several runs that share one
+    // cleaning), or nothing (clean_rows = 0: a launch earlier on the stream cleaned this run's region)
+    if (clean_rows < 0) hipLaunchKernelGGL(k_zero_ints, dim3((nflag + 255) / 256), dim3(256), 0, st, a.flags, nflag, a.sticky + 2);
+    else if (clean_rows > 0) hipLaunchKernelGGL(k_zero_ints, dim3((clean_rows + 255) / 256), dim3(256), 0, st, a.sticky + 64, clean_rows, a.sticky + 2);
     const int ks2 = channels >= 64 && (channels / 16) % 2 == 0 ? 2 : 1;
     const int nch2 = channels / 16 / ks2;
     // weight ring of at most two chunks: the four-chunk ring of the single-pair kernel does not fit the registers next to the
@@ -1488,7 +1509,8 @@ static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, in
             fa.tA[i] = wa_packed[j] + sec + pair_f16_bytes(channels) / 4;
             fa.tB[i] = wb_packed[j] + sec + pair_f16_bytes(channels) / 4;
         }
-        fa.rowmax = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + lav::align_up((size_t)nflag * sizeof(int), 256));
+        fa.rowmax = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + cap_rows * sizeof(int)) + row_off;
+        fa.rm_stride = (int)cap_rows;
         fa.dbmax = dbmax;
         const size_t lds16 = 16384 + (size_t)channels * w * 12 + (size_t)channels * (w + 2 * dbmax) * 4;
         constexpr size_t F16_STATIC_LDS = 2064 + 64;   // s_abort, s_epi, s_wmax, s_bmax, s_m3

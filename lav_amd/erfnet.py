@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .ops import Conv1dPair, Conv1dPairChain, ConvLayer, GroupedDeconv, infer_precision
 
 _USE_PAIRS = os.environ.get("LAV_ERFNET_PAIRS", "1") != "0"   # A/B switch: 0 = four lav_conv2d launches per block
@@ -227,6 +228,20 @@ class ERFNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("ERFNet: eval-mode forward needs a tensor in HBM - lav_amd has no CPU path "
                                "(CPU evaluation for tests and baselines: oracle/camera.py)")
+        # round 6: the persistent runs of one pass share ONE cleaning of their progress counters - the first run zeroes the whole counter
+        # array, each run keeps its counters in a region of its own behind the previous run's (ops.pair_chain_region) - instead of a small
+        # launch in front of every run (4 x 4.7 us of the frame's lidar graph).  LAV_CHAIN_SHARED_CLEAN=0: every run cleans its own.
+        shared = os.environ.get("LAV_CHAIN_SHARED_CLEAN", "1") != "0"
+        cap, off, first = ops.pair_chain_capacity(x.device), 0, True
         for stage in self._engine(x.device, input_affine, softmax):
-            x = stage(x)
+            chain = getattr(stage, "chain", None)
+            rows = x.shape[0] * x.shape[2]
+            if shared and chain is not None and chain.supported(x) and off + rows <= cap:
+                with ops.pair_chain_region(off, cap if first else 0):
+                    x = stage(x)
+                off, first = off + rows, False
+            else:
+                if chain is not None:
+                    shared = False   # (a run outside the scheme cleans rows from 0 on: later runs must not rely on the shared cleaning)
+                x = stage(x)
         return x

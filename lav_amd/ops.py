@@ -817,7 +817,7 @@ class Conv1dPairChain:
         out = bufs + [torch.empty_like(x)]
         # sized ONCE for the largest run the chip can hold (2 rows per CU): the buffer never grows, so the sticky time-out / launch
         # counters of already captured graphs stay the ones pair_chain_status() reads
-        ws = _workspace("pair_chain", max(lib.lav_conv1d_pair_chain_workspace_bytes(B, h), lib.lav_conv1d_pair_chain_workspace_bytes(2 * _cu_count(x.device), 1)), x.device)
+        ws = _workspace("pair_chain", max(lib.lav_conv1d_pair_chain_workspace_bytes(B, h), lib.lav_conv1d_pair_chain_workspace_bytes(pair_chain_capacity(x.device), 1)), x.device)
         ia = lambda vals: (C.c_int * n)(*vals)
         pa = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
         ps = self.pairs
@@ -830,6 +830,28 @@ class Conv1dPairChain:
     def timeouts(self, x_like: torch.Tensor) -> int:
         """Workgroups of pair-chain launches on the current stream that gave up waiting for a neighbour row (0 = all results valid)."""
         return pair_chain_status(x_like.device)[0]
+
+
+def pair_chain_capacity(device) -> int:
+    """Rows of progress counters in the pair-chain workspace: room for several runs' regions (pair_chain_region)."""
+    return 4 * _cu_count(device)
+
+
+class pair_chain_region:
+    """`with ops.pair_chain_region(row_offset, clean_rows):` - the Conv1dPairChain launches enqueued inside keep their progress counters at
+    that offset of the workspace and zero the first `clean_rows` counters first (0: cleaned by an earlier launch; lav_conv1d_pair_chain_region).
+    ERFNet's runs use it to share one cleaning launch per forward pass."""
+
+    def __init__(self, row_offset: int, clean_rows: int):
+        self.args = (int(row_offset), int(clean_rows))
+
+    def __enter__(self):
+        check(_lib.load().lav_conv1d_pair_chain_region(*self.args), "lav_conv1d_pair_chain_region")
+        return self
+
+    def __exit__(self, *exc):
+        check(_lib.load().lav_conv1d_pair_chain_region(0, -1), "lav_conv1d_pair_chain_region")
+        return False
 
 
 def pair_chain_status(device, stream=None):

@@ -225,3 +225,38 @@ def test_forced_others_hook_runs_the_others_branch_on_the_given_poses(models):
     pipe.set_forced_others(None)
     free = step(4)
     assert free["other_cast_locs"].shape[0] == min(len(up.others_from_detections(free["det"][1], 320, 320)[0]), 15)
+
+
+def test_erfnet_runs_share_one_cleaning_of_their_counters(monkeypatch):
+    """Round 6: ERFNet's four persistent runs of a pass keep their progress counters in regions of one array that the FIRST run zeroes for
+    all of them (lav_conv1d_pair_chain_region) instead of a small launch in front of every run: bit-identical to every run cleaning its
+    own, pass after pass (each pass cleans again), in both precisions, eagerly and replayed from a HIP graph; no workgroup times out and
+    every run is counted."""
+    from lav_amd import _lib, ops
+    from lav_amd.rgb import RGBSegmentationModel
+    seg = RGBSegmentationModel([4, 6, 7, 10]); seg.load_state_dict(synth.seeded_state_dict(seg, prefix="seg.")); seg.eval().to(DEV)
+    cams, _ = synth.rgb_frames()
+    x = torch.tensor(np.stack([c[..., :3][..., ::-1] for c in cams], 0).copy()).permute(0, 3, 1, 2).float().to(DEV)
+    for prec in (_lib.CONV_F16X3, _lib.CONV_BF16X6):
+        with torch.no_grad(), ops.precision(prec):
+            monkeypatch.setenv("LAV_CHAIN_SHARED_CLEAN", "0")
+            want = seg(x).clone()
+            monkeypatch.setenv("LAV_CHAIN_SHARED_CLEAN", "1")
+            t0, n0 = ops.pair_chain_status(DEV)
+            got = [seg(x).clone() for _ in range(3)]
+            t1, n1 = ops.pair_chain_status(DEV)
+            assert t1 == t0 and n1 == n0 + 3 * 4, (t0, n0, t1, n1)
+            assert all(torch.equal(g, want) for g in got)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                seg(x)                      # (workspace of the capture stream)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                y = seg(x)
+            for _ in range(3):
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(y, want)
+            with torch.cuda.stream(s):
+                assert ops.pair_chain_status(DEV)[0] == 0
