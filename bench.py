@@ -31,9 +31,10 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (same guide); the split convolution kernels run on these pipes
 DTYPE = ("f32 (convolution contractions on the matrix cores with f32 accumulate at the error of an fp32 dot product, DESIGN 4.3: the layers on "
-         "the split-operand kernel - BEV backbone, heads, crop stems, the brake net's mid-size layers - as two power-of-two-scaled fp16 pieces "
-         "per fp32 operand and three partial products, ERFNet's pairs as three bf16 pieces and six products, the small layers on the fp32 MFMA; "
-         "LAV_INFER_PRECISION=bf16x6 restores round 5's bf16 pieces everywhere; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
+         "the split-operand kernel - BEV backbone, heads, crop stems, the brake net's mid-size layers - and ERFNet's persistent runs of pairs as two "
+         "power-of-two-scaled fp16 pieces per fp32 operand and three partial products, the small layers and the backbone's 1x1 / 4x4-stride-4 "
+         "up-convolutions on the fp32 MFMA (exact products); LAV_INFER_PRECISION=bf16x6 restores round 5's three bf16 pieces / six products "
+         "everywhere; LAV_CONV_PRECISION=f32 selects the fp32-MFMA kernels)")
 
 
 def build_pipeline(device, eager=False):
@@ -669,7 +670,8 @@ def main():
             finally:
                 torch.Tensor.copy_ = orig
             torch.cuda.synchronize()
-            per_frame[label] = {k: round(v / 10, 1) for k, v in sorted(counts.items())}
+            per_frame[label] = {k: round(counts.get(k, 0) / 10, 1) for k in ("d2h", "h2d")}   # (round 6: 0 / 0 with resident inputs - the peak rows
+            #  reach the host through lav_det_decode_report's stores into pinned memory, the pose block rides in the staging launch's arguments)
         return dict(ms_per_step=round(ms, 4), frames_per_s=round(1e3 / ms, 2), steps=steps, bytes_per_frame=int(nbytes),
                     h2d_ms_per_frame=round(h2d_ms, 4), h2d_GBs=round(nbytes / h2d_ms / 1e6, 1),
                     note="float32 camera tensors (7.0 MB per frame: an upper bound - the agent itself uploads uint8 images, 3.2 MB); pinned host memory",
