@@ -836,8 +836,9 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
 // operand is scaled by a power of two first (exact): the weights by their convolution's largest magnitude at packing time (the
 // scale rides behind the packed pieces), the activations by a scale the WORKGROUP derives per pair from the largest finite
 // magnitude of the three rows it multiplies - its own row's maximum (a wave reduction in the epilogue that produced the row) and
-// the two neighbour rows' maxima, which travel with the hand-off: a row publishes rowmax[pair][row] before it raises its progress
-// counter.  The intermediate row (ReLU of the vertical convolution) is scaled by a BOUND instead of its maximum - (largest input
+// the two neighbour rows' maxima, which travel with the hand-off IN its flag: a row publishes ONE 64-bit word per pair, {pairs done |
+// maximum of the row it just wrote} (rowmax[pair][row], zero at the start of a pass), and its neighbours poll that word - count and
+// maximum arrive in one load, the plain progress counters of the bf16 run are not used.  The intermediate row (ReLU of the vertical convolution) is scaled by a BOUND instead of its maximum - (largest input
 // magnitude) x (largest L1 norm of a filter, from the packing) + largest |bias| - so that no barrier is added between the two
 // phases: two fp16 pieces keep 22 significant bits over 18 binades below the scale's top, a bound that is loose by a few binades
 // costs nothing (tests/test_gpu_conv.py holds the run to the fp32 dot product's error against float64).
@@ -847,7 +848,10 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain(PairChainArgs a)
 struct PairChainF16Args {
     PairChainArgs c;
     const float *tA[CHAIN_MAX], *tB[CHAIN_MAX];   // tails of the fp16 sections: {weight scale, largest L1 norm of a filter}
-    float *rowmax;                                // [CHAIN_MAX][rm_stride], the run's rows from its region's first: largest finite magnitude of pair i's output row
+    // [CHAIN_MAX][rm_stride] 64-bit words, the run's rows from its region's first: {pairs done = i + 1 | largest finite magnitude of pair i's output row},
+    // zero at the start of a pass.  The word IS the hand-off's flag: count and maximum arrive in one load (a counter followed by a separate
+    // maximum cost the producer a second drained store and the consumer a second round trip per pair - the first version of this kernel).
+    unsigned long long *rowmax;
     int rm_stride;
     int dbmax;
 };
@@ -1010,10 +1014,12 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                 const int yu = y - dA, yd = y + dA;
                 long long spins = 0;
                 bool ok = false;
+                const unsigned long long *rm = fa.rowmax + (long)(p - 1) * rm_stride + n * H;
+                unsigned long long wu = (unsigned long long)p << 32, wd = (unsigned long long)p << 32;   // rows outside the image: done, maximum 0
                 while (!ok) {
-                    const int fu = yu >= 0 ? __hip_atomic_load(a.flags + n * H + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
-                    const int fd = yd < H ? __hip_atomic_load(a.flags + n * H + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p;
-                    ok = fu >= p && fd >= p;
+                    if (yu >= 0) wu = __hip_atomic_load(rm + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (yd < H) wd = __hip_atomic_load(rm + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (int)(wu >> 32) == p && (int)(wd >> 32) == p;
                     if (!ok) {
                         ++spins;
                         const bool timed_out = spins > a.spin_limit;
@@ -1028,12 +1034,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                if (ok) {
-                    const float *rm = fa.rowmax + (long)(p - 1) * rm_stride + n * H;
-                    const float mu = yu >= 0 ? __hip_atomic_load(rm + max(yu, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                    const float md = yd < H ? __hip_atomic_load(rm + min(yd, H - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                    if (lane == 0) s_m3 = fmaxf(m_own, fmaxf(finite_abs(mu), finite_abs(md)));
-                }
+                if (ok && lane == 0) s_m3 = fmaxf(m_own, fmaxf(finite_abs(__uint_as_float((unsigned)wu)), finite_abs(__uint_as_float((unsigned)wd))));
             }
             __syncthreads();
             if (*(volatile int *)&s_abort) {
@@ -1209,11 +1210,9 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
         __syncthreads();
         if (wid8 == 0) {
             m_own = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
-            if (lane == 0) {
-                __hip_atomic_store(fa.rowmax + (long)p * rm_stride + n * H + y, m_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(a.flags + n * H + y, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (lane == 0)
+                __hip_atomic_store(fa.rowmax + (long)p * rm_stride + n * H + y, ((unsigned long long)(p + 1) << 32) | __float_as_uint(m_own), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         if (*(volatile int *)&s_abort) return;
     }
@@ -1409,22 +1408,23 @@ extern "C" int lav_conv1d_pair(int batch, int channels, int h, int w, int d_a, i
 }
 
 namespace {
-__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *abort_word) {
+__global__ __launch_bounds__(256) void k_zero_ints(int *p, int n, int *q, int nq, int *abort_word) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0;
+    else if (i - n < nq) q[i - n] = 0;   // (the fp16 runs' count-and-maximum words)
     if (i == 0) *abort_word = 0;   // sticky[2]: the abort word of the launches that follow
 }
 
 // lav_conv1d_pair_chain_region: where this thread's next runs keep their counters, and what they clean first
 thread_local int g_chain_row_offset = 0, g_chain_clean_rows = -1;
-inline size_t chain_cap_rows(size_t workspace_bytes) { return workspace_bytes > 256 ? (workspace_bytes - 256) / 68 / 64 * 64 : 0; }
+inline size_t chain_cap_rows(size_t workspace_bytes) { return workspace_bytes > 256 ? (workspace_bytes - 256) / 132 / 64 * 64 : 0; }
 }  // namespace
 
 extern "C" size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h) {
-    // sticky counters | per-row progress counters (capacity rounded up to 64 rows) | (fp16 run) every pair's per-row maxima
+    // sticky counters | per-row progress counters (capacity rounded up to 64 rows) | (fp16 run) every pair's per-row count-and-maximum words
     if (batch <= 0 || h <= 0) return 0;
     const size_t cap = ((size_t)batch * h + 63) / 64 * 64;
-    return 256 + cap * 68;
+    return 256 + cap * 132;
 }
 
 extern "C" int lav_conv1d_pair_chain_region(int row_offset, int clean_rows) {
@@ -1489,8 +1489,13 @@ static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, in
     const int nflag = batch * h;
     // counters at zero: this run's own (default), the first `clean_rows` of the array (the first of several runs that share one
     // cleaning), or nothing (clean_rows = 0: a launch earlier on the stream cleaned this run's region)
-    if (clean_rows < 0) hipLaunchKernelGGL(k_zero_ints, dim3((nflag + 255) / 256), dim3(256), 0, st, a.flags, nflag, a.sticky + 2);
-    else if (clean_rows > 0) hipLaunchKernelGGL(k_zero_ints, dim3((clean_rows + 255) / 256), dim3(256), 0, st, a.sticky + 64, clean_rows, a.sticky + 2);
+    {
+        // (the fp16 runs hand off through their count-and-maximum words - 16 pairs x capacity rows x 8 bytes behind the counters, cleaned as a whole)
+        int *words = reinterpret_cast<int *>(static_cast<char *>(workspace) + 256 + cap_rows * sizeof(int));
+        const int nwords = f16 ? (int)(CHAIN_MAX * cap_rows * 2) : 0;
+        if (clean_rows < 0) hipLaunchKernelGGL(k_zero_ints, dim3((nflag + nwords + 255) / 256), dim3(256), 0, st, a.flags, nflag, words, nwords, a.sticky + 2);
+        else if (clean_rows > 0) hipLaunchKernelGGL(k_zero_ints, dim3((clean_rows + nwords + 255) / 256), dim3(256), 0, st, a.sticky + 64, clean_rows, words, nwords, a.sticky + 2);
+    }
     const int ks2 = channels >= 64 && (channels / 16) % 2 == 0 ? 2 : 1;
     const int nch2 = channels / 16 / ks2;
     // weight ring of at most two chunks: the four-chunk ring of the single-pair kernel does not fit the registers next to the
@@ -1509,7 +1514,7 @@ static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, in
             fa.tA[i] = wa_packed[j] + sec + pair_f16_bytes(channels) / 4;
             fa.tB[i] = wb_packed[j] + sec + pair_f16_bytes(channels) / 4;
         }
-        fa.rowmax = reinterpret_cast<float *>(static_cast<char *>(workspace) + 256 + cap_rows * sizeof(int)) + row_off;
+        fa.rowmax = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + 256 + cap_rows * sizeof(int)) + row_off;
         fa.rm_stride = (int)cap_rows;
         fa.dbmax = dbmax;
         const size_t lds16 = 16384 + (size_t)channels * w * 12 + (size_t)channels * (w + 2 * dbmax) * 4;
