@@ -1008,6 +1008,24 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
         const unsigned char *wA = a.wA[p], *wB = a.wB[p];
         const bool last = p + 1 == a.npairs;
         const float swA = fa.tA[p][0], l1A = fa.tA[p][1], swB = fa.tB[p][0];
+        {   // the pair's epilogue vectors through LDS, and the largest |bias| of the vertical convolution (for the intermediate row's bound):
+            // fetched by waves 1-2 while wave 0 polls its neighbours (everybody is past the previous pair's last read of them: the barrier
+            // that closed it); behind the hand-off their round trip stood in front of every pair's first matrix instruction
+            float bm = 0.f;
+            const int et = tid - 64;
+            if (et >= 0 && et < C) {
+                const float b0 = a.bA[p][et];
+                s_epi[0][et] = b0;
+                s_epi[1][et] = a.bB[p][et];
+                s_epi[2][et] = a.scale[p][et];
+                s_epi[3][et] = a.shift[p][et];
+                bm = finite_abs(b0);
+            }
+            if (wid8 == 1 || wid8 == 2) {
+                bm = wave_finite_absmax(bm);
+                if (lane == 0) s_bmax[wid8 - 1] = bm;
+            }
+        }
         if (p > 0) {
             // ---- the two neighbour rows of the previous pair's output: wait for their counters, take their maxima, then stage them
             if (wid8 == 0) {
@@ -1060,21 +1078,6 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                         *reinterpret_cast<u32x2 *>(s_in + in_piece + entry * 16 + half * 8) = u32x2{pk[1][0], pk[1][1]};
                     }
                 }
-            }
-        }
-        {   // the pair's epilogue vectors through LDS, and the largest |bias| of the vertical convolution (for the intermediate row's bound)
-            float bm = 0.f;
-            if (tid < C) {
-                const float b0 = a.bA[p][tid];
-                s_epi[0][tid] = b0;
-                s_epi[1][tid] = a.bB[p][tid];
-                s_epi[2][tid] = a.scale[p][tid];
-                s_epi[3][tid] = a.shift[p][tid];
-                bm = finite_abs(b0);
-            }
-            if (wid8 < 2) {
-                bm = wave_finite_absmax(bm);
-                if (lane == 0) s_bmax[wid8] = bm;
             }
         }
         __syncthreads();
