@@ -25,6 +25,7 @@ _COPY_STREAM = os.environ.get("LAV_COPY_STREAM", "0") == "1"   # the frame's dev
 _DET_REPORT = os.environ.get("LAV_DET_REPORT", "1") != "0"   # round 6: lav_det_decode writes the peak rows + count into pinned host memory itself and bumps a sequence word the host polls (no device->host copies, no event between the heads and the others graph)
 _POSE_BLOCK = os.environ.get("LAV_POSE_BLOCK", "1") != "0"   # round 6: the 176-byte pose block rides in the staging launch's kernel arguments (no upload of its own in front of the lidar graph)
 _BRAKE_AFTER = os.environ.get("LAV_BRAKE_AFTER", "in")       # "in": the brake graph starts with the frame (beside ERFNet + backbone); "feat": behind the lidar graph (beside heads / others / ego)
+_BRAKE_SPLIT = os.environ.get("LAV_BRAKE_SPLIT", "")        # "" (one graph with the frame) | "wide" | "tele": two graphs, the second behind the lidar graph
 _DIAG_SKIP = set(filter(None, os.environ.get("LAV_DIAG_SKIP", "").split(",")))   # timing diagnosis: skip side graphs
 
 
@@ -296,6 +297,20 @@ class GraphedFramePipeline(FramePipeline):
         ops.nonfinite_count([pred_bra], self.d_health)
         return dict(pred_bra=pred_bra)
 
+    # LAV_BRAKE_SPLIT (round 6 experiment): the brake net as two graphs on its stream - the first image's trunk with the frame, the second
+    # image's trunk + poolings + classifier behind the lidar graph ("wide": wide image first; "tele": tele image first)
+    def _g_brake_a(self):
+        first = self.b_rgbs if _BRAKE_SPLIT == "wide" else self.b_tel
+        return dict(x=self.bra_model.trunk(first))
+
+    def _g_brake_b(self):
+        xa = self.outs["brake_a"]["x"]
+        xb = self.bra_model.trunk(self.b_tel if _BRAKE_SPLIT == "wide" else self.b_rgbs)
+        x1, x2 = (xa, xb) if _BRAKE_SPLIT == "wide" else (xb, xa)
+        pred_bra = self.bra_model.classify(x1, x2)
+        ops.nonfinite_count([pred_bra], self.d_health)
+        return dict(pred_bra=pred_bra)
+
     def _g_ego(self, cmd_value):
         up, features = self.infer_model.uniplanner, self.b_features
         ego_crop = up.crop_feature(features, self.b_zero[:, :2], self.b_zero[0, :1], up.pixels_per_meter / 2, up.crop_size, amax=ops.amax_of(features))
@@ -434,8 +449,15 @@ class GraphedFramePipeline(FramePipeline):
         if not brake_late:
             self.s_bra.wait_event(self.ev_in)
             with torch.cuda.stream(self.s_bra):
-                o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
+                if _BRAKE_SPLIT:
+                    self._replay("brake_a", self._g_brake_a, self.s_bra)
+                else:
+                    o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
         self.ev_feat.record(main)                                      # feature map complete
+        if _BRAKE_SPLIT and not brake_late:
+            self.s_bra.wait_event(self.ev_feat)
+            with torch.cuda.stream(self.s_bra):
+                o_bra = self._replay("brake_b", self._g_brake_b, self.s_bra)
         if brake_late:
             self.s_bra.wait_event(self.ev_feat)
             with torch.cuda.stream(self.s_bra):

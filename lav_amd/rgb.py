@@ -156,28 +156,38 @@ class RGBBrakePredictionModel(nn.Module):
         self.attn2 = Attention(512, num_heads=8)
         self.classifier = nn.Sequential(nn.Linear(1024, 1), nn.Sigmoid())
 
-    def forward(self, rgb1, rgb2, mask=False):
-        if not self.training and rgb1.is_cuda and rgb1.dtype == torch.float32 and rgb1.shape[2] * rgb1.shape[3] % 4 == 0 \
-                and rgb2.shape[2] * rgb2.shape[3] % 4 == 0:
+    def trunk(self, rgb):
+        """One image through normalize + the shared ResNet-18 (eval HIP path when the image allows it) - forward's first half, also
+        called by the frame pipeline when it runs the two images' trunks as separate graphs."""
+        if not self.training and rgb.is_cuda and rgb.dtype == torch.float32 and rgb.shape[2] * rgb.shape[3] % 4 == 0:
             # normalize(rgb / 255) = rgb * (1 / (255 std)) - mean / std: one launch per image instead of three
             st = self.__dict__.get("_norm_affine")      # (constants of the module: computed once per device, not per frame)
-            if st is None or st[0].device != rgb1.device:
+            if st is None or st[0].device != rgb.device:
                 std, mean = self.normalize.std.detach().double(), self.normalize.mean.detach().double()
-                st = ((1.0 / (255.0 * std)).float().reshape(-1).to(rgb1.device), (-mean / std).float().reshape(-1).to(rgb1.device))
+                st = ((1.0 / (255.0 * std)).float().reshape(-1).to(rgb.device), (-mean / std).float().reshape(-1).to(rgb.device))
                 object.__setattr__(self, "_norm_affine", st)
             s_, t_ = st
-            x1 = self.conv_backbone(ops.channel_affine(rgb1, s_, t_))
-            x2 = self.conv_backbone(ops.channel_affine(rgb2, s_, t_))
-        else:
-            x1 = self.conv_backbone(self.normalize(rgb1 / 255.))
-            x2 = self.conv_backbone(self.normalize(rgb2 / 255.))
-        if not self.training and x1.is_cuda and x1.shape[0] == 1 and not mask:
+            return self.conv_backbone(ops.channel_affine(rgb, s_, t_))
+        return self.conv_backbone(self.normalize(rgb / 255.))
+
+    def classify(self, x1, x2):
+        """Both attention poolings + Linear(1024, 1) + sigmoid on the fused HIP path (batch 1, eval), else None."""
+        if not self.training and x1.is_cuda and x1.shape[0] == 1:
             # both pooled vectors land in one (1, 1024) buffer (no cat), classifier = one small launch (no library GEMM)
             both = torch.empty((1, 2 * x1.shape[1]), dtype=torch.float32, device=x1.device)
             C = x1.shape[1]
             self.attn1(x1, out=both[:, :C]); self.attn2(x2, out=both[:, C:])
             lin = self.classifier[0]
             return ops.linear_act(both, lin.weight, lin.bias, sigmoid=True)[:, 0]
+        return None
+
+    def forward(self, rgb1, rgb2, mask=False):
+        x1 = self.trunk(rgb1)
+        x2 = self.trunk(rgb2)
+        if not mask:
+            pred = self.classify(x1, x2)
+            if pred is not None:
+                return pred
         pred = self.classifier(torch.cat([self.attn1(x1), self.attn2(x2)], dim=1))
         if mask:
             return pred[:, 0], F.interpolate(self.seg_head(x1), scale_factor=4), F.interpolate(self.seg_head(x2), scale_factor=4)
