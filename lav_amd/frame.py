@@ -25,7 +25,9 @@ _COPY_STREAM = os.environ.get("LAV_COPY_STREAM", "0") == "1"   # the frame's dev
 _DET_REPORT = os.environ.get("LAV_DET_REPORT", "1") != "0"   # round 6: lav_det_decode writes the peak rows + count into pinned host memory itself and bumps a sequence word the host polls (no device->host copies, no event between the heads and the others graph)
 _POSE_BLOCK = os.environ.get("LAV_POSE_BLOCK", "1") != "0"   # round 6: the 176-byte pose block rides in the staging launch's kernel arguments (no upload of its own in front of the lidar graph)
 _BRAKE_AFTER = os.environ.get("LAV_BRAKE_AFTER", "in")       # "in": the brake graph starts with the frame (beside ERFNet + backbone); "feat": behind the lidar graph (beside heads / others / ego)
-_BRAKE_SPLIT = os.environ.get("LAV_BRAKE_SPLIT", "")        # "" (one graph with the frame) | "wide" | "tele": two graphs, the second behind the lidar graph
+_BRAKE_SPLIT = os.environ.get("LAV_BRAKE_SPLIT", "wide")    # "wide" (round 6 default) | "tele": the brake net as two graphs on its stream - that image's trunk with the frame, the other's + poolings + classifier behind the lidar graph; "0": one graph with the frame
+if _BRAKE_SPLIT in ("0", "off", "none"):
+    _BRAKE_SPLIT = ""
 _DIAG_SKIP = set(filter(None, os.environ.get("LAV_DIAG_SKIP", "").split(",")))   # timing diagnosis: skip side graphs
 
 
@@ -297,8 +299,10 @@ class GraphedFramePipeline(FramePipeline):
         ops.nonfinite_count([pred_bra], self.d_health)
         return dict(pred_bra=pred_bra)
 
-    # LAV_BRAKE_SPLIT (round 6 experiment): the brake net as two graphs on its stream - the first image's trunk with the frame, the second
-    # image's trunk + poolings + classifier behind the lidar graph ("wide": wide image first; "tele": tele image first)
+    # LAV_BRAKE_SPLIT (round 6): the brake net as two graphs on its stream - the first image's trunk with the frame, the second image's trunk +
+    # poolings + classifier behind the lidar graph ("wide", the default: wide image first; "tele": tele image first).  The brake net costs the
+    # frame through the lidar graph it runs beside (0.18 ms): half of it leaves that prefix, the suffix - where the result is not needed before
+    # the frame's end - takes it: 1.969-1.982 vs 1.983-1.989 ms in three interleaved pairs (profiles/r06_frame_experiments.txt section 10)
     def _g_brake_a(self):
         first = self.b_rgbs if _BRAKE_SPLIT == "wide" else self.b_tel
         return dict(x=self.bra_model.trunk(first))
@@ -450,14 +454,16 @@ class GraphedFramePipeline(FramePipeline):
             self.s_bra.wait_event(self.ev_in)
             with torch.cuda.stream(self.s_bra):
                 if _BRAKE_SPLIT:
-                    self._replay("brake_a", self._g_brake_a, self.s_bra)
+                    self._replay("brake_a", self._g_brake_a, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake_a" in self.graphs)
                 else:
                     o_bra = self._replay("brake", self._g_brake, self.s_bra, _skip="brake" in _DIAG_SKIP and "brake" in self.graphs)
         self.ev_feat.record(main)                                      # feature map complete
         if _BRAKE_SPLIT and not brake_late:
-            self.s_bra.wait_event(self.ev_feat)
+            skip_b = "brake" in _DIAG_SKIP and "brake_b" in self.graphs
+            if not skip_b:
+                self.s_bra.wait_event(self.ev_feat)
             with torch.cuda.stream(self.s_bra):
-                o_bra = self._replay("brake_b", self._g_brake_b, self.s_bra)
+                o_bra = self._replay("brake_b", self._g_brake_b, self.s_bra, _skip=skip_b)
         if brake_late:
             self.s_bra.wait_event(self.ev_feat)
             with torch.cuda.stream(self.s_bra):
