@@ -93,7 +93,7 @@ def main():
         flops = 2.0 * y0.numel() * cin * k[0] * k[1] / (s * s if tr else 1)
         t0 = timed(lib, exact, x)
         print(f"{name:24s} fp32  {t0:8.1f} us {flops / t0 / 1e6:7.1f} TF/s  [{plan_str(lib, exact, B, H, W)}]", flush=True)
-        split = ConvLayer(w, precision=_lib.CONV_BF16X6, **kw)
+        split = ConvLayer(w, precision=_lib.CONV_F16X3 if os.environ.get("LAV_PROBE_PREC") == "f16" else _lib.CONV_BF16X6, **kw)   # (LAV_PROBE_PREC=f16: the frame's precision)
         t1 = timed(lib, split, x)
         err = (split(x) - y0).abs().max().item()
         print(f"{'':24s} auto  {t1:8.1f} us {flops / t1 / 1e6:7.1f} TF/s  [{plan_str(lib, split, B, H, W)}] max|diff| {err:.2e} (|y| max {y0.abs().max().item():.2f})", flush=True)
