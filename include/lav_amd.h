@@ -573,7 +573,8 @@ int lav_upconv_pointwise(int batch, int cin, int cout, int ih, int iw, int k, in
  *    One workgroup per image row; the intermediate stays in LDS.  Supported: w in {32, 64, 128},
  *    channels a multiple of 16 with ceil(channels/32) <= 128/w (ERFNet: 16@128, 64@64, 128@32).
  *    Weights: lav_conv1d_pair_pack_weights repacks a PyTorch [cout][cin][3] tensor (the unit kernel dimension
- *    squeezed) on the host; scale/shift/residual may be NULL.
+ *    squeezed) on the host into all the forms the kernels read - exact fp32, three bf16 pieces, two scaled fp16 pieces with
+ *    their scale and the largest L1 norm of a filter behind them (round 6) -; scale/shift/residual may be NULL.
  * ------------------------------------------------------------------------------------------ */
 size_t lav_conv1d_pair_packed_weight_floats(int channels);
 int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_packed);
@@ -584,12 +585,13 @@ int lav_conv1d_pair_pack_weights(int channels, const float *h_weight, float *h_p
  * (write-through stores + a per-row progress counter), its own row, the block residual and the next pair's first weights never
  * leave the CU.  residual[i] != 0: pair i adds the INPUT of pair i-1 (the block's input) before its ReLU; the run starts at a
  * block boundary.  out[i]: output buffer of pair i ([batch][channels][h][w] each, all distinct; out[npairs-1] is the result).
- * batch * h must not exceed the CU count (every row's workgroup waits for its neighbours'); bf16x6 precision only.  Waits are
+ * batch * h must not exceed the CU count (every row's workgroup waits for its neighbours'); three bf16 pieces per operand (lav_conv1d_pair_chain_f16: two fp16 pieces).  Waits are
  * bounded: a workgroup that gives up raises the launch's abort word (its peers poll it and stop waiting too), fills ITS row of
  * out[npairs-1] with NaN - a voided launch cannot be mistaken for a result: every row of the output is either the complete result or
  * NaN (round 5) - and raises a sticky counter: lav_conv1d_pair_chain_status copies {workgroups that gave up, launches}
  * since the workspace was zero-filled (it SYNCHRONISES `stream`; 0 = every result was valid).
- * workspace: lav_conv1d_pair_chain_workspace_bytes, ZERO before its first use, private to the stream.
+ * workspace: lav_conv1d_pair_chain_workspace_bytes (sticky counters | one progress counter per row, capacity rounded up to 64 rows | the fp16
+ * runs' 16 x capacity count-and-maximum words), ZERO before its first use, private to the stream.
  */
 size_t lav_conv1d_pair_chain_workspace_bytes(int batch, int h);
 size_t lav_conv1d_pair_chain_lds_bytes(int channels, int w, int d_b_max);
@@ -601,7 +603,7 @@ int lav_conv1d_pair_chain(int batch, int channels, int h, int w, int npairs, con
  * three matrix products instead of three bf16 pieces and six (LAV_CONV_F16X3 for ERFNet's runs: half the matrix instructions, 2/3 of the
  * weight bytes a row streams per pair).  The weights' scale comes from lav_conv1d_pair_pack_weights (which packs all three forms); the
  * activations' scale is derived per workgroup and pair from the largest finite magnitude of the three rows it multiplies (the
- * neighbours' maxima travel with the hand-off), the intermediate row's from a bound (largest input x largest L1 norm of a filter +
+ * neighbours' maxima travel IN the hand-off's flag: one 64-bit word {pairs done | row maximum} per pair and row), the intermediate row's from a bound (largest input x largest L1 norm of a filter +
  * largest |bias|).  Error: that of an fp32 dot product (tests/test_gpu_conv.py, against float64); not bit-identical to the bf16 run. */
 int lav_conv1d_pair_chain_f16(int batch, int channels, int h, int w, int npairs, const int *d_a, const int *d_b, const int *residual,
                               const int *relu_post, const float *x, const float *const *wa_packed, const float *const *bias_a,
