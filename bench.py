@@ -759,7 +759,7 @@ def main():
                                         f"({n_pts} pts x 11) + 3x288x256 RGB + 288x480 tele; ERFNet seg, paint, pillar 320x320x64, "
                                         "BEV backbone+heads, uniplanner (cast+plan GRUs), brake net",
                                parallelism=f"replicas x{world}" if world > 1 else "single GPU", vehicles_detected=len(out["det"][1]),
-                               launch="eager" if args.eager else "hip graphs: lidar / heads / others (capacity 15, device-resident count) on the main stream, brake and ego[cmd] on side streams"),
+                               launch="eager" if args.eager else "hip graphs: lidar / heads / others (capacity 15, device-resident count) on the main stream, brake_a (with the frame) + brake_b (behind the lidar graph) and ego[cmd] on side streams"),
                    roofline=roofline, roofline_pillar_isolated=micro, roofline_mfma=conv_roof, roofline_hbm_glue=glue,
                    forced_others=forced, hip_kernel_us_per_frame=per_frame_us,
                    health=health, last_frame_outputs_finite=host_finite, plan_vs_step_path_max_abs=plan_dev, chain_only_ms=chain_ms,
