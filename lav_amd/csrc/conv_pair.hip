@@ -866,9 +866,15 @@ __device__ __forceinline__ void pair_split2h(float u0, float u1, unsigned &q0, u
     q1 = __builtin_bit_cast(unsigned, h1);
 }
 
-template <int KS, int R>
+// TRACE (LAV_PAIR_CHAIN_TRACE): as in the bf16 run - thread 0 of every workgroup accumulates the shader-clock cycles of each phase into a.trace[workgroup][8]:
+// 0 whole run, 1 hand-off waits, 2 neighbour rows + own row (loads, conversion, LDS), 3 barrier, 4 phase A, 5 combine + intermediate row, 6 phase B,
+// 7 epilogue + publication
+template <int KS, int R, bool TRACE = false>
 __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16Args fa) {
     const PairChainArgs &a = fa.c;
+    long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0, tr_t0 = 0;
+    if constexpr (TRACE) { tr_t0 = tr_t = clock64(); }
+#define CH_MARK(i) do { if constexpr (TRACE) { const long long now_ = clock64(); tr_acc[i] += now_ - tr_t; tr_t = now_; } } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wid8 = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
     const int wid = wid8 & 3, kpart = wid8 >> 2;
@@ -1061,6 +1067,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                 for (int i = tid; i < C * W; i += 256 * KS) o[(long)(i / W) * plane + (i % W)] = __uint_as_float(0x7fc00000u);
                 return;
             }
+            CH_MARK(1);
             m3 = s_m3;
             const float inv = 1.f / f16_scale_of(m3);
             (void)stage_load(a.out[p - 1], dA, std::false_type{}, true);
@@ -1080,7 +1087,9 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                 }
             }
         }
+        CH_MARK(2);
         __syncthreads();
+        CH_MARK(3);
         const float sx = f16_scale_of(m3);
         // |relu(conv + bias)| <= (largest input) x (largest L1 norm of a filter) + largest |bias|: the intermediate row's scale without a reduction
         const float smid = f16_scale_of(fminf(fmaf(m3, l1A, fmaxf(s_bmax[0], s_bmax[1])), 3.0e38f));
@@ -1111,6 +1120,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                 }
             }
         }
+        CH_MARK(4);
         if constexpr (KS == 2) {
             if (kpart == 1) {
 #pragma unroll
@@ -1141,6 +1151,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
         }
         __syncthreads();
 
+        CH_MARK(5);
         // ---- phase B: horizontal taps over the intermediate; the ring is refilled with the NEXT pair's first vertical fragments
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1179,6 +1190,7 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
         }
         // ---- epilogue: bias, BatchNorm, block residual, ReLU; the row goes out write-through, stays in registers for the next pair, and
         //      leaves its largest finite magnitude
+        CH_MARK(6);
         float lm = 0.f;
         if (co_ok && kpart == 0) {
 #pragma unroll
@@ -1217,8 +1229,16 @@ __global__ __launch_bounds__(256 * KS) void k_conv1d_pair_chain_f16(PairChainF16
                 __hip_atomic_store(fa.rowmax + (long)p * rm_stride + n * H + y, ((unsigned long long)(p + 1) << 32) | __float_as_uint(m_own), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
+        CH_MARK(7);
         if (*(volatile int *)&s_abort) return;
     }
+    if constexpr (TRACE) {
+        CH_MARK(7);
+        tr_acc[0] = clock64() - tr_t0;
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) a.trace[(long)blockIdx.x * 8 + i] = tr_acc[i];
+    }
+#undef CH_MARK
 }
 
 // fp32 floats of the exact packing of one convolution of a pair
@@ -1535,7 +1555,28 @@ static int pair_chain_launch(bool f16, int batch, int channels, int h, int w, in
         /* (the residency rule above was checked with the bf16 run's LDS size: this run claims what THAT one would, so the same rows per CU) */ \
         hipLaunchKernelGGL((k_conv1d_pair_chain_f16<KS_, R_>), dim3(batch * h), dim3(256 * KS_), \
                            std::min(cap, std::max(lds16, lav::lds_claim(lds, F16_STATIC_LDS, batch * h > cus))), st, fa); }
+        static const bool want_trace16 = getenv("LAV_PAIR_CHAIN_TRACE") != nullptr;
+        if (want_trace16 && ks2 == 2 && ring2 == 2 && batch * h <= 512) {
+            static long long *d_trace16 = nullptr;
+            if (!d_trace16) LAV_HIP(hipMalloc(&d_trace16, (size_t)512 * 8 * sizeof(long long)));
+            fa.c.trace = d_trace16;
+            static bool attr_t = false;
+            if (!attr_t) { LAV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv1d_pair_chain_f16<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_t = true; }
+            hipLaunchKernelGGL((k_conv1d_pair_chain_f16<2, 2, true>), dim3(batch * h), dim3(512), std::max(lds16, lav::lds_claim(lds, F16_STATIC_LDS, batch * h > cus)), st, fa);
+            static int runs16 = 0;
+            if (++runs16 % 10 == 0) {
+                std::vector<long long> hst((size_t)batch * h * 8);
+                if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hst.data(), d_trace16, hst.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                    double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int i = 0; i < batch * h; ++i) for (int k = 0; k < 8; ++k) m[k] += (double)hst[(size_t)i * 8 + k];
+                    const double f = 1.0 / (batch * h) / npairs;
+                    fprintf(stderr, "[pair chain f16 trace] C %d W %d, %d rows, %d pairs: cycles per pair and workgroup: all %.0f | hand-off wait %.0f | neighbour + own rows %.0f | barrier %.0f | phase A %.0f | combine+mid %.0f | phase B %.0f | epilogue+publish %.0f\n",
+                            channels, w, batch * h, npairs, m[0] * f, m[1] * f, m[2] * f, m[3] * f, m[4] * f, m[5] * f, m[6] * f, m[7] * f);
+                }
+            }
+        } else {
         LAV_CHAIN16_CASE(1, 1) LAV_CHAIN16_CASE(1, 2) LAV_CHAIN16_CASE(2, 1) LAV_CHAIN16_CASE(2, 2)
+        }
 #undef LAV_CHAIN16_CASE
         timer_end(tok, st);
         LAV_LAUNCH_CHECK();
