@@ -239,3 +239,41 @@ def test_module_level_extract_peak_keeps_the_reference_signature():
     assert len(got) == len(want) > 0
     for (s, x, y), (ws, wx, wy) in zip(got, want):
         assert abs(s - ws) < 2e-7 and (x, y) == (wx, wy)
+
+
+def test_frame_knobs_do_not_change_the_frame(tmp_path):
+    """The launch-plumbing knobs of round 6 choose HOW a frame is enqueued, never what it computes: the default (peak rows reported through
+    pinned memory, pose block in the staging launch's arguments, the brake net as two graphs) against every knob switched back
+    (LAV_DET_REPORT=0 LAV_POSE_BLOCK=0 LAV_BRAKE_SPLIT=0: copies + event, an upload of its own, one brake graph), each in a process of
+    its own (the knobs are read at import): the brake prediction, the plan, the detections' rows and the other vehicles' forecasts of
+    four frames agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = tmp_path / "frames.py"
+    worker.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {repo!r})\n"
+        "import bench\n"
+        "dev = torch.device('cuda', 0)\n"
+        "pipe, _, _ = bench.build_pipeline(dev)\n"
+        "host, d = bench.synthetic_inputs(dev)\n"
+        "out = {}\n"
+        "for i in range(5):\n"
+        "    loc, ori = bench.pose(i)\n"
+        "    o = pipe.step(d['ticks'][i % len(d['ticks'])], d['all_rgbs'], d['rgbs'], d['tel_rgbs'], loc, ori, d['nxp'], 3)\n"
+        "    torch.cuda.synchronize()\n"
+        "    if o is None: continue\n"
+        "    out[f'bra{i}'] = o['pred_bra'].cpu().numpy(); out[f'plan{i}'] = o['ego_plan_locs'].cpu().numpy()\n"
+        "    out[f'cast{i}'] = o['other_cast_locs'].cpu().numpy(); out[f'det{i}'] = pipe.hn_det.copy()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    got = {}
+    for name, env in (("default", {}), ("knobs_off", {"LAV_DET_REPORT": "0", "LAV_POSE_BLOCK": "0", "LAV_BRAKE_SPLIT": "0"})):
+        f = tmp_path / f"{name}.npz"
+        r = subprocess.run([sys.executable, str(worker), str(f)], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = dict(np.load(f))
+    assert got["default"].keys() == got["knobs_off"].keys() and len(got["default"]) == 16
+    for k in got["default"]:
+        np.testing.assert_array_equal(got["default"][k], got["knobs_off"][k], err_msg=k)
